@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Run only in the build container (the reference never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+The reference modules (TSPEnv, CVRPEnv, AttentionModelPolicy, decoding strategies,
+PointerAttention ...) are imported unmodified from /root/reference through the
+container stand-ins of `_refshim.py` (tensordict/torchrl are absent; they carry no
+arithmetic of this path).  Weights are the closed-form `goldweights` streams, instances
+come from the reference generators under a pinned torch seed, and for sampling cases the
+Exp(1) noise consumed by `torch.multinomial` is recorded so a
+deterministic implementation can replay it.
+
+Each fixture holds inputs (locs/demand, noise), per-step decoder outputs for the steps
+listed in `steps_kept`, and the rollout outputs (actions, reward, log-likelihood).
+Torch version used is stored in every file.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import _refshim  # noqa: E402
+
+_refshim.install()
+
+import torch  # noqa: E402
+
+import goldweights  # noqa: E402
+import rl4co.utils.decoding as ref_decoding  # noqa: E402
+from rl4co.envs.routing.cvrp.env import CVRPEnv  # noqa: E402
+from rl4co.envs.routing.tsp.env import TSPEnv  # noqa: E402
+from rl4co.models.zoo.am.policy import AttentionModelPolicy  # noqa: E402
+
+torch.set_num_threads(1)  # results are thread-count invariant; 1 keeps the run reproducible
+
+
+def make_policy(env_name, **kw):
+    pol = AttentionModelPolicy(env_name=env_name, **kw).eval()
+    sd = pol.state_dict()
+    new = goldweights.fill_state_dict(sd)
+    for k, v in new.items():
+        sd[k].copy_(torch.from_numpy(v))
+    return pol
+
+
+class Recorder:
+    """Records decoder logits / masks, processed logprobs and multinomial noise."""
+
+    def __init__(self, policy):
+        self.policy = policy
+        self.logits, self.masks, self.logprobs, self.noise = [], [], [], []
+
+    def __enter__(self):
+        dec = self.policy.decoder
+        self._dec_fwd = dec.forward
+
+        def fwd(td, cached, num_starts=0):
+            logits, mask = self._dec_fwd(td, cached, num_starts)
+            self.logits.append(logits.detach().clone())
+            self.masks.append(mask.detach().clone())
+            return logits, mask
+
+        dec.forward = fwd
+
+        self._pl = ref_decoding.process_logits
+
+        def pl(*a, **k):
+            out = self._pl(*a, **k)
+            self.logprobs.append(out.detach().clone())
+            return out
+
+        ref_decoding.process_logits = pl
+
+        self._mn = torch.multinomial
+
+        def mn(probs, num_samples, *a, **k):
+            state = torch.get_rng_state()
+            res = self._mn(probs, num_samples, *a, **k)
+            after = torch.get_rng_state()
+            torch.set_rng_state(state)
+            q = torch.empty_like(probs).exponential_(1)
+            replay = torch.argmax(probs / q, dim=-1, keepdim=True)
+            assert torch.equal(replay, res), "multinomial != argmax(p / Exp(1)) replay"
+            torch.set_rng_state(after)
+            self.noise.append(q.clone())
+            return res
+
+        torch.multinomial = mn
+        return self
+
+    def __exit__(self, *exc):
+        self.policy.decoder.forward = self._dec_fwd
+        ref_decoding.process_logits = self._pl
+        torch.multinomial = self._mn
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_starts=None,
+             keep_steps=None, keep_embeds=False, data_seed=1234, sample_seed=4321, actions=None,
+             td_init=None):
+    Env = TSPEnv if env_name == "tsp" else CVRPEnv
+    env = Env(generator_params=dict(num_loc=num_loc), seed=data_seed)
+    if td_init is None:
+        torch.manual_seed(data_seed)
+        td_init = env.reset(batch_size=[batch])
+    policy = make_policy(env_name, **(policy_kw or {}))
+    kw = dict(decode_type=decode_type)
+    if num_starts is not None:
+        kw["num_starts"] = num_starts
+    torch.manual_seed(sample_seed)
+    with torch.inference_mode(), Recorder(policy) as rec:
+        out = policy(td_init.clone(), env, phase="test", return_hidden=keep_embeds,
+                     return_init_embeds=keep_embeds, return_sum_log_likelihood=False,
+                     actions=actions, **kw)
+    T = len(rec.logits)
+    steps = list(range(T)) if keep_steps is None else [s for s in keep_steps if s < T]
+    fx = {
+        "torch_version": np.array(torch.__version__),
+        "env_name": np.array(env_name),
+        "decode_type": np.array(decode_type if actions is None else "evaluate"),
+        "num_starts": np.array(0 if num_starts is None else num_starts, dtype=np.int64),
+        "data_seed": np.array(data_seed, dtype=np.int64),
+        "locs": np_(td_init["locs"]),
+        "actions": np_(out["actions"]),
+        "reward": np_(out["reward"]),
+        "logp_steps": np_(out["log_likelihood"]),          # [B(*S), T(+1)] per-step selected logp
+        "log_likelihood": np_(out["log_likelihood"].sum(1)),
+        "steps_kept": np.array(steps, dtype=np.int64),
+        "step_logits": np.stack([np_(rec.logits[s]) for s in steps], 1),      # raw decoder logits
+        "step_logprobs": np.stack([np_(rec.logprobs[s]) for s in steps], 1),  # after process_logits
+        "step_mask": np.stack([np_(rec.masks[s]) for s in steps], 1),
+        "n_decoder_steps": np.array(T, dtype=np.int64),
+    }
+    if env_name == "cvrp":
+        fx["demand"] = np_(td_init["demand"])
+        fx["vehicle_capacity"] = np_(td_init["vehicle_capacity"])
+    if rec.noise:
+        fx["noise"] = np.stack([np_(q) for q in rec.noise], 1)  # [rows, T, M] Exp(1) draws
+    if policy_kw:
+        for k, v in policy_kw.items():
+            fx["policy_kw_" + k] = np.array(v)
+    if keep_embeds:
+        cache = out["hidden"]  # PrecomputedCache after the decoder's pre_decoder_hook
+        fx["init_embeds"] = np_(out["init_embeds"])
+        fx["embeddings"] = np_(cache.node_embeddings)
+        fx["glimpse_key"] = np_(cache.glimpse_key)
+        fx["glimpse_val"] = np_(cache.glimpse_val)
+        fx["logit_key"] = np_(cache.logit_key)
+        gc = cache.graph_context
+        fx["graph_context"] = np_(gc) if isinstance(gc, torch.Tensor) else np.zeros((0,), np.float32)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"{name}: T={T} reward[:3]={fx['reward'][:3]} -> {os.path.getsize(path) / 1024:.0f} KiB")
+    return fx, td_init
+
+
+def run_env_case(name, env_name, num_loc, batch, data_seed=99, act_seed=7):
+    """Env-only golden: random feasible policy, every state tensor after every step."""
+    Env = TSPEnv if env_name == "tsp" else CVRPEnv
+    env = Env(generator_params=dict(num_loc=num_loc), seed=data_seed)
+    torch.manual_seed(data_seed)
+    gen = env.generator(batch_size=[batch])
+    fx = {"torch_version": np.array(torch.__version__), "env_name": np.array(env_name),
+          "data_seed": np.array(data_seed, dtype=np.int64), "num_loc": np.array(num_loc, dtype=np.int64)}
+    for k, v in gen.items():
+        fx["gen_" + k] = np_(v)
+    td = env.reset(gen.clone())
+    fx["reset_action_mask"] = np_(td["action_mask"])
+    torch.manual_seed(act_seed)
+    per = {k: [] for k in ("action", "action_mask", "done", "current_node")}
+    extra = ("first_node", "i") if env_name == "tsp" else ("used_capacity", "visited")
+    for k in extra:
+        per[k] = []
+    while not td["done"].all():
+        td = ref_decoding.random_policy(td)
+        td = env.step(td)["next"]
+        for k in per:
+            per[k].append(np_(td[k]).copy())
+    for k, v in per.items():
+        fx["step_" + k] = np.stack(v, 1)
+    actions = torch.from_numpy(fx["step_action"])
+    fx["reward"] = np_(env.get_reward(td, actions))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"{name}: T={actions.shape[1]} reward[:3]={fx['reward'][:3]} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    first4 = [0, 1, 2, 3]
+    # ---- TSP (configs C1/C2 shapes, scaled-down batch) --------------------------------------
+    run_case("tsp20_greedy", "tsp", 20, 4, "greedy", keep_embeds=True)
+    fx, td0 = run_case("tsp20_sampling", "tsp", 20, 4, "sampling")
+    run_case("tsp20_evaluate", "tsp", 20, 4, "sampling", actions=torch.from_numpy(fx["actions"]), td_init=td0)
+    run_case("tsp20_multistart_greedy", "tsp", 20, 4, "multistart_greedy", num_starts=20, keep_steps=first4)
+    run_case("tsp100_greedy", "tsp", 100, 16, "greedy", keep_steps=first4 + [50, 99])
+    run_case("tsp100_sampling", "tsp", 100, 8, "sampling", keep_steps=first4)
+    # ---- CVRP (C3 shapes) -------------------------------------------------------------------
+    run_case("cvrp20_greedy", "cvrp", 20, 4, "greedy", keep_embeds=True)
+    fx, td0 = run_case("cvrp20_sampling", "cvrp", 20, 4, "sampling")
+    run_case("cvrp20_evaluate", "cvrp", 20, 4, "sampling", actions=torch.from_numpy(fx["actions"]), td_init=td0)
+    run_case("cvrp20_multistart_greedy", "cvrp", 20, 4, "multistart_greedy", num_starts=20, keep_steps=first4)
+    run_case("cvrp100_greedy", "cvrp", 100, 16, "greedy", keep_steps=first4 + [50])
+    run_case("cvrp100_sampling", "cvrp", 100, 16, "sampling", keep_steps=first4)
+    # ---- POMO policy defaults (C4 shapes): 6 layers, instance norm, no graph context ----------
+    pomo = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False)
+    run_case("pomo_tsp20_multistart_sampling", "tsp", 20, 4, "multistart_sampling", policy_kw=pomo,
+             num_starts=20, keep_steps=first4, keep_embeds=True)
+    # ---- env-only (integer / bool state machine) ------------------------------------------------
+    run_env_case("env_tsp20_random", "tsp", 20, 8)
+    run_env_case("env_cvrp20_random", "cvrp", 20, 8)
+    run_env_case("env_cvrp100_random", "cvrp", 100, 4)
+
+
+if __name__ == "__main__":
+    main()
