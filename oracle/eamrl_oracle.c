@@ -1,0 +1,626 @@
+/*
+ * eamrl_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the reference's batched autoregressive construction rollout
+ * (RL4CO fork at /root/reference; paths below are relative to it) with a DEFINED
+ * floating-point evaluation order, so that the hand-written HIP kernels can be held to
+ * bit-for-bit equality with it.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product path never does.
+ *
+ * Parity status: PINNED -- this oracle is checked against golden vectors produced by
+ * running the reference itself (tests/golden/make_golden.py, tests/test_oracle_golden.py):
+ * identical actions / masks / integer state, float outputs within the tolerances written
+ * in those tests (the reference's torch CPU kernels have no defined summation order, so
+ * float equality with them is tolerance-level by nature, SURVEY.md section 7 hard part 1).
+ *
+ * What each function follows:
+ *   orc_linear ................ torch.nn.Linear as used by every projection below
+ *   orc_mha_encoder ........... rl4co/models/nn/attention.py:66-136 (MultiHeadAttention)
+ *   orc_batchnorm_eval ........ rl4co/models/nn/ops.py:32-47  (BatchNorm1d, eval mode)
+ *   orc_instancenorm .......... rl4co/models/nn/ops.py:48-49  (InstanceNorm1d, affine)
+ *   orc_init_embed_* .......... rl4co/models/nn/env_embeddings/init.py:55-68,115-138
+ *   orc_mean_nodes ............ rl4co/models/zoo/am/decoder.py:225-227 (embeddings.mean(1))
+ *   orc_decode_step ........... rl4co/models/zoo/am/decoder.py:133-198 (_compute_q/_compute_kvl/forward),
+ *                               rl4co/models/nn/env_embeddings/context.py:50-74,105-157,
+ *                               rl4co/models/nn/attention.py:282-328 (PointerAttention),
+ *                               rl4co/utils/decoding.py:140-190 (process_logits), 391-417, 430-465
+ *   orc_tsp_step .............. rl4co/envs/routing/tsp/env.py:62-88
+ *   orc_cvrp_step ............. rl4co/envs/routing/cvrp/env.py:68-100,132-144
+ *   orc_cvrp_mask ............. rl4co/envs/routing/cvrp/env.py:132-144
+ *   orc_tour_length ........... rl4co/utils/ops.py:59-95 + tsp/env.py:152-159 + cvrp/env.py:146-155
+ *   orc_check_tsp/cvrp ........ tsp/env.py:161-168, cvrp/env.py:157-185
+ *   orc_rollout ............... rl4co/models/common/constructive/base.py:236-250 (decode loop)
+ *
+ * DEFINED ORDER (DESIGN.md "Canonical arithmetic"):
+ *   chain(x,y,K,init): acc=init; for k ascending: acc=fmaf(x[k],y[k],acc).  This is exactly
+ *   what gfx950's f32 MFMA computes along its K dimension, and what a lane-sequential loop does.
+ *   lane_tree(v,n): pad to a multiple of 64 with +0; inside each 64-block add adjacent pairs level
+ *   by level (the result of a xor-butterfly over a 64-lane wavefront); add block sums ascending.
+ *   Transcendentals are the polynomial d_expf/d_logf/d_tanhf below (only fmaf/mul/add/div, all
+ *   IEEE-exact), never libm, so CPU and GPU agree bit-for-bit.
+ *
+ * Build: gcc -O2 -ffp-contract=off (see Makefile).  -ffp-contract=off is REQUIRED.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+enum { ORC_ENV_TSP = 0, ORC_ENV_CVRP = 1 };
+enum { ORC_GREEDY = 0, ORC_SAMPLE = 1, ORC_EVALUATE = 2 };
+#define ORC_NCHUNK 4 /* node chunks for the glimpse accumulation, column chunks for the logit dot */
+
+/* ------------------------------------------------------------------------------------------
+ * defined transcendentals
+ * ---------------------------------------------------------------------------------------- */
+static inline float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* exp(x) for x <= 88; returns 0 below -87 (results stay normal numbers). */
+static float d_expf(float x)
+{
+    if (!(x >= -87.0f)) return 0.0f;      /* also maps -inf (and NaN) to 0 */
+    if (x > 88.0f) x = 88.0f;
+    float t = x * 1.44269504088896341f;
+    float n = rintf(t);                    /* round-half-even == v_rndne_f32 */
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = fmaf(p, r2, r) + 1.0f;
+    int ni = (int)n;
+    return y * bits2f((uint32_t)(ni + 127) << 23);
+}
+
+/* log(x) for normal positive x. */
+static float d_logf(float x)
+{
+    uint32_t u = f2bits(x);
+    int e = (int)(u >> 23) - 126;                         /* x = m * 2^e, m in [0.5,1) */
+    float m = bits2f((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+    float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, m, -1.1514610310e-1f);
+    p = fmaf(p, m, 1.1676998740e-1f);
+    p = fmaf(p, m, -1.2420140846e-1f);
+    p = fmaf(p, m, 1.4249322787e-1f);
+    p = fmaf(p, m, -1.6668057665e-1f);
+    p = fmaf(p, m, 2.0000714765e-1f);
+    p = fmaf(p, m, -2.4999993993e-1f);
+    p = fmaf(p, m, 3.3333331174e-1f);
+    float y = (p * m) * z;
+    float fe = (float)e;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    float r = m + y;
+    return fmaf(0.693359375f, fe, r);
+}
+
+static float d_tanhf(float x)
+{
+    float a = fabsf(x);
+    float t;
+    if (a < 0.625f) {
+        float z = a * a;
+        float p = -5.70498872745e-3f;
+        p = fmaf(p, z, 2.06390887954e-2f);
+        p = fmaf(p, z, -5.37397155531e-2f);
+        p = fmaf(p, z, 1.33314422036e-1f);
+        p = fmaf(p, z, -3.33332819422e-1f);
+        t = fmaf(p * z, a, a);
+    } else if (a > 9.0f) {
+        t = 1.0f;
+    } else {
+        float e = d_expf(a + a);
+        t = 1.0f - 2.0f / (e + 1.0f);
+    }
+    return copysignf(t, x);
+}
+
+ORC_API void orc_math_probe(const float* x, float* y_exp, float* y_log, float* y_tanh, long n)
+{
+    for (long i = 0; i < n; ++i) {
+        y_exp[i] = d_expf(x[i]);
+        y_log[i] = (x[i] > 0.0f) ? d_logf(x[i]) : 0.0f;
+        y_tanh[i] = d_tanhf(x[i]);
+    }
+}
+
+/* adjacent-pair tree inside 64-blocks, blocks ascending */
+static float lane_tree(const float* v, int n)
+{
+    float total = 0.0f;
+    for (int b0 = 0; b0 < n; b0 += 64) {
+        float t[64];
+        for (int i = 0; i < 64; ++i) t[i] = (b0 + i < n) ? v[b0 + i] : 0.0f;
+        for (int w = 1; w < 64; w <<= 1)
+            for (int i = 0; i < 64; i += 2 * w) t[i] = t[i] + t[i + w];
+        total = (b0 == 0) ? t[0] : total + t[0];
+    }
+    return total;
+}
+
+ORC_API float orc_lane_tree(const float* v, int n) { return lane_tree(v, n); }
+
+/* ------------------------------------------------------------------------------------------
+ * one-shot encoder pieces
+ * ---------------------------------------------------------------------------------------- */
+/* y[r][j] = chain_k x[r][k]*W[j][k], init bias[j] (or 0); optional ReLU.  W is [out][in] (torch). */
+ORC_API void orc_linear(const float* x, const float* W, const float* bias, float* y,
+                        long rows, int in_dim, int out_dim, int relu)
+{
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r) {
+        const float* xr = x + r * in_dim;
+        for (int j = 0; j < out_dim; ++j) {
+            const float* w = W + (long)j * in_dim;
+            float acc = bias ? bias[j] : 0.0f;
+            for (int k = 0; k < in_dim; ++k) acc = fmaf(xr[k], w[k], acc);
+            if (relu && !(acc > 0.0f)) acc = 0.0f;
+            y[r * out_dim + j] = acc;
+        }
+    }
+}
+
+/* y[r][j] = chain_k x[r][k]*Wt[k][j]  (right-multiply by a [in][out] matrix; used for Lp = L*Wout) */
+ORC_API void orc_matmul_right(const float* x, const float* Wt, float* y, long rows, int in_dim, int out_dim)
+{
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r) {
+        const float* xr = x + r * in_dim;
+        for (int j = 0; j < out_dim; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < in_dim; ++k) acc = fmaf(xr[k], Wt[(long)k * out_dim + j], acc);
+            y[r * out_dim + j] = acc;
+        }
+    }
+}
+
+/* Encoder self-attention on packed qkv [B][N][3E] ("b s (three h d)"), no mask.
+ * s = chain_d(q,k)*scale ; w = exp(s-max) ; Z sequential ; o = chain_j(w, v) / Z. */
+ORC_API void orc_mha_encoder(const float* qkv, float* out, long B, int N, int E, int H)
+{
+    const int D = E / H;
+    const float scale = 1.0f / sqrtf((float)D);
+#pragma omp parallel for schedule(static)
+    for (long b = 0; b < B; ++b) {
+        float* s = (float*)malloc(sizeof(float) * N);
+        const float* base = qkv + b * (long)N * 3 * E;
+        for (int h = 0; h < H; ++h)
+            for (int i = 0; i < N; ++i) {
+                const float* q = base + (long)i * 3 * E + h * D;
+                float m = -INFINITY;
+                for (int j = 0; j < N; ++j) {
+                    const float* k = base + (long)j * 3 * E + E + h * D;
+                    float acc = 0.0f;
+                    for (int d = 0; d < D; ++d) acc = fmaf(q[d], k[d], acc);
+                    acc = acc * scale;
+                    s[j] = acc;
+                    if (acc > m) m = acc;
+                }
+                float Z = 0.0f;
+                for (int j = 0; j < N; ++j) { s[j] = d_expf(s[j] - m); Z = Z + s[j]; }
+                for (int d = 0; d < D; ++d) {
+                    float acc = 0.0f;
+                    for (int j = 0; j < N; ++j)
+                        acc = fmaf(s[j], base[(long)j * 3 * E + 2 * E + h * D + d], acc);
+                    out[(b * N + i) * (long)E + h * D + d] = acc / Z;
+                }
+            }
+        free(s);
+    }
+}
+
+/* x += y (residual) */
+ORC_API void orc_add_inplace(float* x, const float* y, long n)
+{
+    for (long i = 0; i < n; ++i) x[i] = x[i] + y[i];
+}
+
+/* BatchNorm1d eval: scale = gamma / sqrt(var + eps); shift = beta - mean*scale; y = fma(x, scale, shift) */
+ORC_API void orc_batchnorm_eval(float* x, long rows, int E, const float* gamma, const float* beta,
+                                const float* mean, const float* var, float eps)
+{
+    float* scale = (float*)malloc(sizeof(float) * E);
+    float* shift = (float*)malloc(sizeof(float) * E);
+    for (int e = 0; e < E; ++e) {
+        scale[e] = gamma[e] / sqrtf(var[e] + eps);
+        float ms = mean[e] * scale[e];
+        shift[e] = beta[e] - ms;
+    }
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r)
+        for (int e = 0; e < E; ++e) x[r * E + e] = fmaf(x[r * E + e], scale[e], shift[e]);
+    free(scale);
+    free(shift);
+}
+
+/* InstanceNorm1d(affine) over nodes per (instance, channel): sequential sums, biased variance. */
+ORC_API void orc_instancenorm(float* x, long B, int N, int E, const float* gamma, const float* beta, float eps)
+{
+#pragma omp parallel for schedule(static)
+    for (long b = 0; b < B; ++b)
+        for (int e = 0; e < E; ++e) {
+            float* col = x + b * (long)N * E + e;
+            float s = 0.0f;
+            for (int n = 0; n < N; ++n) s = s + col[(long)n * E];
+            float mean = s / (float)N;
+            float v = 0.0f;
+            for (int n = 0; n < N; ++n) { float d = col[(long)n * E] - mean; v = fmaf(d, d, v); }
+            float inv = 1.0f / sqrtf(v / (float)N + eps);
+            for (int n = 0; n < N; ++n) {
+                float d = col[(long)n * E] - mean;
+                col[(long)n * E] = fmaf(d * inv, gamma[e], beta[e]);
+            }
+        }
+}
+
+/* mean over nodes: sequential sum / M */
+ORC_API void orc_mean_nodes(const float* emb, float* out, long B, int M, int E)
+{
+    for (long b = 0; b < B; ++b)
+        for (int e = 0; e < E; ++e) {
+            float s = 0.0f;
+            for (int n = 0; n < M; ++n) s = s + emb[(b * M + n) * (long)E + e];
+            out[b * E + e] = s / (float)M;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * environments (integer / bool state machines)
+ * ---------------------------------------------------------------------------------------- */
+/* TSPEnv._step: mask is the action mask (1 = not visited). */
+ORC_API void orc_tsp_step(uint8_t* mask, int64_t* first, int64_t* cur, int64_t* istep,
+                          const int64_t* action, uint8_t* done, long R, int N)
+{
+    for (long r = 0; r < R; ++r) {
+        int64_t a = action[r];
+        if (istep[r] == 0) first[r] = a;
+        cur[r] = a;
+        mask[r * N + a] = 0;
+        istep[r] += 1;
+        int any = 0;
+        for (int n = 0; n < N; ++n) any |= mask[r * N + n];
+        done[r] = !any;
+    }
+}
+
+/* CVRPEnv.get_action_mask; M = N + 1 (depot = node 0) */
+ORC_API void orc_cvrp_mask(const uint8_t* visited, const float* used, const float* vcap, const float* demand,
+                           const int64_t* cur, uint8_t* mask, long R, long Binst, int N)
+{
+    const int M = N + 1;
+    for (long r = 0; r < R; ++r) {
+        const float* dem = demand + (r % Binst) * N;
+        float lim = vcap[r] + 1e-5f;
+        int any_free = 0;
+        for (int j = 0; j < N; ++j) {
+            float load = dem[j] + used[r];
+            int blocked = (visited[r * M + 1 + j] != 0) | (load > lim);
+            mask[r * M + 1 + j] = !blocked;
+            any_free |= !blocked;
+        }
+        int mask_depot = (cur[r] == 0) && any_free;
+        mask[r * M] = !mask_depot;
+    }
+}
+
+/* CVRPEnv._step (+ get_action_mask) */
+ORC_API void orc_cvrp_step(uint8_t* visited, float* used, const float* vcap, const float* demand,
+                           int64_t* cur, const int64_t* action, uint8_t* mask, uint8_t* done,
+                           long R, long Binst, int N)
+{
+    const int M = N + 1;
+    for (long r = 0; r < R; ++r) {
+        int64_t a = action[r];
+        int64_t di = a - 1; if (di < 0) di = 0; if (di > N - 1) di = N - 1;
+        float d = demand[(r % Binst) * N + di];
+        float nz = (a != 0) ? 1.0f : 0.0f;
+        used[r] = (used[r] + d) * nz;
+        visited[r * M + a] = 1;
+        cur[r] = a;
+        int cnt = 0;
+        for (int n = 0; n < M; ++n) cnt += visited[r * M + n];
+        done[r] = (cnt == M);
+    }
+    orc_cvrp_mask(visited, used, vcap, demand, cur, mask, R, Binst, N);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * decode step (decoder + process_logits + selection); one row = one instance or one (start,instance)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int env;            /* ORC_ENV_* */
+    long R;             /* rows */
+    long Binst;         /* instances owning the cache; row r uses instance r % Binst */
+    int M, E, H;
+    const float *K, *V, *Lp;      /* [Binst][M][E] glimpse key, glimpse value, folded logit key */
+    const float *Pa, *Pb;         /* TSP: P1 (first) / P2 (current); CVRP: Pc / NULL   [Binst][M][E] */
+    const float *cvec;            /* TSP: c0[E] (placeholder query); CVRP: wcap[E] */
+    const float *gctx;            /* [Binst][E] or NULL */
+    float clip, temp;
+} orc_dec_t;
+
+static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, int64_t istep, float remaining,
+                      const uint8_t* mask, int mode, const float* noise, int64_t given,
+                      int64_t* out_action, float* out_logp, float* out_logits, float* out_logprobs, float* scratch)
+{
+    const int M = c->M, E = c->E, H = c->H, D = E / H;
+    const long bi = r % c->Binst;
+    const float* K = c->K + bi * (long)M * E;
+    const float* V = c->V + bi * (long)M * E;
+    const float* Lp = c->Lp + bi * (long)M * E;
+    float* q = scratch;                 /* E */
+    float* heads = q + E;               /* E */
+    float* w = heads + E;               /* H*M */
+    float* x = w + (long)H * M;         /* M */
+    float* ex = x + M;                  /* M */
+
+    /* D1 query */
+    for (int e = 0; e < E; ++e) {
+        float g = c->gctx ? c->gctx[bi * E + e] : 0.0f;
+        float ctx;
+        if (c->env == ORC_ENV_TSP) {
+            if (istep == 0) ctx = c->cvec[e];
+            else ctx = c->Pa[(bi * M + first) * (long)E + e] + c->Pb[(bi * M + cur) * (long)E + e];
+        } else {
+            ctx = fmaf(c->cvec[e], remaining, c->Pa[(bi * M + cur) * (long)E + e]);
+        }
+        q[e] = ctx + g;
+    }
+    /* D2-D4 glimpse */
+    const int C = (M + ORC_NCHUNK - 1) / ORC_NCHUNK;
+    const float qk_scale = 1.0f / sqrtf((float)D);
+    for (int h = 0; h < H; ++h) {
+        float* wh = w + (long)h * M;
+        float mx = -INFINITY;
+        for (int n = 0; n < M; ++n) {
+            if (!mask[n]) { wh[n] = -INFINITY; continue; }
+            float acc = 0.0f;
+            for (int d = 0; d < D; ++d) acc = fmaf(q[h * D + d], K[(long)n * E + h * D + d], acc);
+            acc = acc * qk_scale;                 /* 1/sqrt(D); D=16 -> exactly 0.25 */
+            wh[n] = acc;
+            if (acc > mx) mx = acc;
+        }
+        for (int n = 0; n < M; ++n) wh[n] = mask[n] ? d_expf(wh[n] - mx) : 0.0f;
+        float Z = 0.0f;
+        for (int g = 0; g < ORC_NCHUNK; ++g) {
+            float zg = 0.0f;
+            for (int n = g * C; n < M && n < (g + 1) * C; ++n) zg = zg + wh[n];
+            Z = (g == 0) ? zg : Z + zg;
+        }
+        for (int d = 0; d < D; ++d) {
+            float A = 0.0f;
+            for (int g = 0; g < ORC_NCHUNK; ++g) {
+                float ag = 0.0f;
+                for (int n = g * C; n < M && n < (g + 1) * C; ++n)
+                    ag = fmaf(wh[n], V[(long)n * E + h * D + d], ag);
+                A = (g == 0) ? ag : A + ag;
+            }
+            heads[h * D + d] = A / Z;
+        }
+    }
+    /* D5-D6 logits, clip, mask, temperature */
+    const int EC = E / ORC_NCHUNK;
+    const float sqrtE = sqrtf((float)E);
+    float mx = -INFINITY;
+    int nan_seen = 0;
+    for (int n = 0; n < M; ++n) {
+        float u = 0.0f;
+        for (int g = 0; g < ORC_NCHUNK; ++g) {
+            float cg = 0.0f;
+            for (int e = g * EC; e < (g + 1) * EC; ++e) cg = fmaf(heads[e], Lp[(long)n * E + e], cg);
+            u = (g == 0) ? cg : u + cg;
+        }
+        float logit = u / sqrtE;
+        if (logit != logit) nan_seen = 1;
+        if (out_logits) out_logits[n] = logit;
+        float v = (c->clip > 0.0f) ? d_tanhf(logit) * c->clip : logit;
+        if (!mask[n]) v = -INFINITY;
+        v = v / c->temp;
+        x[n] = v;
+        if (v > mx) mx = v;
+    }
+    /* D7 log-softmax */
+    for (int n = 0; n < M; ++n) ex[n] = mask[n] ? d_expf(x[n] - mx) : 0.0f;
+    float lse = d_logf(lane_tree(ex, M));
+    for (int n = 0; n < M; ++n) {
+        x[n] = mask[n] ? (x[n] - mx) - lse : -INFINITY;
+        if (out_logprobs) out_logprobs[n] = x[n];
+    }
+    /* D8 selection (lowest index wins ties, as torch.argmax) */
+    int64_t a = 0;
+    if (mode == ORC_EVALUATE) {
+        a = given;
+    } else if (mode == ORC_GREEDY) {
+        float best = x[0];
+        for (int n = 1; n < M; ++n) if (x[n] > best) { best = x[n]; a = n; }
+    } else {
+        float best = d_expf(x[0]) / noise[0];
+        for (int n = 1; n < M; ++n) {
+            float rr = d_expf(x[n]) / noise[n];
+            if (rr > best) { best = rr; a = n; }
+        }
+    }
+    *out_action = a;
+    *out_logp = x[a];
+    return nan_seen ? -1 : (mask[a] ? 0 : -2);
+}
+
+/* One decode step for R rows.  State arrays are per row.  mask: [R][M] u8 (1 = feasible).
+ * remaining capacity (CVRP) = vcap - used is computed here, as VRPContext._state_embedding does.
+ * noise: [R][M] or NULL; given: [R] or NULL; out_logits/out_logprobs: [R][M] or NULL.
+ * Returns 0, -1 (NaN logits), -2 (infeasible action selected). */
+ORC_API int orc_decode_step(int env, long R, long Binst, int M, int E, int H,
+                            const float* K, const float* V, const float* Lp,
+                            const float* Pa, const float* Pb, const float* cvec, const float* gctx,
+                            const int64_t* first, const int64_t* cur, const int64_t* istep,
+                            const float* used, const float* vcap, const uint8_t* mask,
+                            int mode, const float* noise, const int64_t* given, float clip, float temp,
+                            int64_t* out_action, float* out_logp, float* out_logits, float* out_logprobs)
+{
+    orc_dec_t c = { env, R, Binst, M, E, H, K, V, Lp, Pa, Pb, cvec, gctx, clip, temp };
+    int status = 0;
+#pragma omp parallel
+    {
+        float* scratch = (float*)malloc(sizeof(float) * (2 * (long)E + (long)H * M + 2 * (long)M));
+#pragma omp for schedule(static)
+        for (long r = 0; r < R; ++r) {
+            float rem = (env == ORC_ENV_CVRP) ? (vcap[r] - used[r]) : 0.0f;
+            int st = decode_row(&c, r, first ? first[r] : 0, cur[r], istep ? istep[r] : 1, rem,
+                                mask + r * (long)M, mode, noise ? noise + r * (long)M : NULL,
+                                given ? given[r] : 0, out_action + r, out_logp + r,
+                                out_logits ? out_logits + r * (long)M : NULL,
+                                out_logprobs ? out_logprobs + r * (long)M : NULL, scratch);
+            if (st != 0) {
+#pragma omp critical
+                if (status == 0) status = st;
+            }
+        }
+        free(scratch);
+    }
+    return status;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * reward and validity
+ * ---------------------------------------------------------------------------------------- */
+/* Closed tour length over `actions` [R][T] into locs [Binst][M][2]; with_depot prepends node 0.
+ * out = -length (the reward). */
+ORC_API void orc_tour_length(const float* locs, const int64_t* actions, float* reward,
+                             long R, long Binst, int M, int T, int with_depot)
+{
+#pragma omp parallel
+    {
+        const int P = T + (with_depot ? 1 : 0);
+        float* d = (float*)malloc(sizeof(float) * P);
+#pragma omp for schedule(static)
+        for (long r = 0; r < R; ++r) {
+            const float* L = locs + (r % Binst) * (long)M * 2;
+            for (int t = 0; t < P; ++t) {
+                int64_t a0, a1;
+                if (with_depot) {
+                    a0 = (t == 0) ? 0 : actions[r * T + t - 1];
+                    a1 = (t + 1 == P) ? 0 : actions[r * T + t];
+                } else {
+                    a0 = actions[r * T + t];
+                    a1 = actions[r * T + ((t + 1 == P) ? 0 : t + 1)];
+                }
+                float dx = L[2 * a1] - L[2 * a0];
+                float dy = L[2 * a1 + 1] - L[2 * a0 + 1];
+                d[t] = sqrtf(fmaf(dy, dy, dx * dx));
+            }
+            reward[r] = -lane_tree(d, P);
+        }
+        free(d);
+    }
+}
+
+/* sum of per-step selected log-probs, sequential over t */
+ORC_API void orc_sum_logp(const float* logp, float* out, long R, int T)
+{
+    for (long r = 0; r < R; ++r) {
+        float s = 0.0f;
+        for (int t = 0; t < T; ++t) s = s + logp[r * T + t];
+        out[r] = s;
+    }
+}
+
+/* TSP: every node exactly once.  Returns the number of invalid rows. */
+ORC_API long orc_check_tsp(const int64_t* actions, long R, int N)
+{
+    long bad = 0;
+    uint8_t* seen = (uint8_t*)malloc(N);
+    for (long r = 0; r < R; ++r) {
+        memset(seen, 0, N);
+        int ok = 1;
+        for (int t = 0; t < N; ++t) {
+            int64_t a = actions[r * N + t];
+            if (a < 0 || a >= N || seen[a]) { ok = 0; break; }
+            seen[a] = 1;
+        }
+        bad += !ok;
+    }
+    free(seen);
+    return bad;
+}
+
+/* CVRP: customers exactly once, any number of depot visits, running load <= cap + 1e-5.
+ * Returns invalid-tour rows + 1000000 * over-capacity rows. */
+ORC_API long orc_check_cvrp(const int64_t* actions, const float* demand, const float* vcap,
+                            long R, long Binst, int N, int T)
+{
+    long bad_tour = 0, bad_cap = 0;
+    uint8_t* seen = (uint8_t*)malloc(N + 1);
+    for (long r = 0; r < R; ++r) {
+        memset(seen, 0, N + 1);
+        int ok = 1;
+        for (int t = 0; t < T; ++t) {
+            int64_t a = actions[r * T + t];
+            if (a < 0 || a > N) { ok = 0; break; }
+            if (a != 0) { if (seen[a]) { ok = 0; break; } seen[a] = 1; }
+        }
+        for (int n = 1; n <= N && ok; ++n) if (!seen[n]) ok = 0;
+        bad_tour += !ok;
+        if (!ok) continue;
+        float usedc = 0.0f, lim = vcap[r] + 1e-5f;
+        int over = 0;
+        for (int t = 0; t < T; ++t) {
+            int64_t a = actions[r * T + t];
+            float dd = (a == 0) ? -vcap[r] : demand[(r % Binst) * N + a - 1];
+            usedc = usedc + dd;
+            if (usedc < 0.0f) usedc = 0.0f;
+            if (usedc > lim) over = 1;
+        }
+        bad_cap += over;
+    }
+    free(seen);
+    return bad_tour + 1000000 * bad_cap;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * whole rollout: decode step + env step until every row is done (ConstructivePolicy.forward loop)
+ * ---------------------------------------------------------------------------------------- */
+/* State in/out as for the step functions.  actions/logps: [R][Tmax] (row-major, right-padded as the
+ * reference does: finished CVRP rows keep choosing the depot).  noise: [R][Tmax][M] or NULL;
+ * given: [R][Tgiven] or NULL (teacher forcing).  Returns the number of steps taken, or <0 on error. */
+ORC_API int orc_rollout(int env, long R, long Binst, int M, int E, int H,
+                        const float* K, const float* V, const float* Lp,
+                        const float* Pa, const float* Pb, const float* cvec, const float* gctx,
+                        int64_t* first, int64_t* cur, int64_t* istep,
+                        float* used, const float* vcap, const float* demand,
+                        uint8_t* mask, uint8_t* visited, uint8_t* done,
+                        int mode, const float* noise, const int64_t* given, int Tgiven,
+                        float clip, float temp, int Tmax,
+                        int64_t* actions, float* logps)
+{
+    int64_t* a = (int64_t*)malloc(sizeof(int64_t) * R);
+    float* lp = (float*)malloc(sizeof(float) * R);
+    float* nz = noise ? (float*)malloc(sizeof(float) * R * M) : NULL;
+    int64_t* gv = given ? (int64_t*)malloc(sizeof(int64_t) * R) : NULL;
+    int t = 0, status = 0;
+    for (;;) {
+        int all_done = 1;
+        for (long r = 0; r < R; ++r) if (!done[r]) { all_done = 0; break; }
+        if (all_done || t >= Tmax) break;
+        if (noise) for (long r = 0; r < R; ++r) memcpy(nz + r * M, noise + (r * (long)Tmax + t) * M, sizeof(float) * M);
+        if (given) for (long r = 0; r < R; ++r) gv[r] = (t < Tgiven) ? given[r * (long)Tgiven + t] : 0;
+        status = orc_decode_step(env, R, Binst, M, E, H, K, V, Lp, Pa, Pb, cvec, gctx, first, cur, istep,
+                                 used, vcap, mask, mode, nz, gv, clip, temp, a, lp, NULL, NULL);
+        if (status != 0) break;
+        for (long r = 0; r < R; ++r) { actions[r * (long)Tmax + t] = a[r]; logps[r * (long)Tmax + t] = lp[r]; }
+        if (env == ORC_ENV_TSP) orc_tsp_step(mask, first, cur, istep, a, done, R, M);
+        else orc_cvrp_step(visited, used, vcap, demand, cur, a, mask, done, R, Binst, M - 1);
+        ++t;
+    }
+    free(a); free(lp); free(nz); free(gv);
+    return status != 0 ? status : t;
+}

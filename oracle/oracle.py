@@ -1,0 +1,343 @@
+"""ctypes front-end of the CPU oracle (test infrastructure -- see eamrl_oracle.c header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+Arrays are numpy; weights are a {state_dict key: np.float32 array} mapping using the
+reference's key names (tests/golden/state_dict_contract.json).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ENV_TSP, ENV_CVRP = 0, 1
+GREEDY, SAMPLE, EVALUATE = 0, 1, 2
+MODES = {"greedy": GREEDY, "sampling": SAMPLE, "evaluate": EVALUATE}
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _cpu_has_fma() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fl = line.split()
+                    return "fma" in fl and "avx2" in fl
+    except OSError:
+        pass
+    return False
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        name = "liboracle.so" if _cpu_has_fma() else "liboracle_generic.so"
+        path = os.path.join(_HERE, "build", name)
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_lane_tree.restype = C.c_float
+        _LIB.orc_check_tsp.restype = C.c_long
+        _LIB.orc_check_cvrp.restype = C.c_long
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------
+# primitive wrappers
+# ---------------------------------------------------------------------------------------------
+def math_probe(x):
+    x = _f32(x).ravel()
+    e, l, t = (np.empty_like(x) for _ in range(3))
+    lib().orc_math_probe(_p(x), _p(e), _p(l), _p(t), C.c_long(x.size))
+    return e, l, t
+
+
+def lane_tree(v):
+    v = _f32(v).ravel()
+    return np.float32(lib().orc_lane_tree(_p(v), C.c_int(v.size)))
+
+
+def linear(x, W, b=None, relu=False):
+    x = _f32(x)
+    W = _f32(W)
+    rows = int(np.prod(x.shape[:-1]))
+    y = np.empty(x.shape[:-1] + (W.shape[0],), np.float32)
+    bb = None if b is None else _f32(b)
+    lib().orc_linear(_p(x), _p(W), _p(bb), _p(y), C.c_long(rows), C.c_int(W.shape[1]), C.c_int(W.shape[0]),
+                     C.c_int(int(relu)))
+    return y
+
+
+def matmul_right(x, Wt):
+    x = _f32(x)
+    Wt = _f32(Wt)
+    rows = int(np.prod(x.shape[:-1]))
+    y = np.empty(x.shape[:-1] + (Wt.shape[1],), np.float32)
+    lib().orc_matmul_right(_p(x), _p(Wt), _p(y), C.c_long(rows), C.c_int(Wt.shape[0]), C.c_int(Wt.shape[1]))
+    return y
+
+
+def mha_encoder(qkv, H):
+    qkv = _f32(qkv)
+    B, N, E3 = qkv.shape
+    out = np.empty((B, N, E3 // 3), np.float32)
+    lib().orc_mha_encoder(_p(qkv), _p(out), C.c_long(B), C.c_int(N), C.c_int(E3 // 3), C.c_int(H))
+    return out
+
+
+def batchnorm_eval(x, gamma, beta, mean, var, eps=1e-5):
+    x = _f32(x).copy()
+    E = x.shape[-1]
+    lib().orc_batchnorm_eval(_p(x), C.c_long(x.size // E), C.c_int(E), _p(_f32(gamma)), _p(_f32(beta)),
+                             _p(_f32(mean)), _p(_f32(var)), C.c_float(eps))
+    return x
+
+
+def instancenorm(x, gamma, beta, eps=1e-5):
+    x = _f32(x).copy()
+    B, N, E = x.shape
+    lib().orc_instancenorm(_p(x), C.c_long(B), C.c_int(N), C.c_int(E), _p(_f32(gamma)), _p(_f32(beta)),
+                           C.c_float(eps))
+    return x
+
+
+def mean_nodes(emb):
+    emb = _f32(emb)
+    B, M, E = emb.shape
+    out = np.empty((B, E), np.float32)
+    lib().orc_mean_nodes(_p(emb), _p(out), C.c_long(B), C.c_int(M), C.c_int(E))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# encoder + cache (AttentionModelEncoder.forward, AttentionModelDecoder._precompute_cache)
+# ---------------------------------------------------------------------------------------------
+def encode(sd, env_name, locs, demand=None, num_heads=8):
+    """-> (init_embeds, embeddings).  locs: TSP [B,N,2]; CVRP [B,N+1,2] with depot first."""
+    pre = "encoder.init_embedding."
+    if env_name == "tsp":
+        h = linear(locs, sd[pre + "init_embed.weight"], sd[pre + "init_embed.bias"])
+    else:
+        depot = linear(locs[:, :1], sd[pre + "init_embed_depot.weight"], sd[pre + "init_embed_depot.bias"])
+        feat = np.concatenate([_f32(locs[:, 1:]), _f32(demand)[..., None]], -1)
+        cust = linear(feat, sd[pre + "init_embed.weight"], sd[pre + "init_embed.bias"])
+        h = np.concatenate([depot, cust], 1)
+    init_h = h.copy()
+    layer = 0
+    while f"encoder.net.layers.{layer}.0.module.Wqkv.weight" in sd:
+        p = f"encoder.net.layers.{layer}."
+        qkv = linear(h, sd[p + "0.module.Wqkv.weight"], sd[p + "0.module.Wqkv.bias"])
+        att = mha_encoder(qkv, num_heads)
+        h = h + linear(att, sd[p + "0.module.out_proj.weight"], sd[p + "0.module.out_proj.bias"])
+        h = _norm(sd, p + "1.normalizer.", h)
+        f = linear(h, sd[p + "2.module.lins.0.weight"], sd[p + "2.module.lins.0.bias"], relu=True)
+        h = h + linear(f, sd[p + "2.module.lins.1.weight"], sd[p + "2.module.lins.1.bias"])
+        h = _norm(sd, p + "3.normalizer.", h)
+        layer += 1
+    return init_h, h
+
+
+def _norm(sd, p, h):
+    if p + "running_mean" in sd:
+        return batchnorm_eval(h, sd[p + "weight"], sd[p + "bias"], sd[p + "running_mean"], sd[p + "running_var"])
+    return instancenorm(h, sd[p + "weight"], sd[p + "bias"])
+
+
+def precompute(sd, env_name, emb, use_graph_context=True):
+    """K/V/L cache plus the folded tensors of DESIGN.md (Pa/Pb, cvec, Lp) and the graph context."""
+    emb = _f32(emb)
+    E = emb.shape[-1]
+    kvl = linear(emb, sd["decoder.project_node_embeddings.weight"])
+    K, V, L = (np.ascontiguousarray(kvl[..., i * E:(i + 1) * E]) for i in range(3))
+    Wctx = _f32(sd["decoder.context_embedding.project_context.weight"])
+    out = {"K": K, "V": V, "L": L, "Lp": matmul_right(L, sd["decoder.pointer.project_out.weight"])}
+    if env_name == "tsp":
+        out["Pa"] = linear(emb, np.ascontiguousarray(Wctx[:, :E]))
+        out["Pb"] = linear(emb, np.ascontiguousarray(Wctx[:, E:]))
+        out["cvec"] = linear(_f32(sd["decoder.context_embedding.W_placeholder"])[None], Wctx)[0]
+    else:
+        out["Pa"] = linear(emb, np.ascontiguousarray(Wctx[:, :E]))
+        out["Pb"] = None
+        out["cvec"] = np.ascontiguousarray(Wctx[:, E])
+    out["gctx"] = linear(mean_nodes(emb), sd["decoder.project_fixed_context.weight"]) if use_graph_context else None
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# env state + decode + rollout
+# ---------------------------------------------------------------------------------------------
+class State:
+    """Per-row rollout state in the oracle's flat layout (R rows over Binst instances)."""
+
+    def __init__(self, env_name, locs, demand=None, vehicle_capacity=1.0, num_starts=0):
+        self.env_name = env_name
+        self.env = ENV_TSP if env_name == "tsp" else ENV_CVRP
+        self.locs = _f32(locs)
+        self.Binst, self.M = self.locs.shape[:2]
+        S = max(int(num_starts), 1)
+        R = self.R = self.Binst * S
+        self.first = np.zeros(R, np.int64)
+        self.cur = np.zeros(R, np.int64)
+        self.istep = np.zeros(R, np.int64)
+        self.done = np.zeros(R, np.uint8)
+        self.used = np.zeros(R, np.float32)
+        self.vcap = np.full(R, vehicle_capacity, np.float32)
+        if env_name == "tsp":
+            self.demand = None
+            self.visited = None
+            self.mask = np.ones((R, self.M), np.uint8)
+        else:
+            self.demand = _f32(demand)
+            self.visited = np.zeros((R, self.M), np.uint8)
+            self.mask = np.empty((R, self.M), np.uint8)
+            lib().orc_cvrp_mask(_p(self.visited), _p(self.used), _p(self.vcap), _p(self.demand), _p(self.cur),
+                                _p(self.mask), C.c_long(R), C.c_long(self.Binst), C.c_int(self.M - 1))
+
+    def step(self, action):
+        a = _i64(action)
+        if self.env == ENV_TSP:
+            lib().orc_tsp_step(_p(self.mask), _p(self.first), _p(self.cur), _p(self.istep), _p(a), _p(self.done),
+                               C.c_long(self.R), C.c_int(self.M))
+        else:
+            lib().orc_cvrp_step(_p(self.visited), _p(self.used), _p(self.vcap), _p(self.demand), _p(self.cur),
+                                _p(a), _p(self.mask), _p(self.done), C.c_long(self.R), C.c_long(self.Binst),
+                                C.c_int(self.M - 1))
+
+
+def decode_step(st: State, cache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0, num_heads=8,
+                want_all=False):
+    R, M = st.R, st.M
+    E = cache["K"].shape[-1]
+    act = np.empty(R, np.int64)
+    lp = np.empty(R, np.float32)
+    logits = np.empty((R, M), np.float32) if want_all else None
+    logprobs = np.empty((R, M), np.float32) if want_all else None
+    nz = None if noise is None else _f32(noise)
+    gv = None if given is None else _i64(given)
+    rc = lib().orc_decode_step(
+        C.c_int(st.env), C.c_long(R), C.c_long(st.Binst), C.c_int(M), C.c_int(E), C.c_int(num_heads),
+        _p(cache["K"]), _p(cache["V"]), _p(cache["Lp"]), _p(cache["Pa"]), _p(cache["Pb"]), _p(cache["cvec"]),
+        _p(cache["gctx"]), _p(st.first), _p(st.cur), _p(st.istep), _p(st.used), _p(st.vcap), _p(st.mask),
+        C.c_int(MODES[mode]), _p(nz), _p(gv), C.c_float(clip), C.c_float(temp),
+        _p(act), _p(lp), _p(logits), _p(logprobs))
+    if rc == -1:
+        raise AssertionError("Logits contain NaNs")
+    if rc == -2:
+        raise AssertionError("infeasible action selected")
+    return (act, lp, logits, logprobs) if want_all else (act, lp)
+
+
+def rollout(st: State, cache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0, num_heads=8, t_max=None):
+    """Decode loop until every row is done.  -> (actions [R,T], logp [R,T])."""
+    R, M = st.R, st.M
+    E = cache["K"].shape[-1]
+    if t_max is None:
+        t_max = M if st.env == ENV_TSP else 2 * M + 1
+    if noise is not None:
+        noise = _f32(noise)
+        t_max = noise.shape[1]
+    tg = 0
+    if given is not None:
+        given = _i64(given)
+        tg = given.shape[1]
+        t_max = max(t_max, tg) if noise is None else t_max
+    actions = np.zeros((R, t_max), np.int64)
+    logps = np.zeros((R, t_max), np.float32)
+    T = lib().orc_rollout(
+        C.c_int(st.env), C.c_long(R), C.c_long(st.Binst), C.c_int(M), C.c_int(E), C.c_int(num_heads),
+        _p(cache["K"]), _p(cache["V"]), _p(cache["Lp"]), _p(cache["Pa"]), _p(cache["Pb"]), _p(cache["cvec"]),
+        _p(cache["gctx"]), _p(st.first), _p(st.cur), _p(st.istep), _p(st.used), _p(st.vcap), _p(st.demand),
+        _p(st.mask), _p(st.visited), _p(st.done), C.c_int(MODES[mode]), _p(noise), _p(given), C.c_int(tg),
+        C.c_float(clip), C.c_float(temp), C.c_int(t_max), _p(actions), _p(logps))
+    if T == -1:
+        raise AssertionError("Logits contain NaNs")
+    if T == -2:
+        raise AssertionError("infeasible action selected")
+    return np.ascontiguousarray(actions[:, :T]), np.ascontiguousarray(logps[:, :T])
+
+
+def tour_length_reward(locs, actions, with_depot, binst=None):
+    locs = _f32(locs)
+    actions = _i64(actions)
+    R, T = actions.shape
+    Binst, M = locs.shape[:2]
+    out = np.empty(R, np.float32)
+    lib().orc_tour_length(_p(locs), _p(actions), _p(out), C.c_long(R), C.c_long(Binst), C.c_int(M), C.c_int(T),
+                          C.c_int(int(with_depot)))
+    return out
+
+
+def sum_logp(logp):
+    logp = _f32(logp)
+    R, T = logp.shape
+    out = np.empty(R, np.float32)
+    lib().orc_sum_logp(_p(logp), _p(out), C.c_long(R), C.c_int(T))
+    return out
+
+
+def check_tsp(actions):
+    actions = _i64(actions)
+    return int(lib().orc_check_tsp(_p(actions), C.c_long(actions.shape[0]), C.c_int(actions.shape[1])))
+
+
+def check_cvrp(actions, demand, vcap):
+    actions = _i64(actions)
+    demand = _f32(demand)
+    R, T = actions.shape
+    vc = _f32(np.broadcast_to(np.asarray(vcap, np.float32).reshape(-1), (R,)))
+    return int(lib().orc_check_cvrp(_p(actions), _p(demand), _p(vc), C.c_long(R), C.c_long(demand.shape[0]),
+                                    C.c_int(demand.shape[1]), C.c_int(T)))
+
+
+def policy_rollout(sd, env_name, locs, demand=None, decode_type="greedy", num_starts=0, noise=None, given=None,
+                   use_graph_context=True, clip=10.0, temp=1.0, num_heads=8):
+    """ConstructivePolicy.forward restated on the oracle: encoder, cache, (multistart hook), loop, reward.
+
+    locs for CVRP already include the depot at index 0 (post-reset layout).
+    Returns dict(actions, logp_steps, log_likelihood, reward, steps).
+    """
+    _, emb = encode(sd, env_name, locs, demand, num_heads)
+    cache = precompute(sd, env_name, emb, use_graph_context)
+    multistart = "multistart" in decode_type and num_starts > 1
+    st = State(env_name, locs, demand, num_starts=num_starts if multistart else 0)
+    mode = "evaluate" if given is not None else ("greedy" if "greedy" in decode_type else "sampling")
+    pre_a, pre_lp = [], []
+    if multistart:
+        # select_start_nodes: row j = s*B + b starts at node s (TSP) / s+1 (CVRP)   [utils/ops.py:133-169]
+        B = st.Binst
+        nloc = st.M if env_name == "tsp" else st.M - 1
+        start = (np.repeat(np.arange(num_starts), B) % nloc + (0 if env_name == "tsp" else 1)).astype(np.int64)
+        if given is not None:
+            start, given = _i64(given[:, 0]), np.ascontiguousarray(given[:, 1:])
+        st.step(start)
+        pre_a, pre_lp = [start[:, None]], [np.zeros((st.R, 1), np.float32)]
+    acts, lps = rollout(st, cache, mode, noise=noise, given=given, clip=clip, temp=temp, num_heads=num_heads)
+    actions = np.concatenate(pre_a + [acts], 1)
+    logp = np.concatenate(pre_lp + [lps], 1)
+    reward = tour_length_reward(locs, actions, with_depot=(env_name != "tsp"))
+    return {"actions": actions, "logp_steps": logp, "log_likelihood": sum_logp(logp), "reward": reward,
+            "steps": acts.shape[1], "embeddings": emb, "cache": cache}

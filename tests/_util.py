@@ -1,0 +1,34 @@
+"""Shared helpers for the test-suite: golden fixtures + closed-form weights."""
+import json
+import os
+
+import numpy as np
+
+import goldweights  # tests/golden/goldweights.py (pure numpy)
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+with open(os.path.join(GOLDEN, "state_dict_contract.json")) as _f:
+    CONTRACT = json.load(_f)
+
+
+def golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def golden_weights(cfg):
+    """{key: float32 ndarray} for a contract config: am_tsp, am_cvrp, pomo_tsp, pomo_cvrp."""
+    sd = {}
+    for k, shape, dt in CONTRACT[cfg]:
+        if dt != "float32":
+            continue
+        v = goldweights.tensor_for(k, shape)
+        if v is not None:
+            sd[k] = v
+    return sd
+
+
+def cfg_for(fx):
+    pomo = "policy_kw_num_encoder_layers" in fx
+    return ("pomo_" if pomo else "am_") + str(fx["env_name"])

@@ -196,8 +196,27 @@ def run_env_case(name, env_name, num_loc, batch, data_seed=99, act_seed=7):
     print(f"{name}: T={actions.shape[1]} reward[:3]={fx['reward'][:3]} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def dump_state_dict_contract():
+    """Key names / shapes / dtypes of the reference policies' state_dict (the checkpoint contract)."""
+    import json
+    out = {}
+    cfgs = {
+        "am_tsp": dict(env_name="tsp"),
+        "am_cvrp": dict(env_name="cvrp"),
+        "pomo_tsp": dict(env_name="tsp", num_encoder_layers=6, normalization="instance", use_graph_context=False),
+        "pomo_cvrp": dict(env_name="cvrp", num_encoder_layers=6, normalization="instance", use_graph_context=False),
+    }
+    for name, kw in cfgs.items():
+        sd = AttentionModelPolicy(**kw).state_dict()
+        out[name] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
+    with open(os.path.join(HERE, "state_dict_contract.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("state_dict_contract.json:", {k: len(v) for k, v in out.items()})
+
+
 def main():
     first4 = [0, 1, 2, 3]
+    dump_state_dict_contract()
     # ---- TSP (configs C1/C2 shapes, scaled-down batch) --------------------------------------
     run_case("tsp20_greedy", "tsp", 20, 4, "greedy", keep_embeds=True)
     fx, td0 = run_case("tsp20_sampling", "tsp", 20, 4, "sampling")

@@ -1,0 +1,156 @@
+"""CPU: the C oracle against the golden vectors captured from the reference (tests/golden/make_golden.py).
+
+Integer / bool results (actions, masks, visited, done, step counts) must be IDENTICAL.
+Float results are compared with the tolerances below; the reference's torch CPU kernels have no
+defined summation order (SURVEY.md section 7 hard part 1), so float equality with them is
+tolerance-level by nature:
+    per-step logits / log-probs   abs 1e-5   (values are O(1..10))
+    rewards (tour lengths)        rel 1e-6
+    summed log-likelihood         rel 2e-6   (sum of up to ~115 terms of O(1..5))
+"""
+import numpy as np
+import pytest
+
+from _util import cfg_for, golden, golden_weights
+
+POLICY_CASES = [
+    "tsp20_greedy", "tsp20_sampling", "tsp20_evaluate", "tsp20_multistart_greedy", "tsp100_greedy", "tsp100_sampling",
+    "cvrp20_greedy", "cvrp20_sampling", "cvrp20_evaluate", "cvrp20_multistart_greedy", "cvrp100_greedy",
+    "cvrp100_sampling", "pomo_tsp20_multistart_sampling",
+]
+
+
+def _run(orc, fx):
+    sd = golden_weights(cfg_for(fx))
+    decode_type = str(fx["decode_type"])
+    given = fx["actions"] if decode_type == "evaluate" else None
+    ns = int(fx["num_starts"])
+    if ns > 1 and "multistart" not in decode_type:
+        decode_type = "multistart_" + decode_type
+    return orc.policy_rollout(
+        sd, str(fx["env_name"]), fx["locs"], fx.get("demand"), decode_type=decode_type, num_starts=ns,
+        noise=fx.get("noise"), given=given, use_graph_context=bool(fx.get("policy_kw_use_graph_context", True)))
+
+
+@pytest.mark.parametrize("name", POLICY_CASES)
+def test_policy_rollout_matches_reference(oracle, name):
+    fx = golden(name)
+    if name.endswith("evaluate"):
+        fx["decode_type"] = np.array("evaluate")
+    out = _run(oracle, fx)
+    assert out["actions"].shape == fx["actions"].shape
+    assert np.array_equal(out["actions"], fx["actions"]), "tours differ from the reference"
+    np.testing.assert_allclose(out["reward"], fx["reward"], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(out["logp_steps"], fx["logp_steps"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["log_likelihood"], fx["log_likelihood"], rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("name", ["tsp20_greedy", "cvrp20_greedy", "pomo_tsp20_multistart_sampling"])
+def test_encoder_and_cache_match_reference(oracle, name):
+    fx = golden(name)
+    sd = golden_weights(cfg_for(fx))
+    env = str(fx["env_name"])
+    init_h, emb = oracle.encode(sd, env, fx["locs"], fx.get("demand"))
+    np.testing.assert_allclose(init_h, fx["init_embeds"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(emb, fx["embeddings"], rtol=0, atol=1e-5)
+    use_gc = fx["graph_context"].size > 0
+    cache = oracle.precompute(sd, env, emb, use_graph_context=use_gc)
+    np.testing.assert_allclose(cache["K"], fx["glimpse_key"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(cache["V"], fx["glimpse_val"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(cache["L"], fx["logit_key"], rtol=0, atol=1e-5)
+    if use_gc:
+        np.testing.assert_allclose(cache["gctx"], fx["graph_context"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["tsp20_greedy", "tsp100_greedy", "cvrp20_greedy", "cvrp100_greedy",
+                                  "cvrp100_sampling", "tsp20_multistart_greedy"])
+def test_per_step_logits_logprobs_masks(oracle, name):
+    """Replay the reference's actions and compare raw decoder logits, processed log-probs and masks."""
+    fx = golden(name)
+    sd = golden_weights(cfg_for(fx))
+    env = str(fx["env_name"])
+    ns = int(fx["num_starts"])
+    _, emb = oracle.encode(sd, env, fx["locs"], fx.get("demand"))
+    cache = oracle.precompute(sd, env, emb)
+    st = oracle.State(env, fx["locs"], fx.get("demand"), num_starts=ns)
+    actions = fx["actions"]
+    col = 0
+    if ns > 1:
+        st.step(actions[:, 0])
+        col = 1
+    kept = {int(s): i for i, s in enumerate(fx["steps_kept"])}
+    for t in range(int(fx["n_decoder_steps"])):
+        a, lp, logits, logprobs = oracle.decode_step(st, cache, "evaluate", given=actions[:, col + t], want_all=True)
+        if t in kept:
+            i = kept[t]
+            ref_mask = fx["step_mask"][:, i].astype(bool)
+            assert np.array_equal(st.mask.astype(bool), ref_mask), f"mask differs at step {t}"
+            # the reference leaves the raw logits of masked nodes finite: compare feasible ones
+            np.testing.assert_allclose(logits[ref_mask], fx["step_logits"][:, i][ref_mask], rtol=0, atol=1e-5)
+            ref_lp = fx["step_logprobs"][:, i]
+            assert np.array_equal(np.isneginf(logprobs), np.isneginf(ref_lp))
+            np.testing.assert_allclose(logprobs[ref_mask], ref_lp[ref_mask], rtol=0, atol=1e-5)
+        st.step(a)
+    assert st.done.all()
+
+
+@pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random"])
+def test_env_state_machine_bit_exact(oracle, name):
+    fx = golden(name)
+    env = str(fx["env_name"])
+    if env == "tsp":
+        locs, demand = fx["gen_locs"], None
+    else:
+        locs = np.concatenate([fx["gen_depot"][:, None], fx["gen_locs"]], 1)
+        demand = fx["gen_demand"]
+    st = oracle.State(env, locs, demand)
+    assert np.array_equal(st.mask.astype(bool), fx["reset_action_mask"])
+    T = fx["step_action"].shape[1]
+    for t in range(T):
+        st.step(fx["step_action"][:, t])
+        assert np.array_equal(st.mask.astype(bool), fx["step_action_mask"][:, t]), t
+        assert np.array_equal(st.done.astype(bool), fx["step_done"][:, t]), t
+        assert np.array_equal(st.cur, fx["step_current_node"][:, t].reshape(-1)), t
+        if env == "tsp":
+            assert np.array_equal(st.first, fx["step_first_node"][:, t]), t
+            assert np.array_equal(st.istep, fx["step_i"][:, t].reshape(-1)), t
+        else:
+            assert np.array_equal(st.visited, fx["step_visited"][:, t]), t
+            # one fp32 add + one mul per step, no reductions: exactly reproducible
+            assert np.array_equal(st.used, fx["step_used_capacity"][:, t].reshape(-1)), t
+    reward = oracle.tour_length_reward(locs, fx["step_action"], with_depot=(env != "tsp"))
+    np.testing.assert_allclose(reward, fx["reward"], rtol=1e-6, atol=0)
+    if env == "tsp":
+        assert oracle.check_tsp(fx["step_action"]) == 0
+    else:
+        assert oracle.check_cvrp(fx["step_action"], demand, 1.0) == 0
+
+
+def test_validity_checks_reject_bad_tours(oracle):
+    fx = golden("env_cvrp20_random")
+    acts = fx["step_action"].copy()
+    assert oracle.check_cvrp(acts, fx["gen_demand"], 1.0) == 0
+    bad = acts.copy()
+    bad[0, np.nonzero(bad[0])[0][0]] = 0  # drop a customer
+    assert oracle.check_cvrp(bad, fx["gen_demand"], 1.0) % 1000000 == 1
+    over = np.tile(np.arange(1, 21, dtype=np.int64), (1, 1))  # one route serving everyone: over capacity
+    assert oracle.check_cvrp(over, fx["gen_demand"][:1], 1.0) // 1000000 == 1
+    t = golden("env_tsp20_random")["step_action"].copy()
+    assert oracle.check_tsp(t) == 0
+    t[1, 3] = t[1, 4]
+    assert oracle.check_tsp(t) == 1
+
+
+def test_defined_math_accuracy(oracle):
+    """d_expf/d_logf/d_tanhf stay within a few ulp of libm on the ranges the rollout uses."""
+    x = np.concatenate([np.linspace(-87, 0, 20001), np.linspace(0, 20, 4001)]).astype(np.float32)
+    e, _, t = oracle.math_probe(x)
+    ref_e = np.exp(x.astype(np.float64))
+    sel = x <= 0
+    assert np.max(np.abs(e[sel] - ref_e[sel]) / ref_e[sel]) < 4e-7
+    assert np.max(np.abs(t - np.tanh(x.astype(np.float64)))) < 3e-7
+    xl = np.linspace(1.0, 600.0, 30001).astype(np.float32)
+    _, l, _ = oracle.math_probe(xl)
+    assert np.max(np.abs(l - np.log(xl.astype(np.float64)))) < 6e-7
+    assert oracle.math_probe(np.array([1.0], np.float32))[1][0] == 0.0
+    assert oracle.math_probe(np.array([-np.inf, 0.0], np.float32))[0].tolist() == [0.0, 1.0]
