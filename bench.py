@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the AttentionModel construction rollout on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tsp100|cvrp100|tsp20|cvrp500] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full rollout of one batch: encoder + decoder cache + the whole decode loop (state update,
+mask, masked single-query attention, selection) + tour-length reward, inputs already resident in HBM
+(env.reset / instance generation excluded).  Default workload = BASELINE.json configs[1]:
+TSP num_loc=100, batch=1024, greedy.  Metric: env-steps/s = ranks * batch * num_loc * K / wall time.
+Multi-GPU: independent instance batches per rank (weak scaling), no data-path collective.
+
+Besides the contract keys the JSON line carries
+  roofline      the decode-loop kernel (the dominant hot-loop kernel): algorithmic bytes per launch
+                (154,852 B per TSP-100 decode step) / its mean duration measured with HIP events
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/) timed on this host's cores on a
+                bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (env, num_loc, default batch, decode type)
+    "tsp100": ("tsp", 100, 1024, "greedy"),        # BASELINE.json configs[1]  (headline)
+    "tsp20": ("tsp", 20, 128, "greedy"),           # configs[0]
+    "cvrp100": ("cvrp", 100, 1024, "sampling"),    # configs[2]
+    "cvrp500": ("cvrp", 500, 512, "greedy"),       # configs[4]
+}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_decode_step(env, M, E=128):
+    """12*M*E (K,V,L) + 4*E*g (context rows) + 2*M (mask r/w) + c."""
+    if env == "tsp":
+        return 12 * M * E + 4 * E * 2 + 2 * M + 28
+    return 12 * M * E + 4 * E * 1 + 2 * M + 32 + 2 * M
+
+
+def build_policy(env_name, device):
+    import eam_rl4co_amd as ea
+    from _util import golden_weights
+
+    pol = ea.AttentionModelPolicy(env_name=env_name).eval()
+    torch.manual_seed(0)
+    sd = pol.state_dict()
+    for k, v in golden_weights("am_" + env_name).items():   # deterministic closed-form weights (untrained)
+        sd[k].copy_(torch.from_numpy(v))
+    return pol.to(device)
+
+
+def cpu_baseline(env_name, num_loc, decode_type, seconds_budget=20.0):
+    """Time the CPU oracle on a bounded sample (batch chosen so the run takes ~10-30 s)."""
+    from _util import golden_weights
+    from oracle import oracle as orc
+    import eam_rl4co_amd as ea
+
+    threads = os.cpu_count() or 1
+    sd = golden_weights("am_" + env_name)
+    env = ea.get_env(env_name, generator_params=dict(num_loc=num_loc), seed=1234)
+
+    def run(batch):
+        torch.manual_seed(1234)
+        td = env.reset(batch_size=[batch])
+        locs = td["locs"].numpy()
+        demand = td["demand"].numpy() if env_name == "cvrp" else None
+        noise = None
+        if decode_type == "sampling":
+            M = locs.shape[1]
+            noise = torch.empty(batch, 2 * M + 1, M).exponential_(1).numpy()
+        t0 = time.perf_counter()
+        out = orc.policy_rollout(sd, env_name, locs, demand, decode_type=decode_type, noise=noise)
+        return time.perf_counter() - t0, out["steps"]
+
+    b = 16
+    t, _ = run(b)                                  # calibration (also warms the library)
+    target = max(b, int(b * min(seconds_budget / max(t, 1e-3), 64)))
+    target = min(target, 1024)
+    t, steps = run(target)
+    return {"value": round(target * num_loc / t, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{env_name.upper()}-{num_loc} {decode_type} rollout, batch={target}, {steps} decode steps, "
+                      f"{t:.2f} s on {threads} OpenMP threads (oracle/eamrl_oracle.c)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="tsp100", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import ops
+
+    env_name, num_loc, batch, decode_type = WORKLOADS[args.workload]
+    batch = args.batch or batch
+    env = ea.get_env(env_name, generator_params=dict(num_loc=num_loc), seed=1234 + rank)
+    torch.manual_seed(1234 + rank)
+    td0 = env.reset(batch_size=[batch]).to(device)         # synthetic uniform-[0,1]^2 instances, resident in HBM
+    policy = build_policy(env_name, device)
+    M = td0["locs"].shape[1]
+
+    # time the decode-loop kernel with HIP events on the launch stream (torch's current stream)
+    kernel_ms, decode_steps = [], []
+    orig_rollout = ops.rollout
+
+    def timed_rollout(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_rollout(*a, **k)
+        e1.record()
+        kernel_ms.append((e0, e1))
+        return r
+
+    def one_step():
+        out = policy(td0.clone(), env, phase="test", decode_type=decode_type)
+        return out
+
+    for _ in range(args.warmup):
+        out = one_step()
+    ops.rollout = timed_rollout
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+        decode_steps.append(out["actions"].shape[1])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.rollout = orig_rollout
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * batch * num_loc * args.steps / elapsed
+        kern = float(np.mean([a.elapsed_time(b) for a, b in kernel_ms]))
+        T = float(np.mean(decode_steps))
+        alg_bytes = algorithmic_bytes_per_decode_step(env_name, M) * batch * T
+        achieved = alg_bytes / (kern * 1e-3) / 1e9
+        line = {
+            "metric": "env-steps/sec (batch x num_loc / s), AttentionModel construction rollout",
+            "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{env_name.upper()} num_loc={num_loc} batch={batch}/GPU AM {decode_type} rollout "
+                                   f"(encoder + cache + decode loop + reward)",
+                       "decode_steps": T, "reward_mean": round(float(out["reward"].mean()), 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "decode loop (eamrl_am_rollout)", "kernel_ms": round(kern, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(env_name, num_loc, decode_type)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""ctypes binding of libeamrl_hip.so (include/eamrl.h).  There is no fallback: if the library is
+missing or cannot be loaded every native op raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libeamrl_hip.so")
+
+ENV_TSP, ENV_CVRP = 0, 1
+GREEDY, SAMPLE, EVALUATE = 0, 1, 2
+NORM_BATCH_EVAL, NORM_INSTANCE = 0, 1
+ST_NAN_LOGITS, ST_INFEASIBLE, ST_STEP_OVERRUN = 1, 2, 4
+
+_vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+
+class Cache(C.Structure):
+    """struct eamrl_cache"""
+    _fields_ = [("K", _vp), ("V", _vp), ("Lp", _vp), ("Pa", _vp), ("Pb", _vp), ("cvec", _vp), ("gctx", _vp),
+                ("ld", _i64), ("B", _i64), ("M", C.c_int32), ("E", C.c_int32), ("H", C.c_int32)]
+
+
+class State(C.Structure):
+    """struct eamrl_state"""
+    _fields_ = [("first", _vp), ("cur", _vp), ("istep", _vp), ("used", _vp), ("vcap", _vp), ("demand", _vp),
+                ("mask", _vp), ("visited", _vp), ("done", _vp)]
+
+
+# name -> argtypes (all return int unless listed in _RESTYPES); mirrors include/eamrl.h one to one
+PROTOTYPES = {
+    "eamrl_version": [],
+    "eamrl_last_error": [],
+    "eamrl_debug_set": [_i32, _i32],
+    "eamrl_tsp_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "eamrl_cvrp_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "eamrl_cvrp_step_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "eamrl_linear": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+    "eamrl_matmul_right": [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
+    "eamrl_mha_encoder": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "eamrl_normalize": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp],
+    "eamrl_mean_nodes": [_vp, _vp, _i64, _i32, _i32, _vp],
+    "eamrl_am_decode_step": [_i32, C.POINTER(Cache), C.POINTER(State), _i64, _i32, _vp, _vp, _f32, _f32, _i32,
+                             _vp, _vp, _vp, _vp, _vp, _vp],
+    "eamrl_am_rollout": [_i32, C.POINTER(Cache), C.POINTER(State), _i64, _i32, _vp, _vp, _i32, _f32, _f32, _i32,
+                         _vp, _vp, _vp, _vp, _vp],
+    "eamrl_tour_length": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+    "eamrl_sum_logp": [_vp, _i64, _vp, _i64, _i32, _vp],
+    "eamrl_check_solution": [_i32, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp],
+}
+_RESTYPES = {"eamrl_last_error": C.c_char_p}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libeamrl_hip.so.  torch must be imported first so that its bundled HIP runtime
+    (same SONAME libamdhip64.so.7) is the one the library binds to: one runtime per process."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads libamdhip64 with the SONAME we link against)
+
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m eam_rl4co_amd.build` (hipcc, gfx950). "
+            "eam_rl4co_amd has no CPU or PyTorch fallback for the rollout path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().eamrl_last_error()
+        raise RuntimeError(f"{what or 'eamrl'} failed ({rc}): {msg.decode() if msg else '?'}")

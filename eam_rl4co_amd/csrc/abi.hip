@@ -1,0 +1,229 @@
+// extern "C" boundary of libeamrl_hip.so (see include/eamrl.h).  Argument validation happens here,
+// before anything is enqueued: a kernel that faults can reset the whole GPU host, so every shape the
+// kernels index with is checked against what they assume.
+#include <cstdarg>
+#include <cstdio>
+
+#include "kernels.hpp"
+
+
+using namespace eamrl;
+
+namespace eamrl { int g_debug[8] = {0}; }
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int launched(int rc, const char* what)
+{
+    if (rc == 0) return 0;
+    if (rc == EAMRL_E_ARG) return fail(rc, "%s: unsupported shape", what);
+    return fail(rc, "%s: launch failed: %s", what, hipGetErrorString(hipGetLastError()));
+}
+
+#define REQUIRE(cond, what)                                                        \
+    do {                                                                           \
+        if (!(cond)) return fail(EAMRL_E_ARG, "%s: requirement failed: %s", what, #cond); \
+    } while (0)
+
+extern "C" {
+
+__attribute__((visibility("default"))) int eamrl_version(void) { return EAMRL_VERSION; }
+__attribute__((visibility("default"))) const char* eamrl_last_error(void) { return g_err; }
+__attribute__((visibility("default"))) int eamrl_debug_set(int key, int value)
+{
+    if (key < 0 || key >= 8) return fail(EAMRL_E_ARG, "eamrl_debug_set: unknown key %d", key);
+    g_debug[key] = value;
+    return 0;
+}
+
+__attribute__((visibility("default"))) int eamrl_tsp_step(uint8_t* mask, int64_t* first, int64_t* cur, int64_t* istep,
+                                                         const int64_t* action, uint8_t* done, int64_t R, int N,
+                                                         void* stream)
+{
+    REQUIRE(mask && first && cur && istep && action && done, "eamrl_tsp_step");
+    REQUIRE(R >= 0 && N > 0, "eamrl_tsp_step");
+    if (R == 0) return 0;
+    return launched(launch_tsp_step(mask, first, cur, istep, action, done, R, N, (hipStream_t)stream), "eamrl_tsp_step");
+}
+
+__attribute__((visibility("default"))) int eamrl_cvrp_mask(const uint8_t* visited, const float* used, const float* vcap,
+                                                          const float* demand, const int64_t* cur, uint8_t* mask,
+                                                          int64_t R, int64_t B, int N, void* stream)
+{
+    REQUIRE(visited && used && vcap && demand && cur && mask, "eamrl_cvrp_mask");
+    REQUIRE(R >= 0 && B > 0 && N > 0, "eamrl_cvrp_mask");
+    if (R == 0) return 0;
+    return launched(launch_cvrp(0, const_cast<uint8_t*>(visited), const_cast<float*>(used), vcap, demand,
+                                const_cast<int64_t*>(cur), nullptr, mask, nullptr, R, B, N, (hipStream_t)stream),
+                    "eamrl_cvrp_mask");
+}
+
+__attribute__((visibility("default"))) int eamrl_cvrp_step_mask(uint8_t* visited, float* used, const float* vcap,
+                                                               const float* demand, int64_t* cur, const int64_t* action,
+                                                               uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N,
+                                                               void* stream)
+{
+    REQUIRE(visited && used && vcap && demand && cur && action && mask && done, "eamrl_cvrp_step_mask");
+    REQUIRE(R >= 0 && B > 0 && N > 0, "eamrl_cvrp_step_mask");
+    if (R == 0) return 0;
+    return launched(launch_cvrp(1, visited, used, vcap, demand, cur, action, mask, done, R, B, N, (hipStream_t)stream),
+                    "eamrl_cvrp_step_mask");
+}
+
+__attribute__((visibility("default"))) int eamrl_linear(const float* x, int64_t ldx, const float* W, int64_t ldw,
+                                                       const float* bias, const float* res, int64_t ldres, float* y,
+                                                       int64_t ldy, int64_t rows, int in_dim, int out_dim, int relu,
+                                                       void* stream)
+{
+    REQUIRE(x && W && y, "eamrl_linear");
+    REQUIRE(rows >= 0 && in_dim > 0 && out_dim > 0, "eamrl_linear");
+    REQUIRE(ldx >= in_dim && ldw >= in_dim && ldy >= out_dim && (!res || ldres >= out_dim), "eamrl_linear");
+    REQUIRE((rows + 127) / 128 <= 0x7fffffffLL, "eamrl_linear");
+    GemmArgs g{x, ldx, W, ldw, 0, bias, res, ldres, y, ldy, rows, in_dim, out_dim, relu};
+    return launched(launch_linear(g, (hipStream_t)stream), "eamrl_linear");
+}
+
+__attribute__((visibility("default"))) int eamrl_matmul_right(const float* x, int64_t ldx, const float* Wt, float* y,
+                                                             int64_t ldy, int64_t rows, int in_dim, int out_dim,
+                                                             void* stream)
+{
+    REQUIRE(x && Wt && y, "eamrl_matmul_right");
+    REQUIRE(rows >= 0 && in_dim > 0 && out_dim > 0 && ldx >= in_dim && ldy >= out_dim, "eamrl_matmul_right");
+    GemmArgs g{x, ldx, Wt, out_dim, 1, nullptr, nullptr, 0, y, ldy, rows, in_dim, out_dim, 0};
+    return launched(launch_linear(g, (hipStream_t)stream), "eamrl_matmul_right");
+}
+
+__attribute__((visibility("default"))) int eamrl_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H,
+                                                            void* stream)
+{
+    REQUIRE(qkv && out, "eamrl_mha_encoder");
+    REQUIRE(B >= 0 && N > 0 && E > 0 && H > 0 && E % H == 0, "eamrl_mha_encoder");
+    if (B == 0) return 0;
+    return launched(launch_mha_encoder(qkv, out, B, N, E, H, (hipStream_t)stream), "eamrl_mha_encoder");
+}
+
+__attribute__((visibility("default"))) int eamrl_normalize(float* x, int64_t B, int N, int E, int kind,
+                                                          const float* gamma, const float* beta, const float* mean,
+                                                          const float* var, float eps, void* stream)
+{
+    REQUIRE(x && gamma && beta, "eamrl_normalize");
+    REQUIRE(B >= 0 && N > 0 && E > 0 && E <= 8192, "eamrl_normalize");
+    return launched(launch_normalize(x, B, N, E, kind, gamma, beta, mean, var, eps, (hipStream_t)stream),
+                    "eamrl_normalize");
+}
+
+__attribute__((visibility("default"))) int eamrl_mean_nodes(const float* emb, float* out, int64_t B, int M, int E,
+                                                           void* stream)
+{
+    REQUIRE(emb && out && B >= 0 && M > 0 && E > 0, "eamrl_mean_nodes");
+    return launched(launch_mean_nodes(emb, out, B, M, E, (hipStream_t)stream), "eamrl_mean_nodes");
+}
+
+static int fill_args(const char* what, int env, const eamrl_cache* c, const eamrl_state* s, int64_t R, int mode,
+                     const float* noise, const int64_t* given, float clip, float temp, uint32_t* status, DecArgs& a)
+{
+    REQUIRE(c && s, what);
+    REQUIRE(env == EAMRL_ENV_TSP || env == EAMRL_ENV_CVRP, what);
+    REQUIRE(mode == EAMRL_GREEDY || mode == EAMRL_SAMPLE || mode == EAMRL_EVALUATE, what);
+    REQUIRE(c->K && c->V && c->Lp && c->Pa && c->cvec, what);
+    REQUIRE(c->B > 0 && c->M > 0 && c->E > 0 && c->H > 0, what);
+    REQUIRE(c->E % c->H == 0 && (c->E / c->H) % 4 == 0 && c->E % (4 * EAMRL_NCHUNK) == 0, what);
+    REQUIRE(c->ld >= c->E && c->ld % 4 == 0, what);
+    REQUIRE(((uintptr_t)c->K % 16 == 0) && ((uintptr_t)c->V % 16 == 0) && ((uintptr_t)c->Lp % 16 == 0), what);
+    REQUIRE(R > 0 && R % c->B == 0 && R <= 0x7fffffffLL, what);
+    REQUIRE(s->cur && s->mask && status, what);
+    REQUIRE(temp > 0.0f, what);
+    if (env == EAMRL_ENV_TSP) REQUIRE(c->Pb && s->first && s->istep, what);
+    if (env == EAMRL_ENV_CVRP) REQUIRE(s->used && s->vcap && c->M >= 2, what);
+    if (mode == EAMRL_SAMPLE) REQUIRE(noise != nullptr, what);
+    if (mode == EAMRL_EVALUATE) REQUIRE(given != nullptr, what);
+    a = DecArgs{};
+    a.K = c->K; a.V = c->V; a.Lp = c->Lp; a.Pa = c->Pa; a.Pb = c->Pb; a.cvec = c->cvec; a.gctx = c->gctx;
+    a.ld = c->ld; a.B = c->B; a.M = c->M; a.E = c->E; a.H = c->H;
+    a.first = s->first; a.cur = s->cur; a.istep = s->istep; a.used = s->used; a.vcap = s->vcap; a.demand = s->demand;
+    a.mask = s->mask; a.visited = s->visited; a.done = s->done;
+    a.R = R; a.mode = mode; a.noise = noise; a.given = given; a.clip = clip; a.temp = temp; a.status = status;
+    return 0;
+}
+
+__attribute__((visibility("default"))) int eamrl_am_decode_step(int env, const eamrl_cache* cache_host,
+                                                               const eamrl_state* state_host, int64_t R, int mode,
+                                                               const float* noise, const int64_t* given, float tanh_clip,
+                                                               float temperature, int fuse_env_step, int64_t* action,
+                                                               float* logp, float* logprobs_all, float* logits_raw,
+                                                               uint32_t* status, void* stream)
+{
+    DecArgs a;
+    int rc = fill_args("eamrl_am_decode_step", env, cache_host, state_host, R, mode, noise, given, tanh_clip, temperature,
+                       status, a);
+    if (rc) return rc;
+    REQUIRE(action && logp, "eamrl_am_decode_step");
+    if (fuse_env_step) {
+        REQUIRE(a.done, "eamrl_am_decode_step");
+        if (env == EAMRL_ENV_CVRP) REQUIRE(a.visited && a.demand, "eamrl_am_decode_step");
+    }
+    a.fuse_env = fuse_env_step;
+    a.action = action; a.logp = logp; a.logprobs_all = logprobs_all; a.logits_raw = logits_raw;
+    return launched(launch_decode_step(env, a, (hipStream_t)stream), "eamrl_am_decode_step");
+}
+
+__attribute__((visibility("default"))) int eamrl_am_rollout(int env, const eamrl_cache* cache_host,
+                                                           const eamrl_state* state_host, int64_t R, int mode,
+                                                           const float* noise, const int64_t* given, int t_given,
+                                                           float tanh_clip, float temperature, int t_max,
+                                                           int64_t* actions, float* logps, int32_t* steps_out,
+                                                           uint32_t* status, void* stream)
+{
+    DecArgs a;
+    int rc = fill_args("eamrl_am_rollout", env, cache_host, state_host, R, mode, noise, given, tanh_clip, temperature,
+                       status, a);
+    if (rc) return rc;
+    REQUIRE(actions && logps && steps_out && a.done && t_max > 0, "eamrl_am_rollout");
+    if (env == EAMRL_ENV_CVRP) REQUIRE(a.visited && a.demand, "eamrl_am_rollout");
+    if (mode == EAMRL_EVALUATE) REQUIRE(t_given > 0, "eamrl_am_rollout");
+    a.fuse_env = 1; a.t_max = t_max; a.t_given = t_given;
+    a.action = actions; a.logp = logps; a.steps_out = steps_out;
+    if (!g_debug[1] && rollout_resident_supports(env, a))
+        return launched(launch_rollout_resident(env, a, (hipStream_t)stream), "eamrl_am_rollout");
+    return launched(launch_rollout_stream(env, a, (hipStream_t)stream), "eamrl_am_rollout");
+}
+
+__attribute__((visibility("default"))) int eamrl_tour_length(const float* locs, const int64_t* actions, float* reward,
+                                                            int64_t R, int64_t B, int M, int T, int with_depot,
+                                                            void* stream)
+{
+    REQUIRE(locs && actions && reward && R >= 0 && B > 0 && M > 0 && T > 0, "eamrl_tour_length");
+    if (R == 0) return 0;
+    return launched(launch_tour_length(locs, actions, reward, R, B, M, T, with_depot, (hipStream_t)stream),
+                    "eamrl_tour_length");
+}
+
+__attribute__((visibility("default"))) int eamrl_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T,
+                                                         void* stream)
+{
+    REQUIRE(logp && out && R >= 0 && T >= 0 && ld >= T, "eamrl_sum_logp");
+    if (R == 0) return 0;
+    return launched(launch_sum_logp(logp, ld, out, R, T, (hipStream_t)stream), "eamrl_sum_logp");
+}
+
+__attribute__((visibility("default"))) int eamrl_check_solution(int env, const int64_t* actions, const float* demand,
+                                                               const float* vcap, int64_t R, int64_t B, int N, int T,
+                                                               int32_t* bad, void* stream)
+{
+    REQUIRE(actions && bad && R >= 0 && B > 0 && N > 0 && T > 0, "eamrl_check_solution");
+    if (env == EAMRL_ENV_CVRP) REQUIRE(demand && vcap, "eamrl_check_solution");
+    if (R == 0) return 0;
+    return launched(launch_check_solution(env, actions, demand, vcap, R, B, N, T, bad, (hipStream_t)stream),
+                    "eamrl_check_solution");
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// Shared declarations of the decode kernels (step API + whole-rollout).
+#pragma once
+#include "../../include/eamrl.h"
+#include "dmath.hpp"
+
+namespace eamrl {
+
+// Flat kernel-argument copy of (eamrl_cache, eamrl_state) plus per-call parameters.
+struct DecArgs {
+    // cache
+    const float* K; const float* V; const float* Lp; const float* Pa; const float* Pb;
+    const float* cvec; const float* gctx;
+    int64_t ld; int64_t B; int M, E, H;
+    // state
+    int64_t* first; int64_t* cur; int64_t* istep; float* used; const float* vcap; const float* demand;
+    uint8_t* mask; uint8_t* visited; uint8_t* done;
+    // call
+    int64_t R; int mode; const float* noise; const int64_t* given; int t_given;
+    float clip, temp; int fuse_env; int t_max;
+    int64_t* action; float* logp; float* logprobs_all; float* logits_raw;
+    int32_t* steps_out; uint32_t* status;
+};
+
+// LDS carve for one row handled by one workgroup.
+struct RowLds {
+    float* q;       // [E]
+    float* heads;   // [E]
+    float* w;       // [H][M] scores -> softmax weights
+    float* x;       // [M]    processed logits -> log-probs
+    float* partA;   // [NCHUNK][E]
+    float* partZ;   // [NCHUNK][H]
+    float* partL;   // [M][NCHUNK] logit partials, then exp terms [M]
+    float* red;     // [64] reduction scratch
+    int* redi;      // [64]
+    uint8_t* msk;   // [M] (padded to 16 B)
+};
+
+inline size_t row_lds_bytes(int M, int E, int H)
+{
+    size_t f = 2 * (size_t)E + (size_t)H * M + M + (size_t)EAMRL_NCHUNK * E + (size_t)EAMRL_NCHUNK * H +
+               (size_t)M * EAMRL_NCHUNK + 64 + 64;
+    return f * 4 + (((size_t)M + 15) & ~(size_t)15);
+}
+
+__device__ __forceinline__ RowLds carve_row_lds(char* base, int M, int E, int H)
+{
+    RowLds l;
+    float* f = reinterpret_cast<float*>(base);
+    l.q = f; f += E;
+    l.heads = f; f += E;
+    l.w = f; f += (size_t)H * M;
+    l.x = f; f += M;
+    l.partA = f; f += EAMRL_NCHUNK * E;
+    l.partZ = f; f += EAMRL_NCHUNK * H;
+    l.partL = f; f += (size_t)M * EAMRL_NCHUNK;
+    l.red = f; f += 64;
+    l.redi = reinterpret_cast<int*>(f); f += 64;
+    l.msk = reinterpret_cast<uint8_t*>(f);
+    return l;
+}
+
+}  // namespace eamrl

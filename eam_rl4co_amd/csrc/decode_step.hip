@@ -1,0 +1,400 @@
+// Step-API decode kernels: one 256-thread workgroup per rollout row, cache streamed from HBM/L2.
+//
+//   k_decode_step<ENV>     one decode step (+ optionally the fused env step) for every row
+//   k_rollout_stream<ENV>  whole decode loop per row, re-reading the row's K/V/Lp every step (any M)
+//
+// Reference path replaced: AttentionModelDecoder.forward + PointerAttention.forward +
+// process_logits + Greedy/Sampling/Evaluate + TSPEnv._step / CVRPEnv._step
+// (rl4co/models/zoo/am/decoder.py:161-198, rl4co/models/nn/attention.py:282-328,
+//  rl4co/utils/decoding.py:140-190,346-465, rl4co/envs/routing/{tsp,cvrp}/env.py).
+//
+// HBM traffic per row-step (algorithmic): K, V, Lp rows of the still-feasible nodes
+// (12*E B per node), 1-2 gathered context rows, mask row r/w.  Coalescing: V is read with
+// lane = column (512 B contiguous per node); K and Lp are read as float4 runs of 64 B / 128 B per
+// lane, consecutive lanes consecutive runs, so every fetched line is fully used.
+#include "kernels.hpp"
+
+namespace eamrl {
+
+constexpr int BLOCK = 256;
+constexpr int NWAVE = BLOCK / EAMRL_WAVE;
+
+struct RowState {
+    int64_t first, cur, istep;
+    float used, vcap;
+};
+
+// block-wide max over values already reduced per thread; result broadcast to all threads
+__device__ __forceinline__ float block_max(float v, float* red)
+{
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    float m = red[0];
+#pragma unroll
+    for (int i = 1; i < NWAVE; ++i) m = __builtin_fmaxf(m, red[i]);
+    return m;
+}
+
+// Decode one row with the whole workgroup.  l.msk holds the row's action mask.  Outputs are
+// workgroup-uniform.  logprobs_row / logits_row may be null.
+template <int ENV>
+__device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const RowState& s, const float* noise_row,
+                           int64_t given, int64_t& out_a, float& out_lp, float* logprobs_row, float* logits_row)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int M = a.M, E = a.E, H = a.H, D = E / H;
+    const int64_t bi = r % a.B;
+    const int64_t ld = a.ld;
+    const float* K = a.K + bi * M * ld;
+    const float* V = a.V + bi * M * ld;
+    const float* Lp = a.Lp + bi * M * ld;
+
+    // ---- D1 context query ----------------------------------------------------------------------
+    for (int e = tid; e < E; e += BLOCK) {
+        float g = a.gctx ? a.gctx[bi * E + e] : 0.0f;
+        float ctx;
+        if (ENV == EAMRL_ENV_TSP) {
+            if (s.istep == 0) ctx = a.cvec[e];
+            else ctx = a.Pa[(bi * M + s.first) * ld + e] + a.Pb[(bi * M + s.cur) * ld + e];
+        } else {
+            ctx = fma_(a.cvec[e], s.vcap - s.used, a.Pa[(bi * M + s.cur) * ld + e]);
+        }
+        l.q[e] = ctx + g;
+    }
+    __syncthreads();
+
+    // ---- D2 scores s[h][n] = chain_d(q, K) / sqrt(D) ------------------------------------------------
+    const float qk_scale = 1.0f / __builtin_sqrtf((float)D);
+    for (int p = tid; p < M * H; p += BLOCK) {
+        const int n = p / H, h = p - n * H;
+        float sc = -INFINITY;
+        if (l.msk[n]) {
+            const float* kp = K + (int64_t)n * ld + h * D;
+            const float* qp = l.q + h * D;
+            float acc = 0.0f;
+            for (int d = 0; d < D; d += 4) {
+                float4 kk = *reinterpret_cast<const float4*>(kp + d);
+                acc = fma_(qp[d], kk.x, acc);
+                acc = fma_(qp[d + 1], kk.y, acc);
+                acc = fma_(qp[d + 2], kk.z, acc);
+                acc = fma_(qp[d + 3], kk.w, acc);
+            }
+            sc = acc * qk_scale;
+        }
+        l.w[h * M + n] = sc;
+    }
+    __syncthreads();
+
+    // ---- D3 per-head max, w = exp(s - max) -------------------------------------------------------------
+    for (int h = wv; h < H; h += NWAVE) {
+        float* wh = l.w + h * M;
+        float m = -INFINITY;
+        for (int n = lane; n < M; n += 64) m = __builtin_fmaxf(m, wh[n]);
+        m = wave_max(m);
+        for (int n = lane; n < M; n += 64) wh[n] = l.msk[n] ? d_expf(wh[n] - m) : 0.0f;
+    }
+    __syncthreads();
+
+    // ---- D4 glimpse: NCHUNK node chunks, sequential inside a chunk, chunks added left to right ----------
+    const int C = (M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
+    for (int pp = tid; pp < E * EAMRL_NCHUNK; pp += BLOCK) {
+        const int g = pp / E, e = pp - g * E, h = e / D;
+        const float* wh = l.w + h * M;
+        const int n0 = g * C, n1 = min(M, n0 + C);
+        float zg = 0.0f, ag = 0.0f;
+        for (int n = n0; n < n1; ++n) {
+            if (l.msk[n]) {
+                float wn = wh[n];
+                zg = zg + wn;
+                ag = fma_(wn, V[(int64_t)n * ld + e], ag);
+            }
+        }
+        l.partA[g * E + e] = ag;
+        if (e - h * D == 0) l.partZ[g * H + h] = zg;
+    }
+    __syncthreads();
+    for (int e = tid; e < E; e += BLOCK) {
+        const int h = e / D;
+        float A = l.partA[e], Z = l.partZ[h];
+#pragma unroll
+        for (int g = 1; g < EAMRL_NCHUNK; ++g) { A = A + l.partA[g * E + e]; Z = Z + l.partZ[g * H + h]; }
+        l.heads[e] = A / Z;
+    }
+    __syncthreads();
+
+    // ---- D5 logit partials over NCHUNK column chunks ---------------------------------------------------------
+    const int EC = E / EAMRL_NCHUNK;
+    for (int p = tid; p < M * EAMRL_NCHUNK; p += BLOCK) {
+        const int n = p / EAMRL_NCHUNK, c = p - n * EAMRL_NCHUNK;
+        float cg = 0.0f;
+        if (l.msk[n]) {
+            const float* lp = Lp + (int64_t)n * ld + c * EC;
+            const float* hp = l.heads + c * EC;
+            for (int e = 0; e < EC; e += 4) {
+                float4 v = *reinterpret_cast<const float4*>(lp + e);
+                cg = fma_(hp[e], v.x, cg);
+                cg = fma_(hp[e + 1], v.y, cg);
+                cg = fma_(hp[e + 2], v.z, cg);
+                cg = fma_(hp[e + 3], v.w, cg);
+            }
+        }
+        l.partL[p] = cg;
+    }
+    __syncthreads();
+
+    // ---- D6 combine, /sqrt(E), tanh clip, mask, /temperature ------------------------------------------------------
+    const float sqrtE = __builtin_sqrtf((float)E);
+    float tmax = -INFINITY;
+    bool nan_seen = false;
+    for (int n = tid; n < M; n += BLOCK) {
+        const float* pl = l.partL + n * EAMRL_NCHUNK;
+        float u = pl[0];
+#pragma unroll
+        for (int c = 1; c < EAMRL_NCHUNK; ++c) u = u + pl[c];
+        float logit = u / sqrtE;
+        const bool feas = l.msk[n] != 0;
+        if (feas && logit != logit) nan_seen = true;
+        if (logits_row) logits_row[n] = feas ? logit : -INFINITY;
+        float v = (a.clip > 0.0f) ? d_tanhf(logit) * a.clip : logit;
+        if (!feas) v = -INFINITY;
+        v = v / a.temp;
+        l.x[n] = v;
+        tmax = __builtin_fmaxf(tmax, v);
+    }
+    if (nan_seen) atomicOr(a.status, EAMRL_ST_NAN_LOGITS);
+    const float mx = block_max(tmax, l.red);  // (syncs inside: partL reads above are complete)
+
+    // ---- D7 log-softmax: lane-tree sum of exp(x - max) ------------------------------------------------------------------
+    float* ex = l.partL;  // reuse
+    for (int n = tid; n < M; n += BLOCK) ex[n] = l.msk[n] ? d_expf(l.x[n] - mx) : 0.0f;
+    __syncthreads();
+    const int nblk = (M + 63) / 64;
+    for (int b = wv; b < nblk; b += NWAVE) {
+        const int n = b * 64 + lane;
+        float v = wave_tree_sum(n < M ? ex[n] : 0.0f);
+        if (lane == 0) l.red[8 + b] = v;   // nblk <= 56
+    }
+    __syncthreads();
+    float Zl = l.red[8];
+    for (int b = 1; b < nblk; ++b) Zl = Zl + l.red[8 + b];
+    const float lse = d_logf(Zl);
+    __syncthreads();  // everyone has read red[] / ex[] before they are reused
+
+    // ---- D8 log-probs + selection -----------------------------------------------------------------------------------------------
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int n = tid; n < M; n += BLOCK) {
+        const bool feas = l.msk[n] != 0;
+        float lpn = feas ? (l.x[n] - mx) - lse : -INFINITY;
+        l.x[n] = lpn;
+        if (logprobs_row) logprobs_row[n] = lpn;
+        float key = lpn;
+        if (a.mode == EAMRL_SAMPLE) key = d_expf(lpn) / noise_row[n];
+        if (key > best || besti == 0x7fffffff) { best = key; besti = n; }  // n ascending per thread: first max kept
+    }
+    wave_argmax(best, besti);
+    if (lane == 0) { l.red[wv] = best; l.redi[wv] = besti; }
+    __syncthreads();
+    int sel = l.redi[0];
+    {
+        float bv = l.red[0];
+#pragma unroll
+        for (int i = 1; i < NWAVE; ++i) {
+            float ov = l.red[i];
+            int oi = l.redi[i];
+            if (ov > bv || (ov == bv && oi < sel)) { bv = ov; sel = oi; }
+        }
+    }
+    if (a.mode == EAMRL_EVALUATE) sel = (int)given;
+    const bool in_range = sel >= 0 && sel < M;
+    if (!in_range || !l.msk[sel]) {
+        if (tid == 0) atomicOr(a.status, EAMRL_ST_INFEASIBLE);
+        if (!in_range) sel = 0;
+    }
+    out_a = sel;
+    out_lp = l.x[sel];
+}
+
+// Apply the env transition to the LDS copy of the row (msk, and vis for CVRP) and the uniform state.
+template <int ENV>
+__device__ bool env_step_row(const DecArgs& a, const RowLds& l, uint8_t* vis, int64_t r, RowState& s, int64_t act)
+{
+    const int tid = threadIdx.x;
+    const int M = a.M;
+    __syncthreads();  // all readers of msk / x are done
+    if (ENV == EAMRL_ENV_TSP) {
+        if (s.istep == 0) s.first = act;
+        s.cur = act;
+        s.istep += 1;
+        if (tid == 0) l.msk[act] = 0;
+        __syncthreads();
+        int any = 0;
+        for (int n = tid; n < M; n += BLOCK) any |= l.msk[n];
+        return __syncthreads_or(any) == 0;
+    } else {
+        const int N = M - 1;
+        const int64_t bi = r % a.B;
+        const float* dem = a.demand + bi * N;
+        int64_t di = act - 1;
+        di = di < 0 ? 0 : (di > N - 1 ? N - 1 : di);
+        s.used = (s.used + dem[di]) * (act != 0 ? 1.0f : 0.0f);
+        s.cur = act;
+        if (tid == 0) vis[act] = 1;
+        __syncthreads();
+        const float lim = s.vcap + 1e-5f;
+        int any_free = 0, all_vis = vis[0] != 0;
+        for (int j = tid; j < N; j += BLOCK) {
+            const int v = vis[j + 1] != 0;
+            const float load = dem[j] + s.used;
+            const int blocked = v | (load > lim);
+            l.msk[j + 1] = !blocked;
+            any_free |= !blocked;
+            all_vis &= v;
+        }
+        any_free = __syncthreads_or(any_free);
+        all_vis = __syncthreads_and(all_vis);
+        if (tid == 0) l.msk[0] = !((s.cur == 0) && any_free);
+        return all_vis != 0;
+    }
+}
+
+template <int ENV>
+__device__ __forceinline__ void load_row_state(const DecArgs& a, int64_t r, RowState& s)
+{
+    s.cur = a.cur[r];
+    if (ENV == EAMRL_ENV_TSP) {
+        s.first = a.first[r];
+        s.istep = a.istep[r];
+        s.used = 0.0f;
+        s.vcap = 0.0f;
+    } else {
+        s.first = 0;
+        s.istep = 1;
+        s.used = a.used[r];
+        s.vcap = a.vcap[r];
+    }
+}
+
+template <int ENV>
+__device__ __forceinline__ void store_row_state(const DecArgs& a, const RowLds& l, const uint8_t* vis, int64_t r,
+                                                const RowState& s, bool done)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    for (int n = tid; n < a.M; n += BLOCK) {
+        a.mask[r * a.M + n] = l.msk[n];
+        if (ENV == EAMRL_ENV_CVRP) a.visited[r * a.M + n] = vis[n];
+    }
+    if (tid == 0) {
+        a.cur[r] = s.cur;
+        a.done[r] = done ? 1 : 0;
+        if (ENV == EAMRL_ENV_TSP) { a.first[r] = s.first; a.istep[r] = s.istep; }
+        else a.used[r] = s.used;
+    }
+}
+
+template <int ENV>
+__global__ __launch_bounds__(BLOCK) void k_decode_step(DecArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RowLds l = carve_row_lds(smem, a.M, a.E, a.H);
+    uint8_t* vis = l.msk + ((a.M + 15) & ~15);
+    const int64_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    RowState s;
+    load_row_state<ENV>(a, r, s);
+    for (int n = tid; n < a.M; n += BLOCK) {
+        l.msk[n] = a.mask[r * a.M + n];
+        if (ENV == EAMRL_ENV_CVRP && a.fuse_env) vis[n] = a.visited[r * a.M + n];
+    }
+    __syncthreads();
+    int64_t act;
+    float lp;
+    decode_row<ENV>(a, l, r, s, a.noise ? a.noise + r * a.M : nullptr, a.given ? a.given[r] : 0, act, lp,
+                    a.logprobs_all ? a.logprobs_all + r * a.M : nullptr,
+                    a.logits_raw ? a.logits_raw + r * a.M : nullptr);
+    if (tid == 0) { a.action[r] = act; a.logp[r] = lp; }
+    if (a.fuse_env) {
+        const bool done = env_step_row<ENV>(a, l, vis, r, s, act);
+        store_row_state<ENV>(a, l, vis, r, s, done);
+    }
+}
+
+// Whole decode loop for one row per workgroup; K/V/Lp re-read from HBM/L2 each step (works for any M).
+template <int ENV>
+__global__ __launch_bounds__(BLOCK) void k_rollout_stream(DecArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RowLds l = carve_row_lds(smem, a.M, a.E, a.H);
+    uint8_t* vis = l.msk + ((a.M + 15) & ~15);
+    const int64_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    RowState s;
+    load_row_state<ENV>(a, r, s);
+    for (int n = tid; n < a.M; n += BLOCK) {
+        l.msk[n] = a.mask[r * a.M + n];
+        if (ENV == EAMRL_ENV_CVRP) vis[n] = a.visited[r * a.M + n];
+    }
+    bool done = a.done[r] != 0;
+    __syncthreads();
+    int t = 0;
+    while (!done && t < a.t_max) {
+        int64_t act;
+        float lp;
+        const float* nz = a.noise ? a.noise + (r * a.t_max + t) * (int64_t)a.M : nullptr;
+        const int64_t gv = a.given ? (t < a.t_given ? a.given[r * a.t_given + t] : 0) : 0;
+        decode_row<ENV>(a, l, r, s, nz, gv, act, lp, nullptr, nullptr);
+        if (tid == 0) { a.action[r * a.t_max + t] = act; a.logp[r * a.t_max + t] = lp; }
+        done = env_step_row<ENV>(a, l, vis, r, s, act);
+        ++t;
+    }
+    store_row_state<ENV>(a, l, vis, r, s, done);
+    if (tid == 0) {
+        atomicMax(a.steps_out, t);
+        if (!done) atomicOr(a.status, EAMRL_ST_STEP_OVERRUN);
+    }
+}
+
+// After the loop the reference keeps stepping finished CVRP rows with the depot until the slowest row
+// is done: rows whose last real action was a customer end at the depot with an
+// empty vehicle.  actions/logps are already right-padded with 0; this fixes the state tensors.
+__global__ void k_rollout_pad_cvrp(DecArgs a)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.R) return;
+    const int T = *a.steps_out;
+    if (T <= 0 || !a.done[r]) return;
+    // A row that needed fewer than T steps never wrote column T-1 (host pre-zeroed = depot); stepping a
+    // finished row with the depot makes (cur, used) = (0, 0) and leaves mask/visited unchanged.
+    if (a.cur[r] != 0 && a.action[r * a.t_max + (T - 1)] == 0) {
+        a.cur[r] = 0;
+        a.used[r] = 0.0f;
+    }
+}
+
+static int launch_decode(int env, const DecArgs& a, bool rollout, hipStream_t st)
+{
+    const size_t lds = row_lds_bytes(a.M, a.E, a.H) + (((size_t)a.M + 15) & ~(size_t)15);
+    if (lds > 160 * 1024) return EAMRL_E_ARG;
+    dim3 grid((unsigned)a.R), block(BLOCK);
+    void (*k)(DecArgs);
+    if (rollout) k = env == EAMRL_ENV_TSP ? k_rollout_stream<EAMRL_ENV_TSP> : k_rollout_stream<EAMRL_ENV_CVRP>;
+    else k = env == EAMRL_ENV_TSP ? k_decode_step<EAMRL_ENV_TSP> : k_decode_step<EAMRL_ENV_CVRP>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return EAMRL_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(k, grid, block, lds, st, a);
+    if (rollout && env == EAMRL_ENV_CVRP)
+        hipLaunchKernelGGL(k_rollout_pad_cvrp, dim3((unsigned)((a.R + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_decode_step(int env, const DecArgs& a, hipStream_t st) { return launch_decode(env, a, false, st); }
+int launch_rollout_stream(int env, const DecArgs& a, hipStream_t st) { return launch_decode(env, a, true, st); }
+
+}  // namespace eamrl

@@ -1,0 +1,357 @@
+// One-shot encoder + cache kernels (fp32, defined k-ordered accumulation).
+//
+//   k_linear_mfma     y = [res +] act(bias + x W^T) on v_mfma_f32_32x32x2_f32: the f32 MFMA accumulates
+//                     along K as an ordered fma chain (k0 then k1, instruction after instruction), i.e.
+//                     bit-for-bit the canonical chain(x, w, K, bias) of DESIGN.md
+//   k_linear_valu     same result on the VALU (cross-check kernel, eamrl_debug_set(0, 1))
+//   k_small_linear    in_dim <= 4 (init embeddings): plain fma chain per output
+//   k_mha_encoder     per (instance, head) self-attention: two passes over the keys (max, then exp/sum/PV)
+//   k_norm_*          BatchNorm1d(eval) / InstanceNorm1d(affine)
+//   k_mean_nodes      embeddings.mean(1)
+//
+// Reference: rl4co/models/zoo/am/encoder.py:70-91, rl4co/models/nn/graph/attnnet.py:16-103,
+// rl4co/models/nn/attention.py:66-136, rl4co/models/nn/ops.py:32-56, rl4co/models/nn/mlp.py:52-61,
+// rl4co/models/nn/env_embeddings/init.py:55-68,115-138, rl4co/models/zoo/am/decoder.py:206-235.
+#include <cstdlib>
+
+#include "kernels.hpp"
+
+namespace eamrl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------
+// GEMM  y[r][j] = bias[j] + sum_k x[r][k] * w(j,k),  w(j,k) = WT ? W[k*ldw + j] : W[j*ldw + k]
+// block = 256 threads (4 waves, 2x2), tile 128 rows x 128 cols, each wave 64x64 = 2x2 MFMA 32x32 tiles
+// ---------------------------------------------------------------------------------------------------
+constexpr int GT = 128;       // block tile (rows and cols)
+constexpr int GK = 32;        // k tile
+constexpr int GKP = GK + 1;   // LDS row stride (odd: conflict-free ds_read_b32 down a column)
+
+
+__device__ __forceinline__ void gemm_load_tiles(const GemmArgs& g, float* As, float* Bs, int64_t row0, int col0, int k0)
+{
+    const int tid = threadIdx.x;
+    // x tile: 128 rows x 32 k, lane-contiguous along k
+    for (int i = tid; i < GT * GK; i += 256) {
+        const int rr = i / GK, kk = i - rr * GK;
+        const int64_t r = row0 + rr;
+        const int k = k0 + kk;
+        As[rr * GKP + kk] = (r < g.rows && k < g.in_dim) ? g.x[r * g.ldx + k] : 0.0f;
+    }
+    if (!g.wt) {
+        for (int i = tid; i < GT * GK; i += 256) {
+            const int jj = i / GK, kk = i - jj * GK;
+            const int j = col0 + jj, k = k0 + kk;
+            Bs[jj * GKP + kk] = (j < g.out_dim && k < g.in_dim) ? g.W[(int64_t)j * g.ldw + k] : 0.0f;
+        }
+    } else {
+        for (int i = tid; i < GT * GK; i += 256) {
+            const int kk = i / GT, jj = i - kk * GT;
+            const int j = col0 + jj, k = k0 + kk;
+            Bs[jj * GKP + kk] = (j < g.out_dim && k < g.in_dim) ? g.W[(int64_t)k * g.ldw + j] : 0.0f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_linear_mfma(GemmArgs g)
+{
+    __shared__ float As[GT * GKP];
+    __shared__ float Bs[GT * GKP];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;           // wave position in the 2x2 grid
+    const int64_t row0 = (int64_t)blockIdx.x * GT;
+    const int col0 = blockIdx.y * GT;
+    const int li = lane & 31, lk = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = col0 + wc * 64 + b * 32 + li;           // C column of this lane
+            const float bj = (g.bias && j < g.out_dim) ? g.bias[j] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = bj;
+        }
+
+    for (int k0 = 0; k0 < g.in_dim; k0 += GK) {
+        __syncthreads();
+        gemm_load_tiles(g, As, Bs, row0, col0, k0);
+        __syncthreads();
+        const int kmax = min(GK, g.in_dim - k0);   // multiple of 2 required (checked by the host)
+        for (int kk = 0; kk < kmax; kk += 2) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = As[(wr * 64 + a * 32 + li) * GKP + kk + lk];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = Bs[(wc * 64 + b * 32 + li) * GKP + kk + lk];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = col0 + wc * 64 + b * 32 + li;
+            if (j >= g.out_dim) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t r = row0 + wr * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;
+                if (r >= g.rows) continue;
+                float v = acc[a][b][i];
+                if (g.relu && !(v > 0.0f)) v = 0.0f;
+                if (g.res) v = g.res[r * g.ldres + j] + v;
+                g.y[r * g.ldy + j] = v;
+            }
+        }
+}
+
+// VALU cross-check: 64x64 tile, 4x4 outputs per thread, sequential k
+__global__ __launch_bounds__(256) void k_linear_valu(GemmArgs g)
+{
+    constexpr int T = 64, KT = 32, KP = KT + 1;
+    __shared__ float As[T * KP];
+    __shared__ float Bs[T * KP];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * T;
+    const int col0 = blockIdx.y * T;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = col0 + tx * 4 + j;
+            acc[i][j] = (g.bias && c < g.out_dim) ? g.bias[c] : 0.0f;
+        }
+    for (int k0 = 0; k0 < g.in_dim; k0 += KT) {
+        __syncthreads();
+        for (int i = tid; i < T * KT; i += 256) {
+            const int rr = i / KT, kk = i - rr * KT;
+            const int64_t r = row0 + rr;
+            const int k = k0 + kk, j = col0 + rr;
+            As[rr * KP + kk] = (r < g.rows && k < g.in_dim) ? g.x[r * g.ldx + k] : 0.0f;
+            float wv = 0.0f;
+            if (j < g.out_dim && k < g.in_dim) wv = g.wt ? g.W[(int64_t)k * g.ldw + j] : g.W[(int64_t)j * g.ldw + k];
+            Bs[rr * KP + kk] = wv;
+        }
+        __syncthreads();
+        const int kmax = min(KT, g.in_dim - k0);
+        for (int kk = 0; kk < kmax; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[(ty * 4 + i) * KP + kk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[(tx * 4 + j) * KP + kk];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma_(a[i], b[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = row0 + ty * 4 + i;
+            const int c = col0 + tx * 4 + j;
+            if (r >= g.rows || c >= g.out_dim) continue;
+            float v = acc[i][j];
+            if (g.relu && !(v > 0.0f)) v = 0.0f;
+            if (g.res) v = g.res[r * g.ldres + c] + v;
+            g.y[r * g.ldy + c] = v;
+        }
+}
+
+// in_dim <= 4: one thread per output element
+__global__ void k_small_linear(GemmArgs g)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.rows * g.out_dim) return;
+    const int64_t r = idx / g.out_dim;
+    const int j = (int)(idx - r * g.out_dim);
+    float acc = g.bias ? g.bias[j] : 0.0f;
+    for (int k = 0; k < g.in_dim; ++k) {
+        const float w = g.wt ? g.W[(int64_t)k * g.ldw + j] : g.W[(int64_t)j * g.ldw + k];
+        acc = fma_(g.x[r * g.ldx + k], w, acc);
+    }
+    if (g.relu && !(acc > 0.0f)) acc = 0.0f;
+    if (g.res) acc = g.res[r * g.ldres + j] + acc;
+    g.y[r * g.ldy + j] = acc;
+}
+
+int launch_linear(const GemmArgs& g, hipStream_t st)
+{
+    const bool force_valu = g_debug[0] != 0;
+    if (g.rows <= 0) return 0;
+    if (g.in_dim <= 4) {
+        const int64_t n = g.rows * g.out_dim;
+        hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
+    } else if (force_valu || (g.in_dim & 1)) {
+        dim3 grid((unsigned)((g.rows + 63) / 64), (unsigned)((g.out_dim + 63) / 64));
+        hipLaunchKernelGGL(k_linear_valu, grid, dim3(256), 0, st, g);
+    } else {
+        dim3 grid((unsigned)((g.rows + GT - 1) / GT), (unsigned)((g.out_dim + GT - 1) / GT));
+        hipLaunchKernelGGL(k_linear_mfma, grid, dim3(256), 0, st, g);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// encoder self-attention: block = (instance, head); thread = query row
+// ---------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(128) void k_mha_encoder(const float* qkv, float* out, int N, int E, int H)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ks = reinterpret_cast<float*>(smem);   // [N][D]
+    float* vs = ks + (size_t)N * D;               // [N][D]
+    const int64_t b = blockIdx.x / H;
+    const int h = blockIdx.x - b * H;
+    const float* base = qkv + b * (int64_t)N * 3 * E;
+    for (int i = threadIdx.x; i < N * D; i += blockDim.x) {
+        const int n = i / D, d = i - n * D;
+        ks[i] = base[(int64_t)n * 3 * E + E + h * D + d];
+        vs[i] = base[(int64_t)n * 3 * E + 2 * E + h * D + d];
+    }
+    __syncthreads();
+    const float scale = 1.0f / __builtin_sqrtf((float)D);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        float q[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) q[d] = base[(int64_t)i * 3 * E + h * D + d];
+        float m = -INFINITY;
+        for (int j = 0; j < N; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc = fma_(q[d], ks[j * D + d], acc);
+            m = __builtin_fmaxf(m, acc * scale);
+        }
+        float Z = 0.0f;
+        float o[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) o[d] = 0.0f;
+        for (int j = 0; j < N; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc = fma_(q[d], ks[j * D + d], acc);
+            const float w = d_expf(acc * scale - m);
+            Z = Z + w;
+#pragma unroll
+            for (int d = 0; d < D; ++d) o[d] = fma_(w, vs[j * D + d], o[d]);
+        }
+        float* op = out + (b * N + i) * (int64_t)E + h * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) op[d] = o[d] / Z;
+    }
+}
+
+int launch_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H, hipStream_t st)
+{
+    const int D = E / H;
+    const size_t lds = (size_t)2 * N * D * sizeof(float);
+    if (D * H != E || lds > 160 * 1024 || B * H > 0x7fffffffLL) return EAMRL_E_ARG;
+    dim3 grid((unsigned)(B * H)), block(128);
+    if (D == 16) {
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_mha_encoder<16>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return EAMRL_E_LAUNCH;
+        hipLaunchKernelGGL(k_mha_encoder<16>, grid, block, lds, st, qkv, out, N, E, H);
+    } else if (D == 32) {
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_mha_encoder<32>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return EAMRL_E_LAUNCH;
+        hipLaunchKernelGGL(k_mha_encoder<32>, grid, block, lds, st, qkv, out, N, E, H);
+    } else {
+        return EAMRL_E_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// normalisation + mean
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm1d eval: scale = gamma / sqrt(var + eps); shift = beta - mean * scale; y = fma(x, scale, shift)
+__global__ __launch_bounds__(256) void k_norm_batch_eval(float* x, int64_t rows, int E, const float* gamma,
+                                                         const float* beta, const float* mean, const float* var, float eps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* scale = reinterpret_cast<float*>(smem);
+    float* shift = scale + E;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        const float s = gamma[e] / __builtin_sqrtf(var[e] + eps);
+        const float ms = mean[e] * s;
+        scale[e] = s;
+        shift[e] = beta[e] - ms;
+    }
+    __syncthreads();
+    const int64_t total = rows * E;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E);
+        x[i] = fma_(x[i], scale[e], shift[e]);
+    }
+}
+
+// InstanceNorm1d(affine): block = instance, thread = channel; sequential over nodes (coalesced across channels)
+__global__ void k_norm_instance(float* x, int N, int E, const float* gamma, const float* beta, float eps)
+{
+    float* xb = x + (int64_t)blockIdx.x * N * E;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        float s = 0.0f;
+        for (int n = 0; n < N; ++n) s = s + xb[(int64_t)n * E + e];
+        const float mean = s / (float)N;
+        float v = 0.0f;
+        for (int n = 0; n < N; ++n) { const float d = xb[(int64_t)n * E + e] - mean; v = fma_(d, d, v); }
+        const float inv = 1.0f / __builtin_sqrtf(v / (float)N + eps);
+        const float g = gamma[e], bt = beta[e];
+        for (int n = 0; n < N; ++n) {
+            const float d = xb[(int64_t)n * E + e] - mean;
+            xb[(int64_t)n * E + e] = fma_(d * inv, g, bt);
+        }
+    }
+}
+
+__global__ void k_mean_nodes(const float* emb, float* out, int M, int E)
+{
+    const float* xb = emb + (int64_t)blockIdx.x * M * E;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        float s = 0.0f;
+        for (int n = 0; n < M; ++n) s = s + xb[(int64_t)n * E + e];
+        out[(int64_t)blockIdx.x * E + e] = s / (float)M;
+    }
+}
+
+int launch_normalize(float* x, int64_t B, int N, int E, int kind, const float* gamma, const float* beta,
+                     const float* mean, const float* var, float eps, hipStream_t st)
+{
+    if (B <= 0) return 0;
+    if (kind == EAMRL_NORM_BATCH_EVAL) {
+        if (!mean || !var) return EAMRL_E_ARG;
+        const int64_t total = B * N * E;
+        const int64_t want = (total + 255) / 256;
+        const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+        hipLaunchKernelGGL(k_norm_batch_eval, dim3(blocks), dim3(256), 2 * E * sizeof(float), st, x, B * N, E, gamma,
+                           beta, mean, var, eps);
+    } else if (kind == EAMRL_NORM_INSTANCE) {
+        hipLaunchKernelGGL(k_norm_instance, dim3((unsigned)B), dim3(E <= 1024 ? ((E + 63) / 64) * 64 : 1024), 0, st, x,
+                           N, E, gamma, beta, eps);
+    } else {
+        return EAMRL_E_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, hipStream_t st)
+{
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_mean_nodes, dim3((unsigned)B), dim3(E <= 1024 ? ((E + 63) / 64) * 64 : 1024), 0, st, emb, out,
+                       M, E);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+}  // namespace eamrl

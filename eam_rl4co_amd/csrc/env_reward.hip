@@ -1,0 +1,222 @@
+// Stand-alone environment transitions, reward and validity kernels (integer / byte work, HBM-bound).
+//
+//   k_tsp_step         TSPEnv._step                        rl4co/envs/routing/tsp/env.py:62-88
+//   k_cvrp_step_mask   CVRPEnv._step + get_action_mask     rl4co/envs/routing/cvrp/env.py:68-100,132-144
+//   k_tour_length      get_reward                          rl4co/utils/ops.py:59-95, tsp/env.py:152-159, cvrp/env.py:146-155
+//   k_sum_logp         get_log_likelihood                  rl4co/utils/decoding.py:38-64
+//   k_check_*          check_solution_validity             tsp/env.py:161-168, cvrp/env.py:157-185
+//
+// One 64-lane wavefront per row: the row's mask / visited bytes are read as one coalesced run, the
+// "any / all" reductions are wave ballots, and the tour length uses the canonical lane tree.
+#include "kernels.hpp"
+
+namespace eamrl {
+
+constexpr int EB = 256;          // threads per block
+constexpr int ROWS_PER_BLOCK = EB / 64;
+
+__global__ __launch_bounds__(EB) void k_tsp_step(uint8_t* mask, int64_t* first, int64_t* cur, int64_t* istep,
+                                                 const int64_t* action, uint8_t* done, int64_t R, int N)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int64_t a = action[r];
+    uint8_t* m = mask + r * N;
+    int any = 0;
+    for (int n = lane; n < N; n += 64) {
+        uint8_t v = m[n];
+        if (n == a) { v = 0; m[n] = 0; }
+        any |= v;
+    }
+    const bool remaining = __ballot(any != 0) != 0ull;
+    if (lane == 0) {
+        if (istep[r] == 0) first[r] = a;
+        cur[r] = a;
+        istep[r] += 1;
+        done[r] = remaining ? 0 : 1;
+    }
+}
+
+// STEP = 0: mask only (get_action_mask); STEP = 1: transition then mask
+template <int STEP>
+__global__ __launch_bounds__(EB) void k_cvrp_step_mask(uint8_t* visited, float* used, const float* vcap,
+                                                       const float* demand, int64_t* cur, const int64_t* action,
+                                                       uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int M = N + 1;
+    const float* dem = demand + (r % B) * N;
+    uint8_t* vis = visited + r * M;
+    float u = used[r];
+    int64_t c = cur[r];
+    int64_t a = -1;
+    if (STEP) {
+        a = action[r];
+        int64_t di = a - 1;
+        di = di < 0 ? 0 : (di > N - 1 ? N - 1 : di);
+        u = (u + dem[di]) * (a != 0 ? 1.0f : 0.0f);
+        c = a;
+    }
+    const float lim = vcap[r] + 1e-5f;
+    int any_free = 0;
+    int all_vis = 1;
+    for (int j = lane; j < N; j += 64) {
+        int v = vis[j + 1] != 0;
+        if (STEP && j + 1 == a) { v = 1; vis[j + 1] = 1; }
+        const float load = dem[j] + u;
+        const int blocked = v | (load > lim);
+        mask[r * M + 1 + j] = !blocked;
+        any_free |= !blocked;
+        all_vis &= v;
+    }
+    const bool any = __ballot(any_free != 0) != 0ull;
+    const bool allc = __ballot(all_vis == 0) == 0ull;
+    if (lane == 0) {
+        int v0 = vis[0] != 0;
+        if (STEP && a == 0) { v0 = 1; vis[0] = 1; }
+        mask[r * M] = !((c == 0) && any);
+        if (STEP) {
+            used[r] = u;
+            cur[r] = c;
+            done[r] = (allc && v0) ? 1 : 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(EB) void k_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R,
+                                                    int64_t B, int M, int T, int with_depot)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* L = locs + (r % B) * (int64_t)M * 2;
+    const int64_t* act = actions + r * T;
+    const int P = T + (with_depot ? 1 : 0);
+    float total = 0.0f;
+    for (int b0 = 0; b0 < P; b0 += 64) {
+        const int t = b0 + lane;
+        float d = 0.0f;
+        if (t < P) {
+            int64_t a0, a1;
+            if (with_depot) {
+                a0 = (t == 0) ? 0 : act[t - 1];
+                a1 = (t + 1 == P) ? 0 : act[t];
+            } else {
+                a0 = act[t];
+                a1 = act[(t + 1 == P) ? 0 : t + 1];
+            }
+            // caller-supplied tours: keep the gather inside the instance whatever the indices are
+            a0 = a0 < 0 ? 0 : (a0 >= M ? M - 1 : a0);
+            a1 = a1 < 0 ? 0 : (a1 >= M ? M - 1 : a1);
+            const float2 p0 = *reinterpret_cast<const float2*>(L + 2 * a0);
+            const float2 p1 = *reinterpret_cast<const float2*>(L + 2 * a1);
+            const float dx = p1.x - p0.x, dy = p1.y - p0.y;
+            d = __builtin_sqrtf(fma_(dy, dy, dx * dx));
+        }
+        const float s = wave_tree_sum(d);
+        total = (b0 == 0) ? s : total + s;
+    }
+    if (lane == 0) reward[r] = -total;
+}
+
+__global__ void k_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float s = 0.0f;
+    for (int t = 0; t < T; ++t) s = s + logp[r * ld + t];
+    out[r] = s;
+}
+
+// One wavefront per row; "seen" bitmap in LDS (M <= 4096).
+__global__ __launch_bounds__(EB) void k_check_solution(int env, const int64_t* actions, const float* demand,
+                                                       const float* vcap, int64_t R, int64_t B, int N, int T,
+                                                       int32_t* bad)
+{
+    __shared__ uint32_t seen_all[ROWS_PER_BLOCK][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wv;
+    if (r >= R) return;
+    uint32_t* seen = seen_all[wv];
+    for (int i = lane; i < 128; i += 64) seen[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t* act = actions + r * T;
+    const int top = (env == EAMRL_ENV_TSP) ? N - 1 : N;  // highest legal node id
+    int bad_lane = 0;
+    for (int t = lane; t < T; t += 64) {
+        const int64_t a = act[t];
+        if (a < 0 || a > top) { bad_lane = 1; continue; }
+        if (env == EAMRL_ENV_CVRP && a == 0) continue;
+        const uint32_t bit = 1u << (a & 31);
+        const uint32_t old = atomicOr(&seen[a >> 5], bit);
+        if (old & bit) bad_lane = 1;  // visited twice
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int lo = (env == EAMRL_ENV_TSP) ? 0 : 1;
+    for (int n = lo + lane; n <= top; n += 64)
+        if (!((seen[n >> 5] >> (n & 31)) & 1u)) bad_lane = 1;  // never visited
+    const bool invalid = __ballot(bad_lane != 0) != 0ull;
+    if (lane != 0) return;
+    if (invalid) { atomicAdd(&bad[0], 1); return; }
+    if (env == EAMRL_ENV_CVRP) {
+        // running load, depot resets it (cvrp/env.py:172-185)
+        const float cap = vcap[r], lim = cap + 1e-5f;
+        const float* dem = demand + (r % B) * N;
+        float usedc = 0.0f;
+        int over = 0;
+        for (int t = 0; t < T; ++t) {
+            const int64_t a = act[t];
+            usedc = usedc + ((a == 0) ? -cap : dem[a - 1]);
+            if (usedc < 0.0f) usedc = 0.0f;
+            if (usedc > lim) over = 1;
+        }
+        if (over) atomicAdd(&bad[1], 1);
+    }
+}
+
+static inline unsigned row_blocks(int64_t R) { return (unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
+
+int launch_tsp_step(uint8_t* mask, int64_t* first, int64_t* cur, int64_t* istep, const int64_t* action,
+                    uint8_t* done, int64_t R, int N, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tsp_step, dim3(row_blocks(R)), dim3(EB), 0, st, mask, first, cur, istep, action, done, R, N);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_cvrp(int step, uint8_t* visited, float* used, const float* vcap, const float* demand, int64_t* cur,
+                const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N, hipStream_t st)
+{
+    if (step)
+        hipLaunchKernelGGL(k_cvrp_step_mask<1>, dim3(row_blocks(R)), dim3(EB), 0, st, visited, used, vcap, demand, cur,
+                           action, mask, done, R, B, N);
+    else
+        hipLaunchKernelGGL(k_cvrp_step_mask<0>, dim3(row_blocks(R)), dim3(EB), 0, st, visited, used, vcap, demand, cur,
+                           action, mask, done, R, B, N);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R, int64_t B, int M, int T,
+                       int with_depot, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tour_length, dim3(row_blocks(R)), dim3(EB), 0, st, locs, actions, reward, R, B, M, T, with_depot);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sum_logp, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, logp, ld, out, R, T);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_check_solution(int env, const int64_t* actions, const float* demand, const float* vcap, int64_t R, int64_t B,
+                          int N, int T, int32_t* bad, hipStream_t st)
+{
+    if (N + 1 > 4096) return EAMRL_E_ARG;
+    hipLaunchKernelGGL(k_check_solution, dim3(row_blocks(R)), dim3(EB), 0, st, env, actions, demand, vcap, R, B, N, T, bad);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+}  // namespace eamrl

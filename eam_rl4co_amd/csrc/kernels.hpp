@@ -1,0 +1,36 @@
+// Launch entry points shared between the kernel translation units and abi.hip.
+#pragma once
+#include "decode_common.hpp"
+
+namespace eamrl {
+
+struct GemmArgs {
+    const float* x; int64_t ldx;
+    const float* W; int64_t ldw; int wt;     // wt: W is [in][out] (right-multiplication)
+    const float* bias; const float* res; int64_t ldres;
+    float* y; int64_t ldy;
+    int64_t rows; int in_dim, out_dim, relu;
+};
+
+extern int g_debug[8];   // eamrl_debug_set knobs
+
+int launch_linear(const GemmArgs& g, hipStream_t st);
+int launch_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H, hipStream_t st);
+int launch_normalize(float* x, int64_t B, int N, int E, int kind, const float* gamma, const float* beta,
+                     const float* mean, const float* var, float eps, hipStream_t st);
+int launch_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, hipStream_t st);
+int launch_tsp_step(uint8_t* mask, int64_t* first, int64_t* cur, int64_t* istep, const int64_t* action,
+                    uint8_t* done, int64_t R, int N, hipStream_t st);
+int launch_cvrp(int step, uint8_t* visited, float* used, const float* vcap, const float* demand, int64_t* cur,
+                const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N, hipStream_t st);
+int launch_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R, int64_t B, int M, int T,
+                       int with_depot, hipStream_t st);
+int launch_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, hipStream_t st);
+int launch_check_solution(int env, const int64_t* actions, const float* demand, const float* vcap, int64_t R, int64_t B,
+                          int N, int T, int32_t* bad, hipStream_t st);
+int launch_decode_step(int env, const DecArgs& a, hipStream_t st);
+int launch_rollout_stream(int env, const DecArgs& a, hipStream_t st);
+int launch_rollout_resident(int env, const DecArgs& a, hipStream_t st);
+bool rollout_resident_supports(int env, const DecArgs& a);
+
+}  // namespace eamrl

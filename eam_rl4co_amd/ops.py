@@ -1,0 +1,419 @@
+"""torch.Tensor front-end of the C ABI: checks device / dtype / contiguity / shapes on the host (a kernel
+that faults can reset the GPU host) and enqueues on torch's current HIP stream.  Tensors are plumbing only:
+every computation below happens in libeamrl_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ENV_CVRP, ENV_TSP, EVALUATE, GREEDY, NORM_BATCH_EVAL, NORM_INSTANCE, SAMPLE,  # noqa: F401
+                   ST_INFEASIBLE, ST_NAN_LOGITS, ST_STEP_OVERRUN)
+
+MODES = {"greedy": GREEDY, "sampling": SAMPLE, "evaluate": EVALUATE}
+ENVS = {"tsp": ENV_TSP, "cvrp": ENV_CVRP}
+
+
+def _need_gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: the eam_rl4co_amd rollout path runs only on an MI355X (HIP) device; "
+            "there is no CPU fallback. Move the TensorDict / policy to 'cuda'.")
+
+
+def _chk(t, name, dtype, shape=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    _need_gpu(t, name)
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _bytes(t):
+    """bool tensors are passed as their uint8 storage."""
+    return t.view(torch.uint8) if t.dtype == torch.bool else t
+
+
+# ------------------------------------------------------------------------------------------------------
+# encoder / cache
+# ------------------------------------------------------------------------------------------------------
+def linear(x, W, bias=None, relu=False, residual=None, out=None, w_cols=None):
+    """y = [residual +] act(x @ W[:, :w_cols].T + bias).  x [..., in] (last dim contiguous, rows strided ok)."""
+    lib = _lib.load()
+    _need_gpu(x, "x")
+    in_dim = x.shape[-1] if w_cols is None else w_cols[1] - w_cols[0]
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    if W.dtype != torch.float32 or W.stride(-1) != 1 or x2.dtype != torch.float32:
+        raise TypeError("linear: fp32 tensors with unit inner stride required")
+    Wv = W if w_cols is None else W[:, w_cols[0]:w_cols[1]]
+    if Wv.shape[1] != in_dim or x2.shape[1] != in_dim:
+        raise ValueError(f"linear: in_dim mismatch {tuple(x2.shape)} vs {tuple(Wv.shape)}")
+    out_dim = Wv.shape[0]
+    rows = x2.shape[0]
+    if out is None:
+        out = torch.empty(*x.shape[:-1], out_dim, device=x.device, dtype=torch.float32)
+    o2 = out.reshape(-1, out.shape[-1]) if out.dim() != 2 else out
+    if o2.stride(-1) != 1 or o2.shape[0] != rows or o2.shape[1] < out_dim and o2.shape[1] != out_dim:
+        raise ValueError("linear: bad output buffer")
+    res2 = None
+    if residual is not None:
+        res2 = residual.reshape(-1, residual.shape[-1])
+        if res2.stride(-1) != 1 or res2.shape != (rows, out_dim) or res2.dtype != torch.float32:
+            raise ValueError("linear: bad residual")
+    if bias is not None:
+        _chk(bias, "bias", torch.float32, (out_dim,))
+    _lib.check(lib.eamrl_linear(_ptr(x2), x2.stride(0), _ptr(Wv), Wv.stride(0), _ptr(bias), _ptr(res2),
+                                res2.stride(0) if res2 is not None else 0, _ptr(o2), o2.stride(0), rows, in_dim,
+                                out_dim, int(relu), _stream(x)), "eamrl_linear")
+    return out
+
+
+def matmul_right(x, Wt, out=None):
+    """y = x @ Wt   (Wt [in][out], contiguous)."""
+    lib = _lib.load()
+    _chk(Wt, "Wt", torch.float32)
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1 or x2.dtype != torch.float32:
+        raise ValueError("matmul_right: bad x")
+    _need_gpu(x2, "x")
+    rows, in_dim = x2.shape
+    if Wt.shape[0] != in_dim:
+        raise ValueError("matmul_right: in_dim mismatch")
+    out_dim = Wt.shape[1]
+    if out is None:
+        out = torch.empty(*x.shape[:-1], out_dim, device=x.device, dtype=torch.float32)
+    o2 = out.reshape(-1, out.shape[-1]) if out.dim() != 2 else out
+    if o2.stride(-1) != 1 or o2.shape != (rows, out_dim):
+        raise ValueError("matmul_right: bad output buffer")
+    _lib.check(lib.eamrl_matmul_right(_ptr(x2), x2.stride(0), _ptr(Wt), _ptr(o2), o2.stride(0), rows, in_dim, out_dim,
+                                      _stream(x)), "eamrl_matmul_right")
+    return out
+
+
+def mha_encoder(qkv, num_heads):
+    lib = _lib.load()
+    _chk(qkv, "qkv", torch.float32)
+    B, N, E3 = qkv.shape
+    out = torch.empty(B, N, E3 // 3, device=qkv.device, dtype=torch.float32)
+    _lib.check(lib.eamrl_mha_encoder(_ptr(qkv), _ptr(out), B, N, E3 // 3, num_heads, _stream(qkv)), "eamrl_mha_encoder")
+    return out
+
+
+def normalize_(x, kind, gamma, beta, mean=None, var=None, eps=1e-5):
+    lib = _lib.load()
+    _chk(x, "x", torch.float32)
+    B, N, E = x.shape
+    for nm, t in (("gamma", gamma), ("beta", beta)):
+        _chk(t, nm, torch.float32, (E,))
+    if kind == NORM_BATCH_EVAL:
+        _chk(mean, "running_mean", torch.float32, (E,))
+        _chk(var, "running_var", torch.float32, (E,))
+    _lib.check(lib.eamrl_normalize(_ptr(x), B, N, E, kind, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), eps,
+                                   _stream(x)), "eamrl_normalize")
+    return x
+
+
+def mean_nodes(emb):
+    lib = _lib.load()
+    _chk(emb, "emb", torch.float32)
+    B, M, E = emb.shape
+    out = torch.empty(B, E, device=emb.device, dtype=torch.float32)
+    _lib.check(lib.eamrl_mean_nodes(_ptr(emb), _ptr(out), B, M, E, _stream(emb)), "eamrl_mean_nodes")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# environment transitions
+# ------------------------------------------------------------------------------------------------------
+def tsp_step_(mask, first, cur, istep, action, done):
+    lib = _lib.load()
+    R, N = mask.shape
+    _chk(mask, "action_mask", torch.bool, (R, N))
+    for nm, t in (("first_node", first), ("current_node", cur), ("i", istep), ("action", action)):
+        _chk(t, nm, torch.int64)
+        if t.numel() != R:
+            raise ValueError(f"{nm} must have {R} elements")
+    _chk(done, "done", torch.bool)
+    if done.numel() != R:
+        raise ValueError("done must have R elements")
+    _lib.check(lib.eamrl_tsp_step(_ptr(_bytes(mask)), _ptr(first), _ptr(cur), _ptr(istep), _ptr(action),
+                                  _ptr(_bytes(done)), R, N, _stream(mask)), "eamrl_tsp_step")
+
+
+def cvrp_mask_(visited, used, vcap, demand, cur, mask):
+    lib = _lib.load()
+    R, M = visited.shape
+    B, N = demand.shape
+    if M != N + 1 or R % B:
+        raise ValueError("cvrp_mask: shape mismatch")
+    _chk(visited, "visited", torch.uint8)
+    _chk(mask, "action_mask", torch.bool, (R, M))
+    for nm, t in (("used_capacity", used), ("vehicle_capacity", vcap)):
+        _chk(t, nm, torch.float32)
+        if t.numel() != R:
+            raise ValueError(f"{nm} must have {R} elements")
+    _chk(demand, "demand", torch.float32)
+    _chk(cur, "current_node", torch.int64)
+    _lib.check(lib.eamrl_cvrp_mask(_ptr(visited), _ptr(used), _ptr(vcap), _ptr(demand), _ptr(cur), _ptr(_bytes(mask)),
+                                   R, B, N, _stream(mask)), "eamrl_cvrp_mask")
+
+
+def cvrp_step_mask_(visited, used, vcap, demand, cur, action, mask, done):
+    lib = _lib.load()
+    R, M = visited.shape
+    B, N = demand.shape
+    if M != N + 1 or R % B:
+        raise ValueError("cvrp_step: shape mismatch")
+    _chk(visited, "visited", torch.uint8)
+    _chk(mask, "action_mask", torch.bool, (R, M))
+    for nm, t in (("used_capacity", used), ("vehicle_capacity", vcap)):
+        _chk(t, nm, torch.float32)
+        if t.numel() != R:
+            raise ValueError(f"{nm} must have {R} elements")
+    _chk(demand, "demand", torch.float32)
+    for nm, t in (("current_node", cur), ("action", action)):
+        _chk(t, nm, torch.int64)
+        if t.numel() != R:
+            raise ValueError(f"{nm} must have {R} elements")
+    _chk(done, "done", torch.bool)
+    _lib.check(lib.eamrl_cvrp_step_mask(_ptr(visited), _ptr(used), _ptr(vcap), _ptr(demand), _ptr(cur), _ptr(action),
+                                        _ptr(_bytes(mask)), _ptr(_bytes(done)), R, B, N, _stream(mask)),
+               "eamrl_cvrp_step_mask")
+
+
+# ------------------------------------------------------------------------------------------------------
+# reward
+# ------------------------------------------------------------------------------------------------------
+def tour_length_reward(locs, actions, with_depot):
+    lib = _lib.load()
+    _chk(locs, "locs", torch.float32)
+    _chk(actions, "actions", torch.int64)
+    B, M, two = locs.shape
+    R, T = actions.shape
+    if two != 2 or R % B:
+        raise ValueError("tour_length: shape mismatch")
+    out = torch.empty(R, device=locs.device, dtype=torch.float32)
+    _lib.check(lib.eamrl_tour_length(_ptr(locs), _ptr(actions), _ptr(out), R, B, M, T, int(with_depot), _stream(locs)),
+               "eamrl_tour_length")
+    return out
+
+
+def sum_logp(logp):
+    lib = _lib.load()
+    _need_gpu(logp, "logp")
+    if logp.dtype != torch.float32 or logp.dim() != 2 or logp.stride(1) != 1:
+        raise ValueError("sum_logp: [R, T] fp32 with unit inner stride required")
+    R, T = logp.shape
+    out = torch.empty(R, device=logp.device, dtype=torch.float32)
+    _lib.check(lib.eamrl_sum_logp(_ptr(logp), logp.stride(0), _ptr(out), R, T, _stream(logp)), "eamrl_sum_logp")
+    return out
+
+
+def check_solution(env_name, actions, demand=None, vcap=None, num_loc=None):
+    """-> device int32[2]: (invalid tours, over-capacity rows)."""
+    lib = _lib.load()
+    _chk(actions, "actions", torch.int64)
+    R, T = actions.shape
+    bad = torch.zeros(2, device=actions.device, dtype=torch.int32)
+    if env_name == "tsp":
+        N, B = (T if num_loc is None else num_loc), R
+        _lib.check(lib.eamrl_check_solution(ENV_TSP, _ptr(actions), None, None, R, B, N, T, _ptr(bad), _stream(actions)),
+                   "eamrl_check_solution")
+    else:
+        _chk(demand, "demand", torch.float32)
+        B, N = demand.shape
+        vc = vcap.reshape(-1).contiguous()
+        if vc.numel() != R:
+            vc = vc.repeat(R // vc.numel())
+        _chk(vc, "vehicle_capacity", torch.float32, (R,))
+        _lib.check(lib.eamrl_check_solution(ENV_CVRP, _ptr(actions), _ptr(demand), _ptr(vc), R, B, N, T, _ptr(bad),
+                                            _stream(actions)), "eamrl_check_solution")
+    return bad
+
+
+# ------------------------------------------------------------------------------------------------------
+# decode
+# ------------------------------------------------------------------------------------------------------
+class DecodeCache:
+    """Device-resident decoder cache (struct eamrl_cache).
+
+    One [B, M, ld] fp32 buffer holds the per-node rows side by side in E-wide slots:
+        TSP : K | V | L | P_first | P_current | Lp        (ld = 6E)
+        CVRP: K | V | L | P_current | Lp                  (ld = 5E)
+    K, V, L are AttentionModelDecoder's glimpse_key / glimpse_val / logit_key
+    (zoo/am/decoder.py:206-235); P_* and Lp are the weight folds described in DESIGN.md.
+    """
+
+    def __init__(self, env_name, buf, cvec, gctx, embeddings, num_heads):
+        self.env_name, self.buf, self.cvec, self.gctx = env_name, buf, cvec, gctx
+        self.node_embeddings = embeddings
+        self.B, self.M, self.ld = buf.shape
+        self.E = embeddings.shape[-1]
+        self.H = num_heads
+        self.slots = slot_map(env_name)
+        assert self.ld == len(self.slots) * self.E
+
+    def view(self, name):
+        i = self.slots[name]
+        return self.buf[..., i * self.E:(i + 1) * self.E]
+
+    # the reference's vocabulary (PrecomputedCache fields, zoo/am/decoder.py:22-41)
+    @property
+    def glimpse_key(self):
+        return self.view("K")
+
+    @property
+    def glimpse_val(self):
+        return self.view("V")
+
+    @property
+    def logit_key(self):
+        return self.view("L")
+
+    @property
+    def graph_context(self):
+        return self.gctx if self.gctx is not None else 0
+
+    def struct(self):
+        c = _lib.Cache()
+        base, step = self.buf.data_ptr(), self.E * 4
+        c.K = C.c_void_p(base + self.slots["K"] * step)
+        c.V = C.c_void_p(base + self.slots["V"] * step)
+        c.Lp = C.c_void_p(base + self.slots["Lp"] * step)
+        c.Pa = C.c_void_p(base + self.slots["Pa"] * step)
+        c.Pb = C.c_void_p(base + self.slots["Pb"] * step) if "Pb" in self.slots else None
+        c.cvec, c.gctx = _ptr(self.cvec), _ptr(self.gctx)
+        c.ld, c.B, c.M, c.E, c.H = self.ld, self.B, self.M, self.E, self.H
+        return c
+
+
+def slot_map(env_name):
+    names = ["K", "V", "L", "Pa", "Pb", "Lp"] if env_name == "tsp" else ["K", "V", "L", "Pa", "Lp"]
+    return {n: i for i, n in enumerate(names)}
+
+
+class RolloutState:
+    """Flat per-row state tensors (struct eamrl_state) for R = S*B rows."""
+
+    def __init__(self, env_name, R, M, device, demand=None):
+        self.env_name, self.R, self.M = env_name, R, M
+        i64 = dict(dtype=torch.int64, device=device)
+        self.first = torch.zeros(R, **i64)
+        self.cur = torch.zeros(R, **i64)
+        self.istep = torch.zeros(R, **i64)
+        self.done = torch.zeros(R, dtype=torch.bool, device=device)
+        self.mask = torch.ones(R, M, dtype=torch.bool, device=device)
+        self.used = self.vcap = self.visited = None
+        self.demand = demand
+        if env_name == "cvrp":
+            self.used = torch.zeros(R, dtype=torch.float32, device=device)
+            self.vcap = torch.ones(R, dtype=torch.float32, device=device)
+            self.visited = torch.zeros(R, M, dtype=torch.uint8, device=device)
+
+    def struct(self):
+        s = _lib.State()
+        s.first, s.cur, s.istep = _ptr(self.first), _ptr(self.cur), _ptr(self.istep)
+        s.used, s.vcap, s.demand = _ptr(self.used), _ptr(self.vcap), _ptr(self.demand)
+        s.mask, s.visited, s.done = _ptr(_bytes(self.mask)), _ptr(self.visited), _ptr(_bytes(self.done))
+        return s
+
+
+def _validate_state(st: RolloutState, cache: DecodeCache):
+    R, M = st.R, st.M
+    if M != cache.M or R % cache.B:
+        raise ValueError("decode: state / cache shape mismatch")
+    _chk(st.mask, "action_mask", torch.bool, (R, M))
+    _chk(st.cur, "current_node", torch.int64, (R,))
+    _chk(st.done, "done", torch.bool, (R,))
+    if st.env_name == "tsp":
+        _chk(st.first, "first_node", torch.int64, (R,))
+        _chk(st.istep, "i", torch.int64, (R,))
+    else:
+        _chk(st.used, "used_capacity", torch.float32, (R,))
+        _chk(st.vcap, "vehicle_capacity", torch.float32, (R,))
+        _chk(st.visited, "visited", torch.uint8, (R, M))
+        _chk(st.demand, "demand", torch.float32, (cache.B, M - 1))
+
+
+def decode_step(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0,
+                fuse_env_step=False, want_logprobs=False, want_logits=False, status=None):
+    """One decode step for all rows.  -> (action [R], logp [R], logprobs [R,M] | None, logits [R,M] | None)."""
+    lib = _lib.load()
+    _validate_state(st, cache)
+    R, M, dev = st.R, st.M, st.mask.device
+    action = torch.empty(R, dtype=torch.int64, device=dev)
+    logp = torch.empty(R, dtype=torch.float32, device=dev)
+    lps = torch.empty(R, M, dtype=torch.float32, device=dev) if want_logprobs else None
+    lgs = torch.empty(R, M, dtype=torch.float32, device=dev) if want_logits else None
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+    if noise is not None:
+        _chk(noise, "noise", torch.float32, (R, M))
+    if given is not None:
+        _chk(given, "given actions", torch.int64, (R,))
+    cs, ss = cache.struct(), st.struct()
+    _lib.check(lib.eamrl_am_decode_step(ENVS[st.env_name], C.byref(cs), C.byref(ss), R, MODES[mode], _ptr(noise),
+                                        _ptr(given), float(clip), float(temp), int(fuse_env_step), _ptr(action),
+                                        _ptr(logp), _ptr(lps), _ptr(lgs), _ptr(status), _stream(st.mask)),
+               "eamrl_am_decode_step")
+    return action, logp, lps, lgs, status
+
+
+def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0,
+            t_max=None):
+    """Whole decode loop in one launch.  -> (actions [R,t_max], logps [R,t_max], info int32[2] = (steps, status))."""
+    lib = _lib.load()
+    _validate_state(st, cache)
+    R, M, dev = st.R, st.M, st.mask.device
+    if t_max is None:
+        t_max = M if st.env_name == "tsp" else 2 * M + 1
+    t_given = 0
+    if noise is not None:
+        _chk(noise, "noise", torch.float32)
+        if noise.shape[0] != R or noise.shape[2] != M or noise.shape[1] < t_max:
+            if noise.shape[0] != R or noise.shape[2] != M:
+                raise ValueError("noise must be [R, T, M]")
+            t_max = noise.shape[1]
+        elif noise.shape[1] != t_max:
+            t_max = noise.shape[1]
+    if given is not None:
+        _chk(given, "given actions", torch.int64)
+        if given.dim() != 2 or given.shape[0] != R:
+            raise ValueError("given actions must be [R, T]")
+        t_given = given.shape[1]
+        if noise is None:
+            t_max = min(t_max, t_given) if st.env_name == "cvrp" else t_max
+    actions = torch.zeros(R, t_max, dtype=torch.int64, device=dev)
+    logps = torch.zeros(R, t_max, dtype=torch.float32, device=dev)
+    info = torch.zeros(2, dtype=torch.int32, device=dev)  # [steps, status]
+    cs, ss = cache.struct(), st.struct()
+    steps_ptr = C.c_void_p(info.data_ptr())
+    status_ptr = C.c_void_p(info.data_ptr() + 4)
+    _lib.check(lib.eamrl_am_rollout(ENVS[st.env_name], C.byref(cs), C.byref(ss), R, MODES[mode], _ptr(noise),
+                                    _ptr(given), t_given, float(clip), float(temp), int(t_max), _ptr(actions),
+                                    _ptr(logps), steps_ptr, status_ptr, _stream(st.mask)), "eamrl_am_rollout")
+    return actions, logps, info
+
+
+def raise_on_status(status: int):
+    """The reference's in-loop asserts, checked once per rollout instead of once per step."""
+    if status & ST_NAN_LOGITS:
+        raise AssertionError("Logits contain NaNs")                       # nn/attention.py:303-304
+    if status & ST_INFEASIBLE:
+        raise AssertionError("infeasible action selected")               # utils/decoding.py:397-399

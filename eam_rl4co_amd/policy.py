@@ -1,0 +1,512 @@
+"""AttentionModelPolicy on MI355X kernels, behind the reference's module tree and forward signature.
+
+Reference interfaces mirrored (same constructor arguments, state_dict keys, forward kwargs, output dict):
+  rl4co/models/zoo/am/policy.py:10-122             AttentionModelPolicy
+  rl4co/models/zoo/am/encoder.py:14-91             AttentionModelEncoder
+  rl4co/models/zoo/am/decoder.py:22-235            AttentionModelDecoder / PrecomputedCache
+  rl4co/models/common/constructive/base.py:157-275 ConstructivePolicy.forward (the rollout)
+  rl4co/utils/decoding.py:17-35,193-465            decode-type registry, multistart hooks
+The nn.Module tree only exists to hold parameters under the reference's names (checkpoint contract,
+tests/golden/state_dict_contract.json); every forward computation is a libeamrl_hip.so launch.
+No CPU / PyTorch implementation of the rollout exists here: tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .envs import RL4COEnvBase, get_env
+from .tensordict_lite import TensorDict  # noqa: F401
+
+log = logging.getLogger(__name__)
+
+DECODE_TYPES = ("greedy", "sampling", "multistart_greedy", "multistart_sampling", "evaluate")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# parameter containers (names = reference state_dict keys)
+# ------------------------------------------------------------------------------------------------------------
+class TSPInitEmbedding(nn.Module):
+    def __init__(self, embed_dim, linear_bias=True):
+        super().__init__()
+        self.init_embed = nn.Linear(2, embed_dim, linear_bias)
+
+    def forward(self, td):
+        return ops.linear(td["locs"].contiguous(), self.init_embed.weight, self.init_embed.bias)
+
+
+class VRPInitEmbedding(nn.Module):
+    def __init__(self, embed_dim, linear_bias=True, node_dim: int = 3):
+        super().__init__()
+        self.init_embed = nn.Linear(node_dim, embed_dim, linear_bias)
+        self.init_embed_depot = nn.Linear(2, embed_dim, linear_bias)
+
+    def forward(self, td):
+        locs = td["locs"]
+        depot = ops.linear(locs[:, :1, :].contiguous(), self.init_embed_depot.weight, self.init_embed_depot.bias)
+        feat = torch.cat((locs[:, 1:, :], td["demand"][..., None]), -1)   # [B, N, 3] input assembly (plumbing)
+        cust = ops.linear(feat, self.init_embed.weight, self.init_embed.bias)
+        return torch.cat((depot, cust), 1)
+
+
+class _Holder(nn.Module):
+    """`.module` wrapper so that parameter names match the reference's SkipConnection(...)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+
+class _MHAParams(nn.Module):
+    def __init__(self, embed_dim, num_heads, bias=True):
+        super().__init__()
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.Wqkv = nn.Linear(embed_dim, 3 * embed_dim, bias=bias)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+
+
+class _MLPParams(nn.Module):
+    def __init__(self, input_dim, output_dim, num_neurons):
+        super().__init__()
+        dims = [input_dim] + list(num_neurons) + [output_dim]
+        self.lins = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+
+class Normalization(nn.Module):
+    def __init__(self, embed_dim, normalization="batch"):
+        super().__init__()
+        if normalization == "batch":
+            self.normalizer = nn.BatchNorm1d(embed_dim, affine=True)
+        elif normalization == "instance":
+            self.normalizer = nn.InstanceNorm1d(embed_dim, affine=True)
+        else:
+            raise NotImplementedError(f"normalization={normalization!r}: only 'batch' (eval) and 'instance' are "
+                                      "built for MI355X")
+
+    def apply_(self, x):
+        n = self.normalizer
+        if isinstance(n, nn.BatchNorm1d):
+            if self.training:
+                raise NotImplementedError(
+                    "BatchNorm batch statistics (policy.train()) are not part of the MI355X rollout path; "
+                    "call policy.eval() (RolloutBaseline / evaluation do, reinforce/baselines.py:232)")
+            return ops.normalize_(x, ops.NORM_BATCH_EVAL, n.weight, n.bias, n.running_mean, n.running_var, n.eps)
+        return ops.normalize_(x, ops.NORM_INSTANCE, n.weight, n.bias, eps=n.eps)
+
+
+class MultiHeadAttentionLayer(nn.Sequential):
+    """[SkipConnection(MHA), Normalization, SkipConnection(MLP), Normalization] (nn/graph/attnnet.py:16-57)."""
+
+    def __init__(self, embed_dim, num_heads=8, feedforward_hidden=512, normalization="batch", bias=True):
+        super().__init__(
+            _Holder(_MHAParams(embed_dim, num_heads, bias=bias)),
+            Normalization(embed_dim, normalization),
+            _Holder(_MLPParams(embed_dim, embed_dim, [feedforward_hidden] if feedforward_hidden > 0 else [])),
+            Normalization(embed_dim, normalization),
+        )
+
+    def forward(self, h):
+        mha, ffn = self[0].module, self[2].module
+        qkv = ops.linear(h, mha.Wqkv.weight, mha.Wqkv.bias)
+        att = ops.mha_encoder(qkv, mha.num_heads)
+        h = ops.linear(att, mha.out_proj.weight, mha.out_proj.bias, residual=h)     # h + MHA(h)
+        h = self[1].apply_(h)
+        x = h
+        for lin in ffn.lins[:-1]:
+            x = ops.linear(x, lin.weight, lin.bias, relu=True)
+        h = ops.linear(x, ffn.lins[-1].weight, ffn.lins[-1].bias, residual=h)        # h + FFN(h)
+        return self[3].apply_(h)
+
+
+class GraphAttentionNetwork(nn.Module):
+    def __init__(self, num_heads, embed_dim, num_layers, normalization="batch", feedforward_hidden=512):
+        super().__init__()
+        self.layers = nn.Sequential(*(MultiHeadAttentionLayer(embed_dim, num_heads, feedforward_hidden, normalization)
+                                      for _ in range(num_layers)))
+
+    def forward(self, x, mask=None):
+        assert mask is None, "Mask not yet supported!"
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+class AttentionModelEncoder(nn.Module):
+    def __init__(self, embed_dim=128, init_embedding=None, env_name="tsp", num_heads=8, num_layers=3,
+                 normalization="batch", feedforward_hidden=512, net=None, sdpa_fn=None, moe_kwargs=None):
+        super().__init__()
+        if isinstance(env_name, RL4COEnvBase):
+            env_name = env_name.name
+        if moe_kwargs is not None or sdpa_fn is not None:
+            raise NotImplementedError("moe_kwargs / sdpa_fn injection is outside the MI355X rollout path")
+        self.env_name = env_name
+        if init_embedding is None:
+            init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding}[env_name](embed_dim)
+        self.init_embedding = init_embedding
+        self.net = GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden) \
+            if net is None else net
+
+    def forward(self, td, mask=None):
+        init_h = self.init_embedding(td)
+        h = self.net(init_h, mask)
+        return h, init_h
+
+
+class _ContextParams(nn.Module):
+    def __init__(self, embed_dim, step_context_dim, placeholder):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.project_context = nn.Linear(step_context_dim, embed_dim, bias=False)
+        if placeholder:
+            self.W_placeholder = nn.Parameter(torch.Tensor(2 * embed_dim).uniform_(-1, 1))
+
+
+class _PointerParams(nn.Module):
+    def __init__(self, embed_dim, num_heads, mask_inner=True, out_bias=False, check_nan=True):
+        super().__init__()
+        if not mask_inner or out_bias:
+            raise NotImplementedError("mask_inner=False / out_bias_pointer_attn=True are not built for MI355X")
+        self.num_heads, self.mask_inner, self.check_nan = num_heads, mask_inner, check_nan
+        self.project_out = nn.Linear(embed_dim, embed_dim, bias=False)
+
+
+class StaticEmbedding(nn.Module):
+    def forward(self, td):
+        return 0, 0, 0
+
+
+class AttentionModelDecoder(nn.Module):
+    """Pointer decoder.  `_precompute_cache` is the one-shot part (GEMMs), `forward` one decode step."""
+
+    def __init__(self, embed_dim=128, num_heads=8, env_name="tsp", context_embedding=None, dynamic_embedding=None,
+                 mask_inner=True, out_bias_pointer_attn=False, linear_bias=False, use_graph_context=True,
+                 check_nan=True, sdpa_fn=None, pointer=None, moe_kwargs=None):
+        super().__init__()
+        if isinstance(env_name, RL4COEnvBase):
+            env_name = env_name.name
+        if any(x is not None for x in (context_embedding, dynamic_embedding, sdpa_fn, pointer, moe_kwargs)) or linear_bias:
+            raise NotImplementedError("custom context/dynamic embeddings, pointer, sdpa_fn, MoE and decoder biases are "
+                                      "outside the MI355X rollout path (TSP / CVRP AttentionModel only)")
+        assert embed_dim % num_heads == 0
+        self.env_name, self.embed_dim, self.num_heads = env_name, embed_dim, num_heads
+        self.context_embedding = _ContextParams(embed_dim, 2 * embed_dim if env_name == "tsp" else embed_dim + 1,
+                                                placeholder=(env_name == "tsp"))
+        self.dynamic_embedding = StaticEmbedding()
+        self.is_dynamic_embedding = False
+        self.pointer = _PointerParams(embed_dim, num_heads, mask_inner, out_bias_pointer_attn, check_nan)
+        self.project_node_embeddings = nn.Linear(embed_dim, 3 * embed_dim, bias=False)
+        self.project_fixed_context = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.use_graph_context = use_graph_context
+
+    def _precompute_cache(self, embeddings: torch.Tensor, num_starts: int = 0) -> ops.DecodeCache:
+        """K | V | L (+ folded context / logit projections) in one slot-major buffer (ops.DecodeCache)."""
+        E = self.embed_dim
+        emb = embeddings.contiguous()
+        B, M, _ = emb.shape
+        slots = ops.slot_map(self.env_name)
+        buf = torch.empty(B, M, len(slots) * E, device=emb.device, dtype=torch.float32)
+        flat = buf.view(B * M, -1)
+        Wctx = self.context_embedding.project_context.weight
+        ops.linear(emb, self.project_node_embeddings.weight, out=flat[:, 0:3 * E])
+        ops.linear(emb, Wctx, w_cols=(0, E), out=flat[:, slots["Pa"] * E:(slots["Pa"] + 1) * E])
+        if self.env_name == "tsp":
+            ops.linear(emb, Wctx, w_cols=(E, 2 * E), out=flat[:, slots["Pb"] * E:(slots["Pb"] + 1) * E])
+            cvec = ops.linear(self.context_embedding.W_placeholder[None, :], Wctx)[0]
+        else:
+            cvec = Wctx[:, E].contiguous()
+        ops.matmul_right(flat[:, slots["L"] * E:(slots["L"] + 1) * E], self.pointer.project_out.weight.contiguous(),
+                         out=flat[:, slots["Lp"] * E:(slots["Lp"] + 1) * E])
+        gctx = None
+        if self.use_graph_context:
+            gctx = ops.linear(ops.mean_nodes(emb), self.project_fixed_context.weight)
+        return ops.DecodeCache(self.env_name, buf, cvec.contiguous(), gctx, emb, self.num_heads)
+
+    def pre_decoder_hook(self, td, env, embeddings, num_starts: int = 0):
+        return td, env, self._precompute_cache(embeddings, num_starts=num_starts)
+
+    def forward(self, td, cached: ops.DecodeCache, num_starts: int = 0):
+        """(logits, mask) for the current state, as the reference decoder returns them (decoder.py:161-198)."""
+        st = state_from_td(self.env_name, td)
+        _, _, _, logits, status = ops.decode_step(st, cached, "greedy", clip=0.0, temp=1.0, want_logits=True)
+        if self.pointer.check_nan:
+            ops.raise_on_status(int(status.item()) & ops.ST_NAN_LOGITS)
+        return logits, td["action_mask"]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# TensorDict <-> flat rollout state
+# ------------------------------------------------------------------------------------------------------------
+def state_from_td(env_name, td, num_starts: int = 0) -> ops.RolloutState:
+    """Flat state tensors for R = max(S,1)*B rows.  With S <= 1 the td's own tensors are used (updated in place);
+    with multistart they are replicated in the reference's (s b) order (utils/ops.py:13-33 batchify)."""
+    mask = td["action_mask"]
+    B, M = mask.shape
+    S = max(int(num_starts), 1)
+    dev = mask.device
+    if not mask.is_cuda:
+        raise RuntimeError(f"TensorDict is on {dev}: the eam_rl4co_amd rollout path runs only on an MI355X (HIP) "
+                           "device; there is no CPU fallback. Use td.to('cuda').")
+    st = ops.RolloutState.__new__(ops.RolloutState)
+    st.env_name, st.R, st.M = env_name, B * S, M
+
+    def rep(t, dtype):
+        t = t.reshape(B, -1) if t.dim() > 1 else t.reshape(B)
+        if t.dtype != dtype:
+            t = t.to(dtype)
+        if S > 1:
+            t = t.repeat(S, *([1] * (t.dim() - 1)))
+        t = t.contiguous()
+        return t.reshape(-1) if t.dim() == 2 and t.shape[1] == 1 else t
+
+    st.mask = rep(mask, torch.bool)
+    st.cur = rep(td["current_node"], torch.int64)
+    done = td["done"] if "done" in td.keys() else torch.zeros(B, dtype=torch.bool, device=dev)
+    st.done = rep(done, torch.bool)
+    st.first = st.istep = st.used = st.vcap = st.visited = st.demand = None
+    if env_name == "tsp":
+        st.first = rep(td["first_node"], torch.int64)
+        st.istep = rep(td["i"], torch.int64)
+    else:
+        st.used = rep(td["used_capacity"], torch.float32)
+        st.vcap = rep(td["vehicle_capacity"], torch.float32)
+        st.visited = rep(td["visited"], torch.uint8)
+        st.demand = td["demand"].contiguous()
+    return st
+
+
+def state_to_td(env_name, st: ops.RolloutState, td, locs_rows=None):
+    """TensorDict of the final state in the reference's post-step shapes."""
+    R = st.R
+    out = {"action_mask": st.mask, "done": st.done, "reward": torch.zeros_like(st.done)}
+    if env_name == "tsp":
+        out.update({"first_node": st.first, "current_node": st.cur, "i": st.istep.reshape(R, 1)})
+    else:
+        out.update({"current_node": st.cur.reshape(R, 1), "used_capacity": st.used.reshape(R, 1),
+                    "vehicle_capacity": st.vcap.reshape(R, 1), "visited": st.visited})
+    B = td.batch_size[0]
+    S = R // B
+    for k, v in td.items():
+        if k in out or k == "action":
+            continue
+        out[k] = v if S == 1 else v.repeat(S, *([1] * (v.dim() - 1)))
+    return TensorDict(out, batch_size=[R])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the policy
+# ------------------------------------------------------------------------------------------------------------
+class AttentionModelPolicy(nn.Module):
+    """Kool et al. (2019) attention model; see module docstring.  Constructor arguments follow
+    rl4co/models/zoo/am/policy.py:50-122 (unsupported injections raise NotImplementedError)."""
+
+    def __init__(self, encoder: nn.Module = None, decoder: nn.Module = None, embed_dim: int = 128,
+                 num_encoder_layers: int = 3, num_heads: int = 8, normalization: str = "batch",
+                 feedforward_hidden: int = 512, env_name: str = "tsp", encoder_network: nn.Module = None,
+                 init_embedding: nn.Module = None, context_embedding: nn.Module = None,
+                 dynamic_embedding: nn.Module = None, use_graph_context: bool = True,
+                 linear_bias_decoder: bool = False, sdpa_fn=None, sdpa_fn_encoder=None, sdpa_fn_decoder=None,
+                 mask_inner: bool = True, out_bias_pointer_attn: bool = False, check_nan: bool = True,
+                 temperature: float = 1.0, tanh_clipping: float = 10.0, mask_logits: bool = True,
+                 train_decode_type: str = "sampling", val_decode_type: str = "greedy",
+                 test_decode_type: str = "greedy", moe_kwargs: dict = None, **unused_kwargs):
+        super().__init__()
+        if unused_kwargs:
+            log.error("Found %d unused kwargs: %s", len(unused_kwargs), unused_kwargs)
+        if isinstance(env_name, RL4COEnvBase):
+            env_name = env_name.name
+        if env_name not in ("tsp", "cvrp"):
+            raise NotImplementedError(f"env_name={env_name!r}: the MI355X rollout path covers 'tsp' and 'cvrp'")
+        if moe_kwargs not in (None, {"encoder": None, "decoder": None}) or any(
+                x is not None for x in (sdpa_fn, sdpa_fn_encoder, sdpa_fn_decoder, encoder_network)):
+            raise NotImplementedError("MoE / sdpa_fn / encoder_network injection is outside the MI355X rollout path")
+        if not mask_logits:
+            raise NotImplementedError("mask_logits=False is not built for MI355X")
+        self.env_name = env_name
+        self.encoder = encoder if encoder is not None else AttentionModelEncoder(
+            embed_dim=embed_dim, num_heads=num_heads, num_layers=num_encoder_layers, env_name=env_name,
+            normalization=normalization, feedforward_hidden=feedforward_hidden, init_embedding=init_embedding)
+        self.decoder = decoder if decoder is not None else AttentionModelDecoder(
+            embed_dim=embed_dim, num_heads=num_heads, env_name=env_name, context_embedding=context_embedding,
+            dynamic_embedding=dynamic_embedding, mask_inner=mask_inner, out_bias_pointer_attn=out_bias_pointer_attn,
+            linear_bias=linear_bias_decoder, use_graph_context=use_graph_context, check_nan=check_nan)
+        self.temperature, self.tanh_clipping, self.mask_logits = temperature, tanh_clipping, mask_logits
+        self.train_decode_type, self.val_decode_type, self.test_decode_type = (
+            train_decode_type, val_decode_type, test_decode_type)
+
+    @torch.no_grad()
+    def forward(self, td, env: Optional[str | RL4COEnvBase] = None, phase: str = "train", calc_reward: bool = True,
+                return_actions: bool = True, return_entropy: bool = False, return_hidden: bool = False,
+                return_init_embeds: bool = False, return_sum_log_likelihood: bool = True, actions=None,
+                max_steps=1_000_000, **decoding_kwargs) -> dict:
+        """The construction rollout (constructive/base.py:157-275): encode once, precompute the cache, run the
+        whole decode loop on the device, compute reward and log-likelihood.  Gradients are not produced here."""
+        if isinstance(env, str) or env is None:
+            env = get_env(self.env_name if env is None else env)
+        if env.name != self.env_name:
+            raise ValueError(f"policy built for {self.env_name!r} got env {env.name!r}")
+
+        # decode type and strategy options (base.py:203-219, decoding.py:17-35,193-262)
+        decode_type = decoding_kwargs.pop("decode_type", None)
+        given_type = None
+        if actions is not None:
+            given_type, decode_type = decode_type, "evaluate"
+        elif decode_type is None:
+            decode_type = getattr(self, f"{phase}_decode_type")
+        if decode_type not in DECODE_TYPES:
+            if decode_type == "beam_search":
+                raise NotImplementedError("beam_search is outside the MI355X rollout path")
+            log.warning("Unknown decode type '%s'. Defaulting to sampling.", decode_type)
+            decode_type = "sampling"
+        temperature = decoding_kwargs.pop("temperature", self.temperature)
+        tanh_clipping = decoding_kwargs.pop("tanh_clipping", self.tanh_clipping)
+        if not decoding_kwargs.pop("mask_logits", self.mask_logits):
+            raise NotImplementedError("mask_logits=False is not built for MI355X")
+        store_all_logp = decoding_kwargs.pop("store_all_logp", return_entropy)
+        num_starts = decoding_kwargs.pop("num_starts", None)
+        num_samples = decoding_kwargs.pop("num_samples", None)
+        multistart = decoding_kwargs.pop("multistart", False) or "multistart" in decode_type or (
+            actions is not None and given_type is not None and "multistart" in given_type)
+        multisample = decoding_kwargs.pop("multisample", False)
+        select_best = decoding_kwargs.pop("select_best", False)
+        select_start_nodes_fn = decoding_kwargs.pop("select_start_nodes_fn", None)
+        noise = decoding_kwargs.pop("noise", None)      # [R, T, M] Exp(1) draws replacing torch.multinomial's
+        for k in ("top_k", "top_p"):
+            if decoding_kwargs.pop(k, 0):
+                raise NotImplementedError(f"{k} filtering is outside the MI355X rollout path")
+        if decoding_kwargs:
+            log.warning("ignored decoding kwargs: %s", list(decoding_kwargs))
+        assert not (multistart and multisample), "Using both multistart and multisample is not supported"
+        if num_samples is not None:
+            multisample = num_samples > 1
+        if num_starts is not None:
+            multistart = num_starts > 1
+        S = 0
+        if multistart or multisample:
+            S = num_starts if multistart else num_samples
+            if S is None:
+                S = env.get_num_starts(td)
+        mode = "evaluate" if actions is not None else ("greedy" if "greedy" in decode_type else "sampling")
+
+        # encoder + cache (one-shot)
+        hidden, init_embeds = self.encoder(td)
+        cache = self.decoder._precompute_cache(hidden, num_starts=S)
+
+        # pre-decoder hook (decoding.py:284-332): multistart picks the first node, state replicated S times
+        st = state_from_td(self.env_name, td, S)
+        pre_actions, pre_logps = [], []
+        if S >= 1 and multistart:
+            if actions is not None:
+                start, actions = actions[..., 0].contiguous(), actions[..., 1:]
+            elif select_start_nodes_fn is not None:
+                start = select_start_nodes_fn(td, env, S)
+            else:
+                start = env.select_start_nodes(td, num_starts=S)
+            start = start.to(torch.int64).contiguous()
+            if self.env_name == "tsp":
+                ops.tsp_step_(st.mask, st.first, st.cur, st.istep, start, st.done)
+            else:
+                ops.cvrp_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, start, st.mask, st.done)
+            pre_actions, pre_logps = [start[:, None]], [torch.zeros(st.R, 1, dtype=torch.float32, device=start.device)]
+
+        # main decoding loop: one launch
+        M = st.M
+        t_max = M if self.env_name == "tsp" else 2 * M + 1
+        t_max = int(min(t_max, max_steps))
+        given = None
+        if actions is not None:
+            given = actions.to(torch.int64).contiguous()
+            t_max = min(t_max, given.shape[1]) if given.shape[1] > 0 else t_max
+        if mode == "sampling":
+            if noise is None:
+                noise = torch.empty(st.R, t_max, M, dtype=torch.float32, device=st.mask.device).exponential_(1)
+            else:
+                noise = noise.to(device=st.mask.device, dtype=torch.float32).contiguous()
+        all_logp = None
+        if store_all_logp:
+            acts, lps, all_logp, T, status = self._rollout_stepwise(st, cache, mode, noise, given, tanh_clipping,
+                                                                    temperature, t_max)
+        else:
+            acts, lps, info = ops.rollout(st, cache, mode, noise=noise, given=given, clip=tanh_clipping,
+                                          temp=temperature, t_max=t_max)
+            T, status = info.tolist()   # the rollout's single device->host sync
+        ops.raise_on_status(status)
+        if status & ops.ST_STEP_OVERRUN:
+            log.error("Exceeded maximum number of steps (%d) during decoding", t_max)
+        assert T > 0 or pre_actions, \
+            "No logprobs were collected because all environments were done. Check your initial state"
+        actions_out = torch.cat(pre_actions + [acts[:, :T]], 1)
+        logprobs = torch.cat(pre_logps + [lps[:, :T]], 1)
+        td_out = state_to_td(self.env_name, st, td)
+
+        if S > 0 and select_best:
+            raise NotImplementedError("select_best is outside the MI355X rollout path (use unbatchify + max on reward)")
+
+        if calc_reward:
+            td_out.set("reward", env.get_reward(td_out, actions_out))
+        td_mask = td_out.get("mask", None)
+        if td_mask is not None:
+            logprobs = logprobs.masked_fill(~td_mask, 0)
+        # get_log_likelihood (decoding.py:38-64); -inf would mean an infeasible action slipped through
+        ll = ops.sum_logp(logprobs) if return_sum_log_likelihood else logprobs
+        out = {"reward": td_out["reward"], "log_likelihood": ll}
+        if return_actions:
+            out["actions"] = actions_out
+        if return_entropy:
+            lp = torch.nan_to_num(all_logp, nan=0.0, neginf=0.0)
+            out["entropy"] = -(lp.exp() * lp).sum(-1).sum(1)
+        if return_hidden:
+            out["hidden"] = cache
+        if return_init_embeds:
+            out["init_embeds"] = init_embeds
+        self._last_td = td_out   # final env state of the last rollout (the reference keeps it in a local)
+        return out
+
+    def _rollout_stepwise(self, st, cache, mode, noise, given, clip, temp, t_max):
+        """Step-API loop (one fused decode+env launch per step) used when every step's full log-prob row
+        is wanted (store_all_logp / return_entropy).  The loop condition is checked on the host each step,
+        as the reference does."""
+        acts, lps, alls = [], [], []
+        status = torch.zeros(1, dtype=torch.int32, device=st.mask.device)
+        t = 0
+        while t < t_max and not bool(st.done.all()):
+            a, lp, all_lp, _, _ = ops.decode_step(
+                st, cache, mode, noise=None if noise is None else noise[:, t].contiguous(),
+                given=None if given is None else given[:, t].contiguous(), clip=clip, temp=temp,
+                fuse_env_step=True, want_logprobs=True, status=status)
+            acts.append(a)
+            lps.append(lp)
+            alls.append(all_lp)
+            t += 1
+        R, M = st.R, st.M
+        dev = st.mask.device
+        acts = torch.stack(acts, 1) if acts else torch.zeros(R, 0, dtype=torch.int64, device=dev)
+        lps = torch.stack(lps, 1) if lps else torch.zeros(R, 0, dtype=torch.float32, device=dev)
+        alls = torch.stack(alls, 1) if alls else torch.zeros(R, 0, M, dtype=torch.float32, device=dev)
+        return acts, lps, alls, t, int(status.item())
+
+
+def rollout(env, td, policy, max_steps: int = None):
+    """Test helper with the reference's signature (utils/decoding.py:87-108): policy is a callable td -> td
+    that sets td["action"]."""
+    max_steps = float("inf") if max_steps is None else max_steps
+    actions, steps = [], 0
+    while not td["done"].all():
+        td = policy(td)
+        actions.append(td["action"])
+        td = env.step(td)["next"]
+        steps += 1
+        if steps > max_steps:
+            break
+    actions = torch.stack(actions, 1)
+    return env.get_reward(td, actions), td, actions
+
+
+def random_policy(td):
+    """Uniform choice among feasible actions (utils/decoding.py:80-84)."""
+    td.set("action", torch.multinomial(td["action_mask"].float(), 1).squeeze(-1))
+    return td

@@ -1,0 +1,174 @@
+/*
+ * eamrl.h -- C ABI of libeamrl_hip.so: the MI355X (gfx950) construction-rollout hot path.
+ *
+ * The reference (RL4CO fork, /root/reference) is pure Python and has no FFI; its seam for this
+ * path is the RL4COEnvBase / AttentionModelPolicy Python interface.  The
+ * entry points below are what a binding for that seam calls; each cites the reference code it
+ * replaces (paths relative to /root/reference).  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); kernels are only enqueued:
+ *     no entry point allocates, frees, copies to the host or synchronises;
+ *   - return value: 0 = enqueued, <0 = rejected before launch (EAMRL_E_*); text via eamrl_last_error();
+ *   - data-dependent failures found ON the device (the reference's asserts) are OR-ed into the
+ *     caller's `status` word (device int32, caller zeroes it): EAMRL_ST_* bits;
+ *   - floats are fp32, indices int64 (torch.long), masks/visited uint8 (torch.bool / torch.uint8
+ *     storage), all row-major and contiguous unless a leading dimension `ld*` (in elements) is given;
+ *   - "rows" R are rollout rows: one per instance, or S*B rows in the reference's "(s b)" order for
+ *     multistart (row r reads the cache of instance r % B)   [rl4co/utils/ops.py:13-56];
+ *   - arithmetic follows the defined order documented in DESIGN.md ("Canonical arithmetic"); results
+ *     are bit-identical to oracle/eamrl_oracle.c.
+ */
+#ifndef EAMRL_H
+#define EAMRL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EAMRL_VERSION 100 /* 0.1.0 */
+
+/* environments */
+#define EAMRL_ENV_TSP 0
+#define EAMRL_ENV_CVRP 1
+/* selection modes  [rl4co/utils/decoding.py:430-465] */
+#define EAMRL_GREEDY 0
+#define EAMRL_SAMPLE 1   /* argmax(p / noise), noise ~ Exp(1) supplied by the caller (== torch.multinomial) */
+#define EAMRL_EVALUATE 2 /* teacher forcing: action given */
+/* normalisation kinds  [rl4co/models/nn/ops.py:32-56] */
+#define EAMRL_NORM_BATCH_EVAL 0
+#define EAMRL_NORM_INSTANCE 1
+
+/* host-side rejections */
+#define EAMRL_E_ARG (-1)     /* bad size / null pointer / unsupported shape */
+#define EAMRL_E_LAUNCH (-2)  /* hipLaunchKernel failed */
+/* device-side status bits (the reference's asserts) */
+#define EAMRL_ST_NAN_LOGITS 1u     /* "Logits contain NaNs"          nn/attention.py:303-304 */
+#define EAMRL_ST_INFEASIBLE 2u     /* "infeasible action selected"   utils/decoding.py:397-399,413-415 */
+#define EAMRL_ST_STEP_OVERRUN 4u   /* decode loop hit t_max before all rows were done   constructive/base.py:246-250 */
+
+int eamrl_version(void);
+const char* eamrl_last_error(void);
+/* Diagnostic knobs (tests / profiling only; results never depend on them, only the kernel variant used).
+ * key 0: 1 = run eamrl_linear on the VALU cross-check kernel instead of the MFMA kernel.
+ * key 1: 1 = eamrl_am_rollout always uses the streaming kernel (never the register-resident one). */
+int eamrl_debug_set(int key, int value);
+
+/* ---- environment state machines ---------------------------------------------------------------- */
+
+/* TSPEnv._step  [rl4co/envs/routing/tsp/env.py:62-88].  In place on (mask, first, cur, istep, done).
+ * mask [R][N] u8 (1 = still available), first/cur/istep [R] i64, action [R] i64, done [R] u8. */
+int eamrl_tsp_step(uint8_t* mask, int64_t* first, int64_t* cur, int64_t* istep, const int64_t* action,
+                   uint8_t* done, int64_t R, int N, void* stream);
+
+/* CVRPEnv.get_action_mask  [rl4co/envs/routing/cvrp/env.py:132-144].  M = N + 1 nodes, depot = 0.
+ * visited [R][M] u8, used/vcap [R] f32, demand [B][N] f32, cur [R] i64 -> mask [R][M] u8 (1 = feasible). */
+int eamrl_cvrp_mask(const uint8_t* visited, const float* used, const float* vcap, const float* demand,
+                    const int64_t* cur, uint8_t* mask, int64_t R, int64_t B, int N, void* stream);
+
+/* CVRPEnv._step + get_action_mask  [rl4co/envs/routing/cvrp/env.py:68-100,132-144].  In place. */
+int eamrl_cvrp_step_mask(uint8_t* visited, float* used, const float* vcap, const float* demand, int64_t* cur,
+                         const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N,
+                         void* stream);
+
+/* ---- one-shot encoder + cache ------------------------------------------------------------------- */
+
+/* y[r][j] = bias[j] + sum_k x[r][k] * W[j][k]  (k-ordered fma chain), optional ReLU, optional residual:
+ * y = res + (...) .  torch.nn.Linear as used by init embeddings, Wqkv/out_proj, the FFN and the decoder's
+ * projections  [models/nn/env_embeddings/init.py:55-68,115-138; nn/attention.py:112-136; nn/mlp.py:52-61;
+ * zoo/am/decoder.py:206-235].  W is [out][in] (ldw = in unless given).  x rows have stride ldx, y rows ldy. */
+int eamrl_linear(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* res,
+                 int64_t ldres, float* y, int64_t ldy, int64_t rows, int in_dim, int out_dim, int relu, void* stream);
+
+/* y[r][j] = sum_k x[r][k] * Wt[k][j]  (right-multiplication; folds PointerAttention.project_out into the
+ * logit key: Lp = L * Wout)  [nn/attention.py:296-301]. */
+int eamrl_matmul_right(const float* x, int64_t ldx, const float* Wt, float* y, int64_t ldy, int64_t rows,
+                       int in_dim, int out_dim, void* stream);
+
+/* Encoder self-attention on packed qkv [B][N][3E] ("b s (three h d)"), no mask -> out [B][N][E]
+ * [nn/attention.py:112-136 MultiHeadAttention.forward]. */
+int eamrl_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H, void* stream);
+
+/* Normalization.forward in place on x [B][N][E]  [nn/ops.py:32-56].
+ * BATCH_EVAL uses running stats (mean, var); INSTANCE ignores them (may be NULL). */
+int eamrl_normalize(float* x, int64_t B, int N, int E, int kind, const float* gamma, const float* beta,
+                    const float* mean, const float* var, float eps, void* stream);
+
+/* out[b][e] = (sum_n emb[b][n][e]) / M   (embeddings.mean(1), zoo/am/decoder.py:225-227) */
+int eamrl_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, void* stream);
+
+/* ---- per-step decode ------------------------------------------------------------------------------ */
+
+/* The decoder cache of one batch (AttentionModelDecoder._precompute_cache, zoo/am/decoder.py:206-235),
+ * with the two weight folds of DESIGN.md:  Pa/Pb = node embeddings already multiplied by the halves of
+ * context_embedding.project_context (nn/env_embeddings/context.py:50-74,105-157) and Lp = logit key times
+ * pointer.project_out.  All [B][M][*] with a common row stride `ld` (elements). */
+typedef struct eamrl_cache {
+    const float* K;    /* glimpse key   */
+    const float* V;    /* glimpse value */
+    const float* Lp;   /* logit key * project_out */
+    const float* Pa;   /* TSP: first-node half; CVRP: current-node part */
+    const float* Pb;   /* TSP: current-node half; CVRP: NULL */
+    const float* cvec; /* [E]  TSP: project_context(W_placeholder); CVRP: capacity column of project_context */
+    const float* gctx; /* [B][E] graph context or NULL (POMO: use_graph_context=False) */
+    int64_t ld;        /* row stride of K/V/Lp/Pa/Pb in floats (>= E) */
+    int64_t B;         /* instances */
+    int32_t M, E, H;   /* nodes (incl. depot), embed dim, heads */
+} eamrl_cache;
+
+/* Per-row rollout state (the TensorDict keys the reference's env keeps, tsp/env.py:105-115,
+ * cvrp/env.py:110-130).  Unused members for an env may be NULL. */
+typedef struct eamrl_state {
+    int64_t* first;    /* [R] TSP first_node */
+    int64_t* cur;      /* [R] current_node */
+    int64_t* istep;    /* [R] TSP i */
+    float* used;       /* [R] CVRP used_capacity */
+    const float* vcap; /* [R] CVRP vehicle_capacity */
+    const float* demand; /* [B][N] CVRP demand */
+    uint8_t* mask;     /* [R][M] action_mask (1 = feasible) */
+    uint8_t* visited;  /* [R][M] CVRP visited */
+    uint8_t* done;     /* [R] */
+} eamrl_state;
+
+/* One decode step for R rows = AttentionModelDecoder.forward + DecodingStrategy.step
+ * [zoo/am/decoder.py:161-198; nn/attention.py:282-328; utils/decoding.py:140-190,346-465]:
+ * context query -> 8-head masked glimpse -> logits -> tanh clip -> mask -> /temperature -> log_softmax ->
+ * greedy / sampling / evaluate.  Reads the state, does not modify it unless fuse_env_step != 0, in which
+ * case it also applies TSPEnv._step / CVRPEnv._step (+mask) with the selected action.
+ * noise [R][M] (SAMPLE) / given [R] (EVALUATE) else NULL.  Outputs: action [R], logp [R];
+ * optional logprobs_all [R][M] (store_all_logp) and logits_raw [R][M] (pre-clip decoder logits). */
+int eamrl_am_decode_step(int env, const eamrl_cache* cache_host, const eamrl_state* state_host, int64_t R,
+                         int mode, const float* noise, const int64_t* given, float tanh_clip, float temperature,
+                         int fuse_env_step, int64_t* action, float* logp, float* logprobs_all, float* logits_raw,
+                         uint32_t* status, void* stream);
+
+/* Whole decode loop in one launch (ConstructivePolicy.forward's while-loop, constructive/base.py:236-250):
+ * repeats {decode step, env step} until every row is done or t_max steps were taken.  actions/logps are
+ * [R][t_max] (right-padded: finished CVRP rows keep selecting the depot, logp 0).  noise [R][t_max][M],
+ * given [R][t_given].  steps_out (device int32): number of steps executed = max over rows. */
+int eamrl_am_rollout(int env, const eamrl_cache* cache_host, const eamrl_state* state_host, int64_t R, int mode,
+                     const float* noise, const int64_t* given, int t_given, float tanh_clip, float temperature,
+                     int t_max, int64_t* actions, float* logps, int32_t* steps_out, uint32_t* status, void* stream);
+
+/* ---- reward ----------------------------------------------------------------------------------------- */
+
+/* reward[r] = -(closed tour length)  [utils/ops.py:59-95; tsp/env.py:152-159; cvrp/env.py:146-155].
+ * locs [B][M][2]; actions [R][T]; with_depot prepends node 0 (CVRP). */
+int eamrl_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R, int64_t B, int M, int T,
+                      int with_depot, void* stream);
+
+/* out[r] = sum_t logp[r][t], sequential  (get_log_likelihood, utils/decoding.py:38-64) */
+int eamrl_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, void* stream);
+
+/* check_solution_validity on the device: bad[0] += invalid tours, bad[1] += over-capacity rows
+ * [tsp/env.py:161-168; cvrp/env.py:157-185].  bad: device int32[2], caller zeroes. */
+int eamrl_check_solution(int env, const int64_t* actions, const float* demand, const float* vcap, int64_t R,
+                         int64_t B, int N, int T, int32_t* bad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAMRL_H */

@@ -157,10 +157,26 @@ ORC_API float orc_lane_tree(const float* v, int n) { return lane_tree(v, n); }
 ORC_API void orc_linear(const float* x, const float* W, const float* bias, float* y,
                         long rows, int in_dim, int out_dim, int relu)
 {
+    /* 8 output columns at a time: 8 independent chains (each still strictly k-ascending) hide the fma latency */
 #pragma omp parallel for schedule(static)
     for (long r = 0; r < rows; ++r) {
         const float* xr = x + r * in_dim;
-        for (int j = 0; j < out_dim; ++j) {
+        int j = 0;
+        for (; j + 8 <= out_dim; j += 8) {
+            const float* w = W + (long)j * in_dim;
+            float a[8];
+            for (int c = 0; c < 8; ++c) a[c] = bias ? bias[j + c] : 0.0f;
+            for (int k = 0; k < in_dim; ++k) {
+                const float xv = xr[k];
+                for (int c = 0; c < 8; ++c) a[c] = fmaf(xv, w[(long)c * in_dim + k], a[c]);
+            }
+            for (int c = 0; c < 8; ++c) {
+                float v = a[c];
+                if (relu && !(v > 0.0f)) v = 0.0f;
+                y[r * out_dim + j + c] = v;
+            }
+        }
+        for (; j < out_dim; ++j) {
             const float* w = W + (long)j * in_dim;
             float acc = bias ? bias[j] : 0.0f;
             for (int k = 0; k < in_dim; ++k) acc = fmaf(xr[k], w[k], acc);
