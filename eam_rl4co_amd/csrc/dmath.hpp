@@ -83,30 +83,73 @@ __device__ __forceinline__ float d_tanhf(float x)
     return __builtin_copysignf(t, x);
 }
 
+// ---- cross-lane exchange steps of a 64-lane butterfly, without LDS traffic -------------------------------
+// Levels 1,2: quad_perm DPP; 4,8: row_half_mirror / row_mirror DPP (the partner lane differs from i^4 / i^8
+// but holds the same value, because after the previous level a value is uniform inside its 4- / 8-lane
+// group); 16, 32: gfx950 v_permlane16_swap / v_permlane32_swap of a register with itself, which leaves the two
+// operands of the level in the two result registers of EVERY lane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
 // Sum over the 64 lanes of a wavefront as an adjacent-pair tree (xor butterfly); every lane gets the
-// total.  This is the "lane tree" of the canonical order: level w adds lanes i and i^w.
+// total.  This is the "lane tree" of the canonical order: level w adds the partial sums of lane groups
+// [i, i+w) and [i+w, i+2w).
 __device__ __forceinline__ float wave_tree_sum(float v)
 {
-#pragma unroll
-    for (int m = 1; m < EAMRL_WAVE; m <<= 1) v = v + __shfl_xor(v, m, EAMRL_WAVE);
-    return v;
+    v = v + dpp_f<DPP_XOR1>(v);
+    v = v + dpp_f<DPP_XOR2>(v);
+    v = v + dpp_f<DPP_HALF_MIRROR>(v);
+    v = v + dpp_f<DPP_MIRROR>(v);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int m = 1; m < EAMRL_WAVE; m <<= 1) v = __builtin_fmaxf(v, __shfl_xor(v, m, EAMRL_WAVE));
-    return v;
+    v = __builtin_fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = __builtin_fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = __builtin_fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    v = __builtin_fmaxf(v, dpp_f<DPP_MIRROR>(v));
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __builtin_fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
 }
 
 // argmax with torch.argmax's tie rule (lowest index); every lane gets the winner.
+__device__ __forceinline__ void argmax_pick(float& v, int& i, float ov, int oi)
+{
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
 __device__ __forceinline__ void wave_argmax(float& v, int& i)
 {
-#pragma unroll
-    for (int m = 1; m < EAMRL_WAVE; m <<= 1) {
-        float ov = __shfl_xor(v, m, EAMRL_WAVE);
-        int oi = __shfl_xor(i, m, EAMRL_WAVE);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    argmax_pick(v, i, dpp_f<DPP_XOR1>(v), dpp_i<DPP_XOR1>(i));
+    argmax_pick(v, i, dpp_f<DPP_XOR2>(v), dpp_i<DPP_XOR2>(i));
+    // from here on a (value, index) pair is uniform inside its 4-, then 8-lane group
+    argmax_pick(v, i, dpp_f<DPP_HALF_MIRROR>(v), dpp_i<DPP_HALF_MIRROR>(i));
+    argmax_pick(v, i, dpp_f<DPP_MIRROR>(v), dpp_i<DPP_MIRROR>(i));
+    {
+        auto rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        auto ri = __builtin_amdgcn_permlane16_swap((unsigned)i, (unsigned)i, false, false);
+        v = __uint_as_float(rv[0]); i = (int)ri[0];
+        argmax_pick(v, i, __uint_as_float(rv[1]), (int)ri[1]);
+    }
+    {
+        auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        auto ri = __builtin_amdgcn_permlane32_swap((unsigned)i, (unsigned)i, false, false);
+        v = __uint_as_float(rv[0]); i = (int)ri[0];
+        argmax_pick(v, i, __uint_as_float(rv[1]), (int)ri[1]);
     }
 }
 
