@@ -37,6 +37,7 @@ PROTOTYPES = {
     "eamrl_cvrp_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "eamrl_cvrp_step_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "eamrl_linear": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+    "eamrl_linear_bn": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp],
     "eamrl_matmul_right": [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "eamrl_mha_encoder": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "eamrl_normalize": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp],

@@ -26,40 +26,83 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------------------------------
 constexpr int GT = 128;       // block tile (rows and cols)
 constexpr int GK = 32;        // k tile
-constexpr int GKP = GK + 1;   // LDS row stride (odd: conflict-free ds_read_b32 down a column)
+constexpr int GS = GK + 4;    // LDS row stride in floats: 144 B = 9 x 16 B -> conflict-free ds_read_b128 / ds_write_b128
 
+// Per-column epilogue constants of a fused BatchNorm1d(eval): y = fma(v, scale, shift)
+__device__ __forceinline__ void bn_consts(const GemmArgs& g, int j, float& scale, float& shift)
+{
+    scale = g.bn_gamma[j] / __builtin_sqrtf(g.bn_var[j] + g.bn_eps);
+    const float ms = g.bn_mean[j] * scale;
+    shift = g.bn_beta[j] - ms;
+}
 
-__device__ __forceinline__ void gemm_load_tiles(const GemmArgs& g, float* As, float* Bs, int64_t row0, int col0, int k0)
+// One 128 x 32 operand tile: 1024 float4, 4 per thread; lanes 0-7 cover one 128-B row segment.
+// The fetch is branch-free: out-of-range rows / columns are clamped to the last valid one (their products land
+// in accumulator rows / columns that are never stored) and k beyond in_dim is zeroed (in_dim % 4 == 0 here).
+// WT tiles (W stored [k][j]) are read as float4 along j and transposed on the way into LDS.
+struct TileRegs { float4 v[4]; };
+
+template <bool WT>
+__device__ __forceinline__ void gemm_fetch(const float* __restrict__ base, int64_t ldm, int64_t row0, int64_t nrows,
+                                           int k0, int kdim, TileRegs& t)
 {
     const int tid = threadIdx.x;
-    // x tile: 128 rows x 32 k, lane-contiguous along k
-    for (int i = tid; i < GT * GK; i += 256) {
-        const int rr = i / GK, kk = i - rr * GK;
-        const int64_t r = row0 + rr;
-        const int k = k0 + kk;
-        As[rr * GKP + kk] = (r < g.rows && k < g.in_dim) ? g.x[r * g.ldx + k] : 0.0f;
-    }
-    if (!g.wt) {
-        for (int i = tid; i < GT * GK; i += 256) {
-            const int jj = i / GK, kk = i - jj * GK;
-            const int j = col0 + jj, k = k0 + kk;
-            Bs[jj * GKP + kk] = (j < g.out_dim && k < g.in_dim) ? g.W[(int64_t)j * g.ldw + k] : 0.0f;
-        }
-    } else {
-        for (int i = tid; i < GT * GK; i += 256) {
-            const int kk = i / GT, jj = i - kk * GT;
-            const int j = col0 + jj, k = k0 + kk;
-            Bs[jj * GKP + kk] = (j < g.out_dim && k < g.in_dim) ? g.W[(int64_t)k * g.ldw + j] : 0.0f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int f = tid + 256 * p;
+        if (!WT) {
+            const int rr = f >> 3, c4 = f & 7;
+            int64_t r = row0 + rr;
+            r = r < nrows ? r : nrows - 1;
+            const int k = k0 + 4 * c4;
+            const int kc = k < kdim ? k : kdim - 4;
+            float4 v = *reinterpret_cast<const float4*>(base + r * ldm + kc);
+            const float keep = k < kdim ? 1.0f : 0.0f;   // multiply keeps this a v_mul, not control flow
+            t.v[p] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+        } else {
+            const int kk = f >> 5, j4 = f & 31;     // 32 float4 = 128 columns per k row
+            const int k = k0 + kk;
+            const int kc = k < kdim ? k : kdim - 1;
+            int64_t j = row0 + 4 * j4;
+            j = j + 3 < nrows ? j : nrows - 4;      // nrows % 4 == 0 on this path
+            float4 v = *reinterpret_cast<const float4*>(base + (int64_t)kc * ldm + j);
+            const float keep = k < kdim ? 1.0f : 0.0f;
+            t.v[p] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_linear_mfma(GemmArgs g)
+// LDS image: row-major [128][GS]; inside every group of 4 consecutive k the order is (k, k+2, k+1, k+3), so
+// that the MFMA operand of lane half lk -- elements k+lk and k+2+lk -- is one aligned 8-byte read.
+template <bool WT>
+__device__ __forceinline__ void gemm_stash(float* S, const TileRegs& t)
 {
-    __shared__ float As[GT * GKP];
-    __shared__ float Bs[GT * GKP];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int f = tid + 256 * p;
+        if (!WT) {
+            const int rr = f >> 3, c4 = f & 7;
+            *reinterpret_cast<float4*>(S + rr * GS + 4 * c4) = make_float4(t.v[p].x, t.v[p].z, t.v[p].y, t.v[p].w);
+        } else {
+            const int kk = f >> 5, j4 = f & 31;
+            const int pos = (kk & ~3) | ((kk & 1) << 1) | ((kk >> 1) & 1);
+            S[(4 * j4 + 0) * GS + pos] = t.v[p].x;
+            S[(4 * j4 + 1) * GS + pos] = t.v[p].y;
+            S[(4 * j4 + 2) * GS + pos] = t.v[p].z;
+            S[(4 * j4 + 3) * GS + pos] = t.v[p].w;
+        }
+    }
+}
+
+// ALIGNED: x / W rows start 16-B aligned (ld % 4 == 0, base % 16 == 0) so tiles are fetched as float4.
+template <bool WT>
+__global__ __launch_bounds__(256, 2) void k_linear_mfma(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) float As[GT * GS];
+    __shared__ __attribute__((aligned(16))) float Bs[GT * GS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv >> 1, wc = wv & 1;           // wave position in the 2x2 grid
+    const int wr = wv >> 1, wc = wv & 1;           // wave position in the 2x2 grid of 64x64 sub-tiles
     const int64_t row0 = (int64_t)blockIdx.x * GT;
     const int col0 = blockIdx.y * GT;
     const int li = lane & 31, lk = lane >> 5;
@@ -75,22 +118,44 @@ __global__ __launch_bounds__(256) void k_linear_mfma(GemmArgs g)
             for (int i = 0; i < 16; ++i) acc[a][b][i] = bj;
         }
 
+    TileRegs ta, tb;
+    gemm_fetch<false>(g.x, g.ldx, row0, g.rows, 0, g.in_dim, ta);
+    gemm_fetch<WT>(g.W, g.ldw, col0, g.out_dim, 0, g.in_dim, tb);
+    gemm_stash<false>(As, ta);
+    gemm_stash<WT>(Bs, tb);
+    __syncthreads();
     for (int k0 = 0; k0 < g.in_dim; k0 += GK) {
-        __syncthreads();
-        gemm_load_tiles(g, As, Bs, row0, col0, k0);
-        __syncthreads();
-        const int kmax = min(GK, g.in_dim - k0);   // multiple of 2 required (checked by the host)
-        for (int kk = 0; kk < kmax; kk += 2) {
-            float af[2], bf[2];
+        const bool more = k0 + GK < g.in_dim;
+        if (more) {   // next tile's global loads fly while this tile is multiplied
+            gemm_fetch<false>(g.x, g.ldx, row0, g.rows, k0 + GK, g.in_dim, ta);
+            gemm_fetch<WT>(g.W, g.ldw, col0, g.out_dim, k0 + GK, g.in_dim, tb);
+        }
+        const int kmax = min(GK, g.in_dim - k0);
+        for (int kq = 0; kq < kmax; kq += 4) {     // 4 k values = 2 MFMA k-steps (zero padded beyond in_dim)
+            // lanes 0-31 carry k, lanes 32-63 carry k+1 (ascending k inside the instruction); .x = first k-step
+            float2 a2[2], b2[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = As[(wr * 64 + a * 32 + li) * GKP + kk + lk];
+            for (int a = 0; a < 2; ++a)
+                a2[a] = *reinterpret_cast<const float2*>(As + (wr * 64 + a * 32 + li) * GS + kq + 2 * lk);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bf[b] = Bs[(wc * 64 + b * 32 + li) * GKP + kk + lk];
+            for (int b = 0; b < 2; ++b)
+                b2[b] = *reinterpret_cast<const float2*>(Bs + (wc * 64 + b * 32 + li) * GS + kq + 2 * lk);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[a].x, b2[b].x, acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[a].y, b2[b].y, acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            gemm_stash<false>(As, ta);
+            gemm_stash<WT>(Bs, tb);
+            __syncthreads();
         }
     }
     // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -100,6 +165,8 @@ __global__ __launch_bounds__(256) void k_linear_mfma(GemmArgs g)
         for (int b = 0; b < 2; ++b) {
             const int j = col0 + wc * 64 + b * 32 + li;
             if (j >= g.out_dim) continue;
+            float scale = 1.0f, shift = 0.0f;
+            if (g.bn_gamma) bn_consts(g, j, scale, shift);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int64_t r = row0 + wr * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;
@@ -107,6 +174,7 @@ __global__ __launch_bounds__(256) void k_linear_mfma(GemmArgs g)
                 float v = acc[a][b][i];
                 if (g.relu && !(v > 0.0f)) v = 0.0f;
                 if (g.res) v = g.res[r * g.ldres + j] + v;
+                if (g.bn_gamma) v = fma_(v, scale, shift);
                 g.y[r * g.ldy + j] = v;
             }
         }
@@ -164,6 +232,7 @@ __global__ __launch_bounds__(256) void k_linear_valu(GemmArgs g)
             float v = acc[i][j];
             if (g.relu && !(v > 0.0f)) v = 0.0f;
             if (g.res) v = g.res[r * g.ldres + c] + v;
+            if (g.bn_gamma) { float sc, sh; bn_consts(g, c, sc, sh); v = fma_(v, sc, sh); }
             g.y[r * g.ldy + c] = v;
         }
 }
@@ -182,6 +251,7 @@ __global__ void k_small_linear(GemmArgs g)
     }
     if (g.relu && !(acc > 0.0f)) acc = 0.0f;
     if (g.res) acc = g.res[r * g.ldres + j] + acc;
+    if (g.bn_gamma) { float sc, sh; bn_consts(g, j, sc, sh); acc = fma_(acc, sc, sh); }
     g.y[r * g.ldy + j] = acc;
 }
 
@@ -192,12 +262,14 @@ int launch_linear(const GemmArgs& g, hipStream_t st)
     if (g.in_dim <= 4) {
         const int64_t n = g.rows * g.out_dim;
         hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
-    } else if (force_valu || (g.in_dim & 1)) {
+    } else if (force_valu || (g.in_dim & 3) || (g.ldx & 3) || ((uintptr_t)g.x & 15) || (g.ldw & 3) ||
+               ((uintptr_t)g.W & 15) || (g.wt && (g.out_dim & 3))) {
         dim3 grid((unsigned)((g.rows + 63) / 64), (unsigned)((g.out_dim + 63) / 64));
         hipLaunchKernelGGL(k_linear_valu, grid, dim3(256), 0, st, g);
     } else {
         dim3 grid((unsigned)((g.rows + GT - 1) / GT), (unsigned)((g.out_dim + GT - 1) / GT));
-        hipLaunchKernelGGL(k_linear_mfma, grid, dim3(256), 0, st, g);
+        if (g.wt) hipLaunchKernelGGL(k_linear_mfma<true>, grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(k_linear_mfma<false>, grid, dim3(256), 0, st, g);
     }
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }

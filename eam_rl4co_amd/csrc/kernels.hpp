@@ -10,6 +10,8 @@ struct GemmArgs {
     const float* bias; const float* res; int64_t ldres;
     float* y; int64_t ldy;
     int64_t rows; int in_dim, out_dim, relu;
+    // optional fused BatchNorm1d(eval) on the output columns (applied after residual): all null or all set
+    const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_var; float bn_eps;
 };
 
 extern int g_debug[8];   // eamrl_debug_set knobs

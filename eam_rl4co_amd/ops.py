@@ -51,8 +51,9 @@ def _bytes(t):
 # ------------------------------------------------------------------------------------------------------
 # encoder / cache
 # ------------------------------------------------------------------------------------------------------
-def linear(x, W, bias=None, relu=False, residual=None, out=None, w_cols=None):
-    """y = [residual +] act(x @ W[:, :w_cols].T + bias).  x [..., in] (last dim contiguous, rows strided ok)."""
+def linear(x, W, bias=None, relu=False, residual=None, out=None, w_cols=None, bn=None):
+    """y = [residual +] act(x @ W[:, w_cols].T + bias), optionally followed by BatchNorm1d(eval) in the same launch
+    (bn = (gamma, beta, running_mean, running_var, eps)).  x [..., in] (last dim contiguous, rows strided ok)."""
     lib = _lib.load()
     _need_gpu(x, "x")
     in_dim = x.shape[-1] if w_cols is None else w_cols[1] - w_cols[0]
@@ -78,6 +79,17 @@ def linear(x, W, bias=None, relu=False, residual=None, out=None, w_cols=None):
             raise ValueError("linear: bad residual")
     if bias is not None:
         _chk(bias, "bias", torch.float32, (out_dim,))
+    if bn is not None:
+        if relu:
+            raise ValueError("linear: relu and fused batch-norm are not combined")
+        gamma, beta, mean, var, eps = bn
+        for nm, t in (("gamma", gamma), ("beta", beta), ("running_mean", mean), ("running_var", var)):
+            _chk(t, nm, torch.float32, (out_dim,))
+        _lib.check(lib.eamrl_linear_bn(_ptr(x2), x2.stride(0), _ptr(Wv), Wv.stride(0), _ptr(bias), _ptr(res2),
+                                       res2.stride(0) if res2 is not None else 0, _ptr(o2), o2.stride(0), rows, in_dim,
+                                       out_dim, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), float(eps), _stream(x)),
+                   "eamrl_linear_bn")
+        return out
     _lib.check(lib.eamrl_linear(_ptr(x2), x2.stride(0), _ptr(Wv), Wv.stride(0), _ptr(bias), _ptr(res2),
                                 res2.stride(0) if res2 is not None else 0, _ptr(o2), o2.stride(0), rows, in_dim,
                                 out_dim, int(relu), _stream(x)), "eamrl_linear")

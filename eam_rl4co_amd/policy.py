@@ -88,14 +88,22 @@ class Normalization(nn.Module):
             raise NotImplementedError(f"normalization={normalization!r}: only 'batch' (eval) and 'instance' are "
                                       "built for MI355X")
 
+    def fused_bn(self):
+        """(gamma, beta, mean, var, eps) when this is an eval-mode BatchNorm that the producing GEMM can apply."""
+        n = self.normalizer
+        if not isinstance(n, nn.BatchNorm1d):
+            return None
+        if self.training:
+            raise NotImplementedError(
+                "BatchNorm batch statistics (policy.train()) are not part of the MI355X rollout path; "
+                "call policy.eval() (RolloutBaseline / evaluation do, reinforce/baselines.py:232)")
+        return (n.weight, n.bias, n.running_mean, n.running_var, n.eps)
+
     def apply_(self, x):
         n = self.normalizer
         if isinstance(n, nn.BatchNorm1d):
-            if self.training:
-                raise NotImplementedError(
-                    "BatchNorm batch statistics (policy.train()) are not part of the MI355X rollout path; "
-                    "call policy.eval() (RolloutBaseline / evaluation do, reinforce/baselines.py:232)")
-            return ops.normalize_(x, ops.NORM_BATCH_EVAL, n.weight, n.bias, n.running_mean, n.running_var, n.eps)
+            g, b, m, v, eps = self.fused_bn()
+            return ops.normalize_(x, ops.NORM_BATCH_EVAL, g, b, m, v, eps)
         return ops.normalize_(x, ops.NORM_INSTANCE, n.weight, n.bias, eps=n.eps)
 
 
@@ -114,13 +122,15 @@ class MultiHeadAttentionLayer(nn.Sequential):
         mha, ffn = self[0].module, self[2].module
         qkv = ops.linear(h, mha.Wqkv.weight, mha.Wqkv.bias)
         att = ops.mha_encoder(qkv, mha.num_heads)
-        h = ops.linear(att, mha.out_proj.weight, mha.out_proj.bias, residual=h)     # h + MHA(h)
-        h = self[1].apply_(h)
+        bn1, bn2 = self[1].fused_bn(), self[3].fused_bn()
+        h = ops.linear(att, mha.out_proj.weight, mha.out_proj.bias, residual=h, bn=bn1)    # norm(h + MHA(h))
+        if bn1 is None:
+            h = self[1].apply_(h)
         x = h
         for lin in ffn.lins[:-1]:
             x = ops.linear(x, lin.weight, lin.bias, relu=True)
-        h = ops.linear(x, ffn.lins[-1].weight, ffn.lins[-1].bias, residual=h)        # h + FFN(h)
-        return self[3].apply_(h)
+        h = ops.linear(x, ffn.lins[-1].weight, ffn.lins[-1].bias, residual=h, bn=bn2)       # norm(h + FFN(h))
+        return h if bn2 is not None else self[3].apply_(h)
 
 
 class GraphAttentionNetwork(nn.Module):
@@ -213,9 +223,10 @@ class AttentionModelDecoder(nn.Module):
         flat = buf.view(B * M, -1)
         Wctx = self.context_embedding.project_context.weight
         ops.linear(emb, self.project_node_embeddings.weight, out=flat[:, 0:3 * E])
-        ops.linear(emb, Wctx, w_cols=(0, E), out=flat[:, slots["Pa"] * E:(slots["Pa"] + 1) * E])
+        # (weight slices are made contiguous so that the GEMM fetches them as aligned float4 rows)
+        ops.linear(emb, Wctx[:, 0:E].contiguous(), out=flat[:, slots["Pa"] * E:(slots["Pa"] + 1) * E])
         if self.env_name == "tsp":
-            ops.linear(emb, Wctx, w_cols=(E, 2 * E), out=flat[:, slots["Pb"] * E:(slots["Pb"] + 1) * E])
+            ops.linear(emb, Wctx[:, E:2 * E].contiguous(), out=flat[:, slots["Pb"] * E:(slots["Pb"] + 1) * E])
             cvec = ops.linear(self.context_embedding.W_placeholder[None, :], Wctx)[0]
         else:
             cvec = Wctx[:, E].contiguous()

@@ -83,6 +83,13 @@ int eamrl_cvrp_step_mask(uint8_t* visited, float* used, const float* vcap, const
 int eamrl_linear(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* res,
                  int64_t ldres, float* y, int64_t ldy, int64_t rows, int in_dim, int out_dim, int relu, void* stream);
 
+/* eamrl_linear followed by Normalization(batch, eval) on the result, in one launch:
+ * y = BN_eval(res + (bias + x W^T))   [SkipConnection + Normalization, nn/graph/attnnet.py:47-57, nn/ops.py:45-47].
+ * Same arithmetic as eamrl_linear then eamrl_normalize(EAMRL_NORM_BATCH_EVAL). */
+int eamrl_linear_bn(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* res,
+                    int64_t ldres, float* y, int64_t ldy, int64_t rows, int in_dim, int out_dim,
+                    const float* gamma, const float* beta, const float* mean, const float* var, float eps, void* stream);
+
 /* y[r][j] = sum_k x[r][k] * Wt[k][j]  (right-multiplication; folds PointerAttention.project_out into the
  * logit key: Lp = L * Wout)  [nn/attention.py:296-301]. */
 int eamrl_matmul_right(const float* x, int64_t ldx, const float* Wt, float* y, int64_t ldy, int64_t rows,

@@ -101,6 +101,11 @@ def test_linear_is_a_k_ordered_fma_chain(oracle, rows, k, n, valu):
         assert_bits_equal(y, res + oracle.linear(x, W, None, relu=True), "linear relu+res")
         if k == n:
             assert_bits_equal(ops.matmul_right(t(x), t(W)), oracle.matmul_right(x, W), "matmul_right")
+        g, bt = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+        mu, var = rng.standard_normal(n).astype(np.float32), (rng.random(n) + 0.5).astype(np.float32)
+        y = ops.linear(t(x), t(W), t(b), residual=t(res), bn=(t(g), t(bt), t(mu), t(var), 1e-5))
+        ref = oracle.batchnorm_eval((res + oracle.linear(x, W, b))[None], g, bt, mu, var)[0]
+        assert_bits_equal(y, ref, "linear + fused batch-norm")
     finally:
         lib.eamrl_debug_set(0, 0)
 
