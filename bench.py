@@ -67,7 +67,7 @@ def cpu_baseline(env_name, num_loc, decode_type, seconds_budget=20.0):
     from oracle import oracle as orc
     import eam_rl4co_amd as ea
 
-    threads = os.cpu_count() or 1
+    threads = orc.set_threads(min(orc.usable_cpus(), 64))   # the box's CPU share, not its core count
     sd = golden_weights("am_" + env_name)
     env = ea.get_env(env_name, generator_params=dict(num_loc=num_loc), seed=1234)
 

@@ -37,70 +37,80 @@ __device__ __forceinline__ void bn_consts(const GemmArgs& g, int j, float& scale
 }
 
 // One 128 x 32 operand tile: 1024 float4, 4 per thread; lanes 0-7 cover one 128-B row segment.
-// The fetch is branch-free: out-of-range rows / columns are clamped to the last valid one (their products land
-// in accumulator rows / columns that are never stored) and k beyond in_dim is zeroed (in_dim % 4 == 0 here).
+// Addresses are a block-uniform base (SGPRs) plus four fixed 32-bit per-thread element offsets, computed once.
+// Out-of-range rows / columns are clamped to the last valid one (their products land in accumulator rows /
+// columns that are never stored); in_dim is a multiple of the k-tile on this path (other shapes take the VALU kernel).
 // WT tiles (W stored [k][j]) are read as float4 along j and transposed on the way into LDS.
-struct TileRegs { float4 v[4]; };
+struct TileOffs { int o[4]; };
 
 template <bool WT>
-__device__ __forceinline__ void gemm_fetch(const float* __restrict__ base, int64_t ldm, int64_t row0, int64_t nrows,
-                                           int k0, int kdim, TileRegs& t)
+__device__ __forceinline__ TileOffs gemm_offsets(int64_t ldm, int nvalid)
 {
+    // nvalid: rows (or columns) of this block's tile that exist, 1..128
+    TileOffs t;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int f = tid + 256 * p;
         if (!WT) {
-            const int rr = f >> 3, c4 = f & 7;
-            int64_t r = row0 + rr;
-            r = r < nrows ? r : nrows - 1;
-            const int k = k0 + 4 * c4;
-            const int kc = k < kdim ? k : kdim - 4;
-            float4 v = *reinterpret_cast<const float4*>(base + r * ldm + kc);
-            const float keep = k < kdim ? 1.0f : 0.0f;   // multiply keeps this a v_mul, not control flow
-            t.v[p] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+            int rr = f >> 3;
+            rr = rr < nvalid ? rr : nvalid - 1;
+            t.o[p] = rr * (int)ldm + 4 * (f & 7);
         } else {
-            const int kk = f >> 5, j4 = f & 31;     // 32 float4 = 128 columns per k row
-            const int k = k0 + kk;
-            const int kc = k < kdim ? k : kdim - 1;
-            int64_t j = row0 + 4 * j4;
-            j = j + 3 < nrows ? j : nrows - 4;      // nrows % 4 == 0 on this path
-            float4 v = *reinterpret_cast<const float4*>(base + (int64_t)kc * ldm + j);
-            const float keep = k < kdim ? 1.0f : 0.0f;
-            t.v[p] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+            int jj = 4 * (f & 31);
+            jj = jj + 3 < nvalid ? jj : nvalid - 4;          // out_dim % 4 == 0 on this path
+            t.o[p] = (f >> 5) * (int)ldm + jj;
         }
     }
+    return t;
 }
 
-// LDS image: row-major [128][GS]; inside every group of 4 consecutive k the order is (k, k+2, k+1, k+3), so
-// that the MFMA operand of lane half lk -- elements k+lk and k+2+lk -- is one aligned 8-byte read.
+#define GEMM_FETCH(WT_, base_, ldm_, off_, k0_, r0_, r1_, r2_, r3_)                                   \
+    do {                                                                                              \
+        const float* kb_ = (WT_) ? (base_) + (int64_t)(k0_) * (ldm_) : (base_) + (k0_);              \
+        r0_ = *reinterpret_cast<const float4*>(kb_ + (off_).o[0]);                                    \
+        r1_ = *reinterpret_cast<const float4*>(kb_ + (off_).o[1]);                                    \
+        r2_ = *reinterpret_cast<const float4*>(kb_ + (off_).o[2]);                                    \
+        r3_ = *reinterpret_cast<const float4*>(kb_ + (off_).o[3]);                                    \
+    } while (0)
+
+// LDS image: plain row-major [128][GS] (float4 stores of the fetched registers as they are -- any register
+// shuffle here makes hipcc wait for the global loads before the MFMA loop instead of after it).
 template <bool WT>
-__device__ __forceinline__ void gemm_stash(float* S, const TileRegs& t)
+__device__ __forceinline__ void gemm_stash1(float* S, int p, const float4 v)
 {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int f = tid + 256 * p;
-        if (!WT) {
-            const int rr = f >> 3, c4 = f & 7;
-            *reinterpret_cast<float4*>(S + rr * GS + 4 * c4) = make_float4(t.v[p].x, t.v[p].z, t.v[p].y, t.v[p].w);
-        } else {
-            const int kk = f >> 5, j4 = f & 31;
-            const int pos = (kk & ~3) | ((kk & 1) << 1) | ((kk >> 1) & 1);
-            S[(4 * j4 + 0) * GS + pos] = t.v[p].x;
-            S[(4 * j4 + 1) * GS + pos] = t.v[p].y;
-            S[(4 * j4 + 2) * GS + pos] = t.v[p].z;
-            S[(4 * j4 + 3) * GS + pos] = t.v[p].w;
-        }
+    const int f = threadIdx.x + 256 * p;
+    if (!WT) {
+        *reinterpret_cast<float4*>(S + (f >> 3) * GS + 4 * (f & 7)) = v;
+    } else {
+        const int kk = f >> 5, j4 = f & 31;
+        S[(4 * j4 + 0) * GS + kk] = v.x;
+        S[(4 * j4 + 1) * GS + kk] = v.y;
+        S[(4 * j4 + 2) * GS + kk] = v.z;
+        S[(4 * j4 + 3) * GS + kk] = v.w;
     }
+}
+#define GEMM_STASH(WT_, S_, r0_, r1_, r2_, r3_)  \
+    do { gemm_stash1<WT_>(S_, 0, r0_); gemm_stash1<WT_>(S_, 1, r1_); gemm_stash1<WT_>(S_, 2, r2_); gemm_stash1<WT_>(S_, 3, r3_); } while (0)
+
+// MFMA operands of 4 consecutive k for one 32-row strip: lane half lk reads the aligned pair (k+2lk, k+2lk+1);
+// one v_permlane32_swap turns ([k | k+2], [k+1 | k+3]) into ([k | k+1], [k+2 | k+3]) = the operands of the two
+// k-steps (lanes 0-31 carry the lower k of a step, lanes 32-63 the higher one).
+__device__ __forceinline__ void mfma_operands(const float* row_ptr, float& first, float& second)
+{
+    const float2 v = *reinterpret_cast<const float2*>(row_ptr);
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v.x), __float_as_uint(v.y), false, false);
+    first = __uint_as_float(r[0]);
+    second = __uint_as_float(r[1]);
 }
 
 // ALIGNED: x / W rows start 16-B aligned (ld % 4 == 0, base % 16 == 0) so tiles are fetched as float4.
 template <bool WT>
-__global__ __launch_bounds__(256, 2) void k_linear_mfma(GemmArgs g)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_mfma(GemmArgs g)
 {
-    __shared__ __attribute__((aligned(16))) float As[GT * GS];
-    __shared__ __attribute__((aligned(16))) float Bs[GT * GS];
+    __shared__ __attribute__((aligned(16))) float smem_ab[2 * GT * GS];   // one object: A tile | B tile, reused by the epilogue
+    float* As = smem_ab;
+    float* Bs = smem_ab + GT * GS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 1, wc = wv & 1;           // wave position in the 2x2 grid of 64x64 sub-tiles
     const int64_t row0 = (int64_t)blockIdx.x * GT;
@@ -118,66 +128,129 @@ __global__ __launch_bounds__(256, 2) void k_linear_mfma(GemmArgs g)
             for (int i = 0; i < 16; ++i) acc[a][b][i] = bj;
         }
 
-    TileRegs ta, tb;
-    gemm_fetch<false>(g.x, g.ldx, row0, g.rows, 0, g.in_dim, ta);
-    gemm_fetch<WT>(g.W, g.ldw, col0, g.out_dim, 0, g.in_dim, tb);
-    gemm_stash<false>(As, ta);
-    gemm_stash<WT>(Bs, tb);
+    float4 ta0, ta1, ta2, ta3, tb0, tb1, tb2, tb3;    // register-staged next operand tiles
+    const int64_t rows_left = g.rows - row0;
+    const TileOffs oa = gemm_offsets<false>(g.ldx, rows_left < GT ? (int)rows_left : GT);
+    const TileOffs ob = gemm_offsets<WT>(g.ldw, g.out_dim - col0 < GT ? g.out_dim - col0 : GT);
+    const float* xbase = g.x + row0 * g.ldx;                                        // block-uniform bases
+    const float* wbase = WT ? g.W + col0 : g.W + (int64_t)col0 * g.ldw;
+    GEMM_FETCH(false, xbase, g.ldx, oa, 0, ta0, ta1, ta2, ta3);
+    GEMM_FETCH(WT, wbase, g.ldw, ob, 0, tb0, tb1, tb2, tb3);
+    GEMM_STASH(false, As, ta0, ta1, ta2, ta3);
+    GEMM_STASH(WT, Bs, tb0, tb1, tb2, tb3);
     __syncthreads();
     for (int k0 = 0; k0 < g.in_dim; k0 += GK) {
         const bool more = k0 + GK < g.in_dim;
         if (more) {   // next tile's global loads fly while this tile is multiplied
-            gemm_fetch<false>(g.x, g.ldx, row0, g.rows, k0 + GK, g.in_dim, ta);
-            gemm_fetch<WT>(g.W, g.ldw, col0, g.out_dim, k0 + GK, g.in_dim, tb);
+            GEMM_FETCH(false, xbase, g.ldx, oa, k0 + GK, ta0, ta1, ta2, ta3);
+            GEMM_FETCH(WT, wbase, g.ldw, ob, k0 + GK, tb0, tb1, tb2, tb3);
         }
-        const int kmax = min(GK, g.in_dim - k0);
-        for (int kq = 0; kq < kmax; kq += 4) {     // 4 k values = 2 MFMA k-steps (zero padded beyond in_dim)
-            // lanes 0-31 carry k, lanes 32-63 carry k+1 (ascending k inside the instruction); .x = first k-step
-            float2 a2[2], b2[2];
+#pragma unroll 1
+        for (int kq = 0; kq < GK; kq += 4) {       // 4 k values = 2 MFMA k-steps
+            float a0[2], a1[2], b0[2], b1[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-                a2[a] = *reinterpret_cast<const float2*>(As + (wr * 64 + a * 32 + li) * GS + kq + 2 * lk);
+            for (int a = 0; a < 2; ++a) mfma_operands(As + (wr * 64 + a * 32 + li) * GS + kq + 2 * lk, a0[a], a1[a]);
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-                b2[b] = *reinterpret_cast<const float2*>(Bs + (wc * 64 + b * 32 + li) * GS + kq + 2 * lk);
+            for (int b = 0; b < 2; ++b) mfma_operands(Bs + (wc * 64 + b * 32 + li) * GS + kq + 2 * lk, b0[b], b1[b]);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[a].x, b2[b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[a], b0[b], acc[a][b], 0, 0, 0);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[a].y, b2[b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[a], b1[b], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
         if (more) {
-            gemm_stash<false>(As, ta);
-            gemm_stash<WT>(Bs, tb);
+            GEMM_STASH(false, As, ta0, ta1, ta2, ta3);
+            GEMM_STASH(WT, Bs, tb0, tb1, tb2, tb3);
             __syncthreads();
         }
     }
-    // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // Epilogue through LDS: each wave parks a 32 x 64 slab of its accumulators (C/D layout: col = lane&31,
+    // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) and reads it back row-major, so residual loads and output
+    // stores are float4 per lane and 256 contiguous bytes per 16 lanes.
+    constexpr int CS = 68;                                  // slab row stride (floats): 272 B keeps float4 alignment
+    float* slab = smem_ab + wv * (32 * CS);                 // 4 waves x 8.5 KB inside the operand tile storage
+    static_assert(4 * 32 * CS <= 2 * GT * GS, "epilogue slabs must fit the operand tile storage");
+    const int er = lane >> 4, ec = (lane & 15) * 4;         // this lane's (row within 4, first column) when reading
+    const int jbase = col0 + wc * 64 + ec;
+    float sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bn_gamma) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int q = 0; q < 4; ++q)
+            if (jbase + q < g.out_dim) bn_consts(g, jbase + q, sc4[q], sh4[q]);
+    }
+    const bool vec_ok = ((g.ldy & 3) == 0) && (((uintptr_t)g.y & 15) == 0) && (jbase + 3 < g.out_dim) &&
+                        (!g.res || (((g.ldres & 3) == 0) && (((uintptr_t)g.res & 15) == 0)));
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int j = col0 + wc * 64 + b * 32 + li;
-            if (j >= g.out_dim) continue;
-            float scale = 1.0f, shift = 0.0f;
-            if (g.bn_gamma) bn_consts(g, j, scale, shift);
+    for (int a = 0; a < 2; ++a) {
+        __syncthreads();                                    // slab (and, first time, the operand tiles) are free
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int64_t r = row0 + wr * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;
-                if (r >= g.rows) continue;
-                float v = acc[a][b][i];
-                if (g.relu && !(v > 0.0f)) v = 0.0f;
-                if (g.res) v = g.res[r * g.ldres + j] + v;
-                if (g.bn_gamma) v = fma_(v, scale, shift);
-                g.y[r * g.ldy + j] = v;
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                slab[((i & 3) + 8 * (i >> 2) + 4 * lk) * CS + b * 32 + li] = acc[a][b][i];
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int rr = er + 4 * p;
+            const int64_t r = row0 + wr * 64 + a * 32 + rr;
+            if (r >= g.rows) continue;
+            float4 v4 = *reinterpret_cast<const float4*>(slab + rr * CS + ec);
+            float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            if (vec_ok) {
+                float rs[4] = {0.f, 0.f, 0.f, 0.f};
+                if (g.res) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(g.res + r * g.ldres + jbase);
+                    rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (g.relu && !(v[q] > 0.0f)) v[q] = 0.0f;
+                    if (g.res) v[q] = rs[q] + v[q];
+                    if (g.bn_gamma) v[q] = fma_(v[q], sc4[q], sh4[q]);
+                }
+                *reinterpret_cast<float4*>(g.y + r * g.ldy + jbase) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = jbase + q;
+                    if (j >= g.out_dim) continue;
+                    float x = v[q];
+                    if (g.relu && !(x > 0.0f)) x = 0.0f;
+                    if (g.res) x = g.res[r * g.ldres + j] + x;
+                    if (g.bn_gamma) x = fma_(x, sc4[q], sh4[q]);
+                    g.y[r * g.ldy + j] = x;
+                }
             }
         }
+    }
+}
+
+// Thin problems (rows * out_dim small, e.g. the placeholder query or the graph context): one thread per output,
+// plain k-ordered chain; W rows stay in L1/L2.
+__global__ void k_thin_linear(GemmArgs g)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.rows * g.out_dim) return;
+    const int64_t r = idx / g.out_dim;
+    const int j = (int)(idx - r * g.out_dim);
+    const float* xr = g.x + r * g.ldx;
+    float acc = g.bias ? g.bias[j] : 0.0f;
+    if (!g.wt) {
+        const float* w = g.W + (int64_t)j * g.ldw;
+        for (int k = 0; k < g.in_dim; ++k) acc = fma_(xr[k], w[k], acc);
+    } else {
+        for (int k = 0; k < g.in_dim; ++k) acc = fma_(xr[k], g.W[(int64_t)k * g.ldw + j], acc);
+    }
+    if (g.relu && !(acc > 0.0f)) acc = 0.0f;
+    if (g.res) acc = g.res[r * g.ldres + j] + acc;
+    if (g.bn_gamma) { float sc, sh; bn_consts(g, j, sc, sh); acc = fma_(acc, sc, sh); }
+    g.y[r * g.ldy + j] = acc;
 }
 
 // VALU cross-check: 64x64 tile, 4x4 outputs per thread, sequential k
@@ -255,14 +328,19 @@ __global__ void k_small_linear(GemmArgs g)
     g.y[r * g.ldy + j] = acc;
 }
 
-int launch_linear(const GemmArgs& g, hipStream_t st)
+int launch_linear(const GemmArgs& g0, hipStream_t st)
 {
+    GemmArgs g = g0;
+    g.dbg = g_debug[2];
     const bool force_valu = g_debug[0] != 0;
     if (g.rows <= 0) return 0;
     if (g.in_dim <= 4) {
         const int64_t n = g.rows * g.out_dim;
         hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
-    } else if (force_valu || (g.in_dim & 3) || (g.ldx & 3) || ((uintptr_t)g.x & 15) || (g.ldw & 3) ||
+    } else if (!force_valu && g.rows * g.out_dim <= 262144) {
+        const int64_t n = g.rows * g.out_dim;
+        hipLaunchKernelGGL(k_thin_linear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
+    } else if (force_valu || (g.in_dim % GK) || (g.ldx & 3) || ((uintptr_t)g.x & 15) || (g.ldw & 3) ||
                ((uintptr_t)g.W & 15) || (g.wt && (g.out_dim & 3))) {
         dim3 grid((unsigned)((g.rows + 63) / 64), (unsigned)((g.out_dim + 63) / 64));
         hipLaunchKernelGGL(k_linear_valu, grid, dim3(256), 0, st, g);

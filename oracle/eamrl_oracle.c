@@ -42,6 +42,7 @@
  * Build: gcc -O2 -ffp-contract=off (see Makefile).  -ffp-contract=off is REQUIRED.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -123,6 +124,13 @@ static float d_tanhf(float x)
         t = 1.0f - 2.0f / (e + 1.0f);
     }
     return copysignf(t, x);
+}
+
+/* worker threads used by every parallel loop below; returns the value in force */
+ORC_API int orc_set_threads(int n)
+{
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
 }
 
 ORC_API void orc_math_probe(const float* x, float* y_exp, float* y_log, float* y_tanh, long n)

@@ -50,6 +50,35 @@ def lib():
     return _LIB
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: affinity mask and cgroup quota, not the machine's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def set_threads(n: int) -> int:
+    return int(lib().orc_set_threads(C.c_int(int(n))))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

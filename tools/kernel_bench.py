@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of single kernels at the TSP-100 B=1024 shapes (run on the GPU box).
+
+    python tools/kernel_bench.py gemm | mha | decode | all      [--iters 20]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from eam_rl4co_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def bench_gemm(iters):
+    rows = 102400
+    dev = "cuda"
+    shapes = [("qkv", 128, 384, False, False), ("out_proj+res+bn", 128, 128, True, True), ("ffn1+relu", 128, 512, False, False),
+              ("ffn2+res+bn", 512, 128, True, True), ("kvl", 128, 384, False, False), ("pa", 128, 128, False, False)]
+    for name, k, n, res, bn in shapes:
+        x = torch.randn(rows, k, device=dev)
+        W = torch.randn(n, k, device=dev) / k ** 0.5
+        b = torch.randn(n, device=dev)
+        r = torch.randn(rows, n, device=dev) if res else None
+        bnp = (torch.rand(n, device=dev) + 0.5, torch.randn(n, device=dev), torch.randn(n, device=dev),
+               torch.rand(n, device=dev) + 0.5, 1e-5) if bn else None
+        out = torch.empty(rows, n, device=dev)
+        us = timeit(lambda: ops.linear(x, W, b, relu=("relu" in name), residual=r, out=out, bn=bnp), iters)
+        fl = 2.0 * rows * k * n
+        by = 4.0 * (rows * k + rows * n * (2 if res else 1))
+        print(f"gemm {name:18s} K={k:4d} N={n:4d}: {us:8.1f} us  {fl / us / 1e6:6.1f} TFLOP/s  {by / us / 1e3:6.0f} GB/s")
+
+
+def bench_mha(iters):
+    qkv = torch.randn(1024, 100, 384, device="cuda")
+    us = timeit(lambda: ops.mha_encoder(qkv, 8), iters)
+    print(f"mha_encoder B=1024 N=100: {us:8.1f} us")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dbg", type=int, default=0, help="eamrl_debug_set(2, dbg): 1 no fetch, 2 no mfma, 4 no sync/stash")
+    a = ap.parse_args()
+    from eam_rl4co_amd import _lib
+    _lib.load().eamrl_debug_set(2, a.dbg)
+    if a.what in ("gemm", "all"):
+        bench_gemm(a.iters)
+    if a.what in ("mha", "all"):
+        bench_mha(a.iters)
+
+
+if __name__ == "__main__":
+    main()
