@@ -96,30 +96,33 @@ __device__ __forceinline__ void gemm_stash1(float* S, int p, const float4 v)
 // MFMA operands of 4 consecutive k for one 32-row strip: lane half lk reads the aligned pair (k+2lk, k+2lk+1);
 // one v_permlane32_swap turns ([k | k+2], [k+1 | k+3]) into ([k | k+1], [k+2 | k+3]) = the operands of the two
 // k-steps (lanes 0-31 carry the lower k of a step, lanes 32-63 the higher one).
-__device__ __forceinline__ void mfma_operands(const float* row_ptr, float& first, float& second)
+__device__ __forceinline__ void pair_swap(const float2 v, float& first, float& second)
 {
-    const float2 v = *reinterpret_cast<const float2*>(row_ptr);
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v.x), __float_as_uint(v.y), false, false);
     first = __uint_as_float(r[0]);
     second = __uint_as_float(r[1]);
 }
 
-// ALIGNED: x / W rows start 16-B aligned (ld % 4 == 0, base % 16 == 0) so tiles are fetched as float4.
-template <bool WT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_mfma(GemmArgs g)
+// Tile = BM rows x 128 columns, 4 waves as 2 x 2, each wave (BM/2) x 64 = (BM/64) x 2 MFMA tiles of 32 x 32.
+// BM = 64 gives twice as many (half-size) tiles: better balance over the 256 CUs and more blocks per CU.
+template <bool WT, int BM>
+__global__ __launch_bounds__(256, 2) void k_linear_mfma(GemmArgs g)
 {
-    __shared__ __attribute__((aligned(16))) float smem_ab[2 * GT * GS];   // one object: A tile | B tile, reused by the epilogue
+    constexpr int TA = BM / 64;                     // MFMA row tiles per wave; also A-tile float4 per thread / 2
+    constexpr int NA = BM / 32;                     // A-tile float4 per thread (BM * 8 float4 / 256 threads)
+    constexpr int SMEM_FLOATS = (BM + GT) * GS > 4 * 32 * 68 ? (BM + GT) * GS : 4 * 32 * 68;
+    __shared__ __attribute__((aligned(16))) float smem_ab[SMEM_FLOATS];   // A tile | B tile, reused by the epilogue slabs
     float* As = smem_ab;
-    float* Bs = smem_ab + GT * GS;
+    float* Bs = smem_ab + BM * GS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv >> 1, wc = wv & 1;           // wave position in the 2x2 grid of 64x64 sub-tiles
-    const int64_t row0 = (int64_t)blockIdx.x * GT;
+    const int wr = wv >> 1, wc = wv & 1;           // wave position in the 2 x 2 grid
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int col0 = blockIdx.y * GT;
     const int li = lane & 31, lk = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TA][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int j = col0 + wc * 64 + b * 32 + li;           // C column of this lane
@@ -129,53 +132,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
 
     float4 ta0, ta1, ta2, ta3, tb0, tb1, tb2, tb3;    // register-staged next operand tiles
+    ta2 = ta3 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t rows_left = g.rows - row0;
-    const TileOffs oa = gemm_offsets<false>(g.ldx, rows_left < GT ? (int)rows_left : GT);
+    const TileOffs oa = gemm_offsets<false>(g.ldx, rows_left < BM ? (int)rows_left : BM);
     const TileOffs ob = gemm_offsets<WT>(g.ldw, g.out_dim - col0 < GT ? g.out_dim - col0 : GT);
     const float* xbase = g.x + row0 * g.ldx;                                        // block-uniform bases
     const float* wbase = WT ? g.W + col0 : g.W + (int64_t)col0 * g.ldw;
-    GEMM_FETCH(false, xbase, g.ldx, oa, 0, ta0, ta1, ta2, ta3);
+#define FETCH_A(k0_)                                                                                   \
+    do {                                                                                               \
+        const float* kb_ = xbase + (k0_);                                                              \
+        ta0 = *reinterpret_cast<const float4*>(kb_ + oa.o[0]);                                         \
+        ta1 = *reinterpret_cast<const float4*>(kb_ + oa.o[1]);                                         \
+        if (NA == 4) {                                                                                 \
+            ta2 = *reinterpret_cast<const float4*>(kb_ + oa.o[2]);                                     \
+            ta3 = *reinterpret_cast<const float4*>(kb_ + oa.o[3]);                                     \
+        }                                                                                              \
+    } while (0)
+#define STASH_A()                                                                                      \
+    do {                                                                                               \
+        gemm_stash1<false>(As, 0, ta0);                                                                \
+        gemm_stash1<false>(As, 1, ta1);                                                                \
+        if (NA == 4) { gemm_stash1<false>(As, 2, ta2); gemm_stash1<false>(As, 3, ta3); }               \
+    } while (0)
+    FETCH_A(0);
     GEMM_FETCH(WT, wbase, g.ldw, ob, 0, tb0, tb1, tb2, tb3);
-    GEMM_STASH(false, As, ta0, ta1, ta2, ta3);
+    STASH_A();
     GEMM_STASH(WT, Bs, tb0, tb1, tb2, tb3);
     __syncthreads();
     for (int k0 = 0; k0 < g.in_dim; k0 += GK) {
         const bool more = k0 + GK < g.in_dim;
         if (more) {   // next tile's global loads fly while this tile is multiplied
-            GEMM_FETCH(false, xbase, g.ldx, oa, k0 + GK, ta0, ta1, ta2, ta3);
+            FETCH_A(k0 + GK);
             GEMM_FETCH(WT, wbase, g.ldw, ob, k0 + GK, tb0, tb1, tb2, tb3);
         }
-#pragma unroll 1
-        for (int kq = 0; kq < GK; kq += 4) {       // 4 k values = 2 MFMA k-steps
-            float a0[2], a1[2], b0[2], b1[2];
+        // 8 groups of 4 k values (= 2 MFMA k-steps each); operand pairs come from LDS as aligned 8-byte reads
+        const float* arow = As + (wr * (BM / 2) + li) * GS + 2 * lk;
+        const float* brow = Bs + (wc * 64 + li) * GS + 2 * lk;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) mfma_operands(As + (wr * 64 + a * 32 + li) * GS + kq + 2 * lk, a0[a], a1[a]);
+        for (int kq = 0; kq < GK; kq += 4) {
+            float a0[TA], a1[TA], b0[2], b1[2];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) mfma_operands(Bs + (wc * 64 + b * 32 + li) * GS + kq + 2 * lk, b0[b], b1[b]);
+            for (int a = 0; a < TA; ++a) pair_swap(*reinterpret_cast<const float2*>(arow + a * 32 * GS + kq), a0[a], a1[a]);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) pair_swap(*reinterpret_cast<const float2*>(brow + b * 32 * GS + kq), b0[b], b1[b]);
+#pragma unroll
+            for (int a = 0; a < TA; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[a], b0[b], acc[a][b], 0, 0, 0);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < TA; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[a], b1[b], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
         if (more) {
-            GEMM_STASH(false, As, ta0, ta1, ta2, ta3);
+            STASH_A();
             GEMM_STASH(WT, Bs, tb0, tb1, tb2, tb3);
             __syncthreads();
         }
     }
+#undef FETCH_A
+#undef STASH_A
     // Epilogue through LDS: each wave parks a 32 x 64 slab of its accumulators (C/D layout: col = lane&31,
     // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) and reads it back row-major, so residual loads and output
     // stores are float4 per lane and 256 contiguous bytes per 16 lanes.
     constexpr int CS = 68;                                  // slab row stride (floats): 272 B keeps float4 alignment
     float* slab = smem_ab + wv * (32 * CS);                 // 4 waves x 8.5 KB inside the operand tile storage
-    static_assert(4 * 32 * CS <= 2 * GT * GS, "epilogue slabs must fit the operand tile storage");
+    static_assert(4 * 32 * CS <= SMEM_FLOATS, "epilogue slabs must fit the shared buffer");
     const int er = lane >> 4, ec = (lane & 15) * 4;         // this lane's (row within 4, first column) when reading
     const int jbase = col0 + wc * 64 + ec;
     float sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -187,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const bool vec_ok = ((g.ldy & 3) == 0) && (((uintptr_t)g.y & 15) == 0) && (jbase + 3 < g.out_dim) &&
                         (!g.res || (((g.ldres & 3) == 0) && (((uintptr_t)g.res & 15) == 0)));
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < TA; ++a) {
         __syncthreads();                                    // slab (and, first time, the operand tiles) are free
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -198,7 +223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int rr = er + 4 * p;
-            const int64_t r = row0 + wr * 64 + a * 32 + rr;
+            const int64_t r = row0 + wr * (BM / 2) + a * 32 + rr;
             if (r >= g.rows) continue;
             float4 v4 = *reinterpret_cast<const float4*>(slab + rr * CS + ec);
             float v[4] = {v4.x, v4.y, v4.z, v4.w};
@@ -345,9 +370,15 @@ int launch_linear(const GemmArgs& g0, hipStream_t st)
         dim3 grid((unsigned)((g.rows + 63) / 64), (unsigned)((g.out_dim + 63) / 64));
         hipLaunchKernelGGL(k_linear_valu, grid, dim3(256), 0, st, g);
     } else {
-        dim3 grid((unsigned)((g.rows + GT - 1) / GT), (unsigned)((g.out_dim + GT - 1) / GT));
-        if (g.wt) hipLaunchKernelGGL(k_linear_mfma<true>, grid, dim3(256), 0, st, g);
-        else hipLaunchKernelGGL(k_linear_mfma<false>, grid, dim3(256), 0, st, g);
+        const int bm = g_debug[4] ? 128 : 64;
+        dim3 grid((unsigned)((g.rows + bm - 1) / bm), (unsigned)((g.out_dim + GT - 1) / GT));
+        if (bm == 64) {
+            if (g.wt) hipLaunchKernelGGL((k_linear_mfma<true, 64>), grid, dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((k_linear_mfma<false, 64>), grid, dim3(256), 0, st, g);
+        } else {
+            if (g.wt) hipLaunchKernelGGL((k_linear_mfma<true, 128>), grid, dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((k_linear_mfma<false, 128>), grid, dim3(256), 0, st, g);
+        }
     }
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
@@ -401,12 +432,115 @@ __global__ __launch_bounds__(128) void k_mha_encoder(const float* qkv, float* ou
     }
 }
 
+// Register-blocked variant for D = 16: one block = (instance, group of 4 heads), one thread = TWO query rows of one
+// head, so every K / V row fetched from LDS feeds two fma chains and the kernel is VALU-bound instead of
+// LDS-bound (a broadcast ds_read_b128 still costs 4 LDS cycles).  Same per-row arithmetic as k_mha_encoder.
+__global__ __launch_bounds__(256) void k_mha_encoder_x2(const float* __restrict__ qkv, float* __restrict__ out, int N, int E,
+                                                        int H)
+{
+    constexpr int D = 16, HG = 4, W = HG * D;          // 64 floats of K (and of V) per node in LDS
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ks = reinterpret_cast<float*>(smem);        // [N][W]
+    float* vs = ks + (size_t)N * W;                    // [N][W]
+    const int groups = H / HG;
+    const int64_t b = blockIdx.x / groups;
+    const int h0 = (blockIdx.x - b * groups) * HG;
+    const float* base = qkv + b * (int64_t)N * 3 * E;
+    for (int i = threadIdx.x; i < N * (W / 4); i += blockDim.x) {
+        const int n = i / (W / 4), c4 = i - n * (W / 4);
+        const float* src = base + (int64_t)n * 3 * E + h0 * D + 4 * c4;
+        *reinterpret_cast<float4*>(ks + n * W + 4 * c4) = *reinterpret_cast<const float4*>(src + E);
+        *reinterpret_cast<float4*>(vs + n * W + 4 * c4) = *reinterpret_cast<const float4*>(src + 2 * E);
+    }
+    __syncthreads();
+    const int P = (N + 1) / 2;                          // row pairs per head
+    const int hh = threadIdx.x / P, pr = threadIdx.x - hh * P;
+    if (hh >= HG) return;
+    const int i0 = pr, i1 = pr + P;                     // rows i0 < P <= i1
+    const bool has1 = i1 < N;
+    const int i1c = has1 ? i1 : N - 1;
+    f32x2 q2[D];                                        // (row i0, row i1) side by side: packed fp32 math
+    {
+        const float* p0 = base + (int64_t)i0 * 3 * E + (h0 + hh) * D;
+        const float* p1 = base + (int64_t)i1c * 3 * E + (h0 + hh) * D;
+#pragma unroll
+        for (int d = 0; d < D; d += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(p0 + d);
+            const float4 c = *reinterpret_cast<const float4*>(p1 + d);
+            q2[d] = (f32x2){a.x, c.x}; q2[d + 1] = (f32x2){a.y, c.y};
+            q2[d + 2] = (f32x2){a.z, c.z}; q2[d + 3] = (f32x2){a.w, c.w};
+        }
+    }
+    const float* kh = ks + hh * D;
+    const float* vh = vs + hh * D;
+    const f32x2 quarter = splat2(0.25f);
+    f32x2 m2 = splat2(-INFINITY);
+    for (int j = 0; j < N; ++j) {
+        f32x2 a2 = splat2(0.0f);
+#pragma unroll
+        for (int d = 0; d < D; d += 4) {
+            const float4 kk = *reinterpret_cast<const float4*>(kh + j * W + d);
+            a2 = pk_fma(q2[d], splat2(kk.x), a2);
+            a2 = pk_fma(q2[d + 1], splat2(kk.y), a2);
+            a2 = pk_fma(q2[d + 2], splat2(kk.z), a2);
+            a2 = pk_fma(q2[d + 3], splat2(kk.w), a2);
+        }
+        a2 = a2 * quarter;
+        m2.x = __builtin_fmaxf(m2.x, a2.x);
+        m2.y = __builtin_fmaxf(m2.y, a2.y);
+    }
+    f32x2 Z2 = splat2(0.0f), o2[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) o2[d] = splat2(0.0f);
+    for (int j = 0; j < N; ++j) {
+        f32x2 a2 = splat2(0.0f);
+#pragma unroll
+        for (int d = 0; d < D; d += 4) {
+            const float4 kk = *reinterpret_cast<const float4*>(kh + j * W + d);
+            a2 = pk_fma(q2[d], splat2(kk.x), a2);
+            a2 = pk_fma(q2[d + 1], splat2(kk.y), a2);
+            a2 = pk_fma(q2[d + 2], splat2(kk.z), a2);
+            a2 = pk_fma(q2[d + 3], splat2(kk.w), a2);
+        }
+        const f32x2 w2 = d_expf2(a2 * quarter - m2);
+        Z2 = Z2 + w2;
+#pragma unroll
+        for (int d = 0; d < D; d += 4) {
+            const float4 vv = *reinterpret_cast<const float4*>(vh + j * W + d);
+            o2[d] = pk_fma(w2, splat2(vv.x), o2[d]);
+            o2[d + 1] = pk_fma(w2, splat2(vv.y), o2[d + 1]);
+            o2[d + 2] = pk_fma(w2, splat2(vv.z), o2[d + 2]);
+            o2[d + 3] = pk_fma(w2, splat2(vv.w), o2[d + 3]);
+        }
+    }
+    float o0[D], o1[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { o0[d] = o2[d].x; o1[d] = o2[d].y; }
+    const float Z0 = Z2.x, Z1 = Z2.y;
+    float* op0 = out + (b * N + i0) * (int64_t)E + (h0 + hh) * D;
+#pragma unroll
+    for (int d = 0; d < D; d += 4)
+        *reinterpret_cast<float4*>(op0 + d) = make_float4(o0[d] / Z0, o0[d + 1] / Z0, o0[d + 2] / Z0, o0[d + 3] / Z0);
+    if (has1) {
+        float* op1 = out + (b * N + i1) * (int64_t)E + (h0 + hh) * D;
+#pragma unroll
+        for (int d = 0; d < D; d += 4)
+            *reinterpret_cast<float4*>(op1 + d) = make_float4(o1[d] / Z1, o1[d + 1] / Z1, o1[d + 2] / Z1, o1[d + 3] / Z1);
+    }
+}
+
 int launch_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H, hipStream_t st)
 {
     const int D = E / H;
     const size_t lds = (size_t)2 * N * D * sizeof(float);
     if (D * H != E || lds > 160 * 1024 || B * H > 0x7fffffffLL) return EAMRL_E_ARG;
     dim3 grid((unsigned)(B * H)), block(128);
+    // blocked kernel: 4 heads per block, 2 query rows per thread (needs 4 * ceil(N/2) <= 256 threads, aligned rows)
+    if (D == 16 && H % 4 == 0 && 2 * (N + 1) <= 256 && !g_debug[3] && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+        const size_t lds2 = (size_t)2 * N * 64 * sizeof(float);
+        hipLaunchKernelGGL(k_mha_encoder_x2, dim3((unsigned)(B * (H / 4))), dim3(256), lds2, st, qkv, out, N, E, H);
+        return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+    }
     if (D == 16) {
         if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_mha_encoder<16>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -54,7 +54,9 @@ int eamrl_version(void);
 const char* eamrl_last_error(void);
 /* Diagnostic knobs (tests / profiling only; results never depend on them, only the kernel variant used).
  * key 0: 1 = run eamrl_linear on the VALU cross-check kernel instead of the MFMA kernel.
- * key 1: 1 = eamrl_am_rollout always uses the streaming kernel (never the register-resident one). */
+ * key 1: 1 = eamrl_am_rollout always uses the streaming kernel (never the register-resident one).
+ * key 4: 1 = eamrl_linear uses 128-row tiles instead of 64-row tiles.
+ * key 3: 1 = eamrl_mha_encoder uses the one-row-per-thread kernel even where the blocked one applies. */
 int eamrl_debug_set(int key, int value);
 
 /* ---- environment state machines ---------------------------------------------------------------- */

@@ -80,11 +80,12 @@ def test_library_loads_and_shares_torch_stream():
     assert y.cpu().reshape(-1).tolist() == [10.0, 32.0, 54.0]
 
 
-@pytest.mark.parametrize("rows,k,n", [(1, 256, 128), (77, 128, 384), (300, 512, 128), (513, 128, 640), (50, 6, 7),
+@pytest.mark.parametrize("rows,k,n", [(1, 256, 128), (77, 128, 384), (300, 512, 128), (513, 128, 640), (2500, 128, 128), (50, 6, 7),
                                        (64, 129, 33), (9, 3, 128)])
-@pytest.mark.parametrize("valu", [0, 1])
-def test_linear_is_a_k_ordered_fma_chain(oracle, rows, k, n, valu):
-    """MFMA (v_mfma_f32_32x32x2_f32) and VALU kernels both equal the oracle's sequential fmaf chain."""
+@pytest.mark.parametrize("variant", ["mfma64", "mfma128", "valu"])
+def test_linear_is_a_k_ordered_fma_chain(oracle, rows, k, n, variant):
+    """MFMA (v_mfma_f32_32x32x2_f32, 64- and 128-row tiles) and VALU kernels all equal the oracle's fmaf chain."""
+    valu = int(variant == "valu")
     from eam_rl4co_amd import _lib, ops
 
     rng = np.random.default_rng(rows * 7 + k)
@@ -94,6 +95,7 @@ def test_linear_is_a_k_ordered_fma_chain(oracle, rows, k, n, valu):
     res = rng.standard_normal((rows, n)).astype(np.float32)
     lib = _lib.load()
     lib.eamrl_debug_set(0, valu)
+    lib.eamrl_debug_set(4, int(variant == "mfma128"))
     try:
         y = ops.linear(t(x), t(W), t(b))
         assert_bits_equal(y, oracle.linear(x, W, b), "linear")
@@ -108,6 +110,7 @@ def test_linear_is_a_k_ordered_fma_chain(oracle, rows, k, n, valu):
         assert_bits_equal(y, ref, "linear + fused batch-norm")
     finally:
         lib.eamrl_debug_set(0, 0)
+        lib.eamrl_debug_set(4, 0)
 
 
 def test_matmul_right(oracle):
@@ -119,14 +122,21 @@ def test_matmul_right(oracle):
     assert_bits_equal(ops.matmul_right(t(x), t(Wt)), oracle.matmul_right(x, Wt), "matmul_right")
 
 
-@pytest.mark.parametrize("B,N", [(3, 20), (2, 100), (1, 301)])
+@pytest.mark.parametrize("B,N", [(3, 20), (2, 100), (2, 101), (1, 127), (1, 301)])
 def test_encoder_attention_norms_mean(oracle, B, N):
     from eam_rl4co_amd import ops
 
     rng = np.random.default_rng(N)
     E, H = 128, 8
+    from eam_rl4co_amd import _lib
     qkv = rng.standard_normal((B, N, 3 * E)).astype(np.float32)
-    assert_bits_equal(ops.mha_encoder(t(qkv), H), oracle.mha_encoder(qkv, H), "mha_encoder")
+    ref = oracle.mha_encoder(qkv, H)
+    for variant in (0, 1):     # blocked (2 rows / thread) and plain kernels
+        _lib.load().eamrl_debug_set(3, variant)
+        try:
+            assert_bits_equal(ops.mha_encoder(t(qkv), H), ref, f"mha_encoder variant {variant}")
+        finally:
+            _lib.load().eamrl_debug_set(3, 0)
     x = rng.standard_normal((B, N, E)).astype(np.float32)
     g, bt = rng.standard_normal(E).astype(np.float32), rng.standard_normal(E).astype(np.float32)
     mu, var = rng.standard_normal(E).astype(np.float32), (rng.random(E) + 0.5).astype(np.float32)

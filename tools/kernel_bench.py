@@ -56,10 +56,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--dbg", type=int, default=0, help="eamrl_debug_set(2, dbg): 1 no fetch, 2 no mfma, 4 no sync/stash")
+    ap.add_argument("--dbg", type=int, default=0)
+    ap.add_argument("--bm128", type=int, default=0)
     a = ap.parse_args()
     from eam_rl4co_amd import _lib
     _lib.load().eamrl_debug_set(2, a.dbg)
+    _lib.load().eamrl_debug_set(4, a.bm128)
     if a.what in ("gemm", "all"):
         bench_gemm(a.iters)
     if a.what in ("mha", "all"):
