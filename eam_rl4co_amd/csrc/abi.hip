@@ -204,7 +204,7 @@ __attribute__((visibility("default"))) int eamrl_am_rollout(int env, const eamrl
     REQUIRE(actions && logps && steps_out && a.done && t_max > 0, "eamrl_am_rollout");
     if (env == EAMRL_ENV_CVRP) REQUIRE(a.visited && a.demand, "eamrl_am_rollout");
     if (mode == EAMRL_EVALUATE) REQUIRE(t_given > 0, "eamrl_am_rollout");
-    a.fuse_env = 1; a.t_max = t_max; a.t_given = t_given;
+    a.fuse_env = 1; a.t_max = t_max; a.t_given = t_given; a.dbg = g_debug[5];
     a.action = actions; a.logp = logps; a.steps_out = steps_out;
     if (!g_debug[1] && rollout_resident_supports(env, a))
         return launched(launch_rollout_resident(env, a, (hipStream_t)stream), "eamrl_am_rollout");

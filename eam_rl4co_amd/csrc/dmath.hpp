@@ -17,13 +17,16 @@ namespace eamrl {
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 // exp(x), x <= 88; exactly 0 below -87 so every result is a normal number (-inf and NaN -> 0).
+// Branch-free (selects only): the decode loop runs these on a single wavefront where every exec-mask branch costs
+// scalar round trips; the arithmetic on the selected path is the same sequence as the oracle's d_expf.
 __device__ __forceinline__ float d_expf(float x)
 {
-    if (!(x >= -87.0f)) return 0.0f;
-    if (x > 88.0f) x = 88.0f;
-    float t = x * 1.44269504088896341f;
+    const bool valid = x >= -87.0f;                 // false for -inf and NaN
+    float xc = valid ? x : 0.0f;
+    xc = xc > 88.0f ? 88.0f : xc;
+    float t = xc * 1.44269504088896341f;
     float n = __builtin_rintf(t);  // v_rndne_f32
-    float r = fma_(n, -0.693359375f, x);
+    float r = fma_(n, -0.693359375f, xc);
     r = fma_(n, 2.12194440e-4f, r);
     float p = 1.9875691500e-4f;
     p = fma_(p, r, 1.3981999507e-3f);
@@ -34,7 +37,8 @@ __device__ __forceinline__ float d_expf(float x)
     float r2 = r * r;
     float y = fma_(p, r2, r) + 1.0f;
     int ni = (int)n;
-    return y * __uint_as_float((uint32_t)(ni + 127) << 23);
+    const float res = y * __uint_as_float((uint32_t)(ni + 127) << 23);
+    return valid ? res : 0.0f;
 }
 
 // Two-wide forms: every operation is the packed (v_pk_*_f32) twin of the scalar sequence above, applied to both
@@ -46,7 +50,9 @@ __device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
 
 __device__ __forceinline__ f32x2 d_expf2(f32x2 x)
 {
-    f32x2 xc = x;
+    f32x2 xc;
+    xc.x = (x.x >= -87.0f) ? x.x : 0.0f;
+    xc.y = (x.y >= -87.0f) ? x.y : 0.0f;
     xc.x = xc.x > 88.0f ? 88.0f : xc.x;
     xc.y = xc.y > 88.0f ? 88.0f : xc.y;
     const f32x2 t = xc * splat2(1.44269504088896341f);
@@ -78,7 +84,9 @@ __device__ __forceinline__ float d_logf(float x)
     uint32_t u = __float_as_uint(x);
     int e = (int)(u >> 23) - 126;
     float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
-    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+    const bool low = m < 0.707106781186547524f;
+    e = low ? e - 1 : e;
+    m = low ? (m + m) - 1.0f : m - 1.0f;
     float z = m * m;
     float p = 7.0376836292e-2f;
     p = fma_(p, m, -1.1514610310e-1f);
@@ -97,25 +105,48 @@ __device__ __forceinline__ float d_logf(float x)
     return fma_(0.693359375f, fe, r);
 }
 
+// tanh: small-|x| polynomial and exp-based branch both evaluated, result selected (no exec-mask branches)
 __device__ __forceinline__ float d_tanhf(float x)
 {
-    float a = __builtin_fabsf(x);
-    float t;
-    if (a < 0.625f) {
-        float z = a * a;
-        float p = -5.70498872745e-3f;
-        p = fma_(p, z, 2.06390887954e-2f);
-        p = fma_(p, z, -5.37397155531e-2f);
-        p = fma_(p, z, 1.33314422036e-1f);
-        p = fma_(p, z, -3.33332819422e-1f);
-        t = fma_(p * z, a, a);
-    } else if (a > 9.0f) {
-        t = 1.0f;
-    } else {
-        float e = d_expf(a + a);
-        t = 1.0f - 2.0f / (e + 1.0f);
-    }
+    const float a = __builtin_fabsf(x);
+    const float z = a * a;
+    float p = -5.70498872745e-3f;
+    p = fma_(p, z, 2.06390887954e-2f);
+    p = fma_(p, z, -5.37397155531e-2f);
+    p = fma_(p, z, 1.33314422036e-1f);
+    p = fma_(p, z, -3.33332819422e-1f);
+    const float t_small = fma_(p * z, a, a);
+    const float ac = a > 9.0f ? 9.0f : a;           // keeps exp finite; |x| > 9 is forced to 1 below
+    const float e = d_expf(ac + ac);
+    const float t_big = 1.0f - 2.0f / (e + 1.0f);
+    const float t = (a < 0.625f) ? t_small : ((a > 9.0f) ? 1.0f : t_big);
     return __builtin_copysignf(t, x);
+}
+
+// two-wide tanh (each half == d_tanhf of that half)
+__device__ __forceinline__ f32x2 d_tanhf2(f32x2 x)
+{
+    f32x2 a;
+    a.x = __builtin_fabsf(x.x);
+    a.y = __builtin_fabsf(x.y);
+    const f32x2 z = a * a;
+    f32x2 p = splat2(-5.70498872745e-3f);
+    p = pk_fma(p, z, splat2(2.06390887954e-2f));
+    p = pk_fma(p, z, splat2(-5.37397155531e-2f));
+    p = pk_fma(p, z, splat2(1.33314422036e-1f));
+    p = pk_fma(p, z, splat2(-3.33332819422e-1f));
+    const f32x2 t_small = pk_fma(p * z, a, a);
+    f32x2 ac;
+    ac.x = a.x > 9.0f ? 9.0f : a.x;
+    ac.y = a.y > 9.0f ? 9.0f : a.y;
+    const f32x2 e = d_expf2(ac + ac);
+    const f32x2 t_big = splat2(1.0f) - splat2(2.0f) / (e + splat2(1.0f));
+    f32x2 t;
+    t.x = (a.x < 0.625f) ? t_small.x : ((a.x > 9.0f) ? 1.0f : t_big.x);
+    t.y = (a.y < 0.625f) ? t_small.y : ((a.y > 9.0f) ? 1.0f : t_big.y);
+    t.x = __builtin_copysignf(t.x, x.x);
+    t.y = __builtin_copysignf(t.y, x.y);
+    return t;
 }
 
 // ---- cross-lane exchange steps of a 64-lane butterfly, without LDS traffic -------------------------------

@@ -7,10 +7,14 @@
 // 512 rows are in flight on the chip and a 1024-row batch takes two waves of workgroups.  Per step nothing
 // but the selected action and its log-prob (12 B) goes to HBM, and the Exp(1) noise row when sampling.
 //
-// Thread layouts (tid in [0,256), lane = tid & 63):
-//   scores / logits : thread (n = tid & 127, hs = tid >> 7) keeps K[n][64hs..64hs+63] and Lp[n][64hs..64hs+63]
-//   glimpse (P*V)   : thread (e = tid & 127, g = tid >> 7) keeps V[n][e] for the nodes of chunks 2g and 2g+1
-//   final softmax   : wavefront 0, lane l handles nodes l and l + 64 (all reductions are DPP butterflies)
+// Thread layouts (tid in [0,256), lane = tid & 63, wave w = tid >> 6).  Each lane owns the node pair
+// (lane, lane + 64), so every reduction over nodes is one in-wave DPP butterfly and a step needs 4 barriers:
+//   scores   : wave w, heads 2w and 2w+1 : K[n][32w .. 32w+31] of both nodes in registers -> per-head max and
+//              softmax weights inside the wave
+//   glimpse  : thread (column e = tid & 127, g = tid >> 7) keeps V[n][e] for the nodes of chunks 2g and 2g+1
+//   logits   : wave w, column chunk w     : Lp[n][32w .. 32w+31] of both nodes; the 32 glimpse values of the
+//              chunk are finished by lanes 0-31 of the same wave and re-read through a wave-private LDS row
+//   finish   : wavefront 0: clip, mask, log-softmax, selection, env transition, next context query
 // The arithmetic follows the canonical order, so tours, log-probs and rewards are bit-identical
 // to k_rollout_stream, k_decode_step and the CPU oracle.
 //
@@ -33,22 +37,22 @@ template <int CP>
 struct ResLds {
     static constexpr int WROW = 4 * CP + 4;     // floats per head row of w (chunk-padded, +4 spreads banks)
     float q[RE];
-    float heads[RE];
+    float headsw[RE];                           // 4 wave-private rows of 32 glimpse values
     float w[RH * WROW];
     float partA[EAMRL_NCHUNK * RE];
     float partZ[EAMRL_NCHUNK * RH];
     float cpart[RNP * 4];
-    float redmax[4 * 4];
     float dem[RNP];
-    int sel;
-    float sel_lp;
-    int flags;
+    float lp_out[2 * RNP + 2];                  // selected log-probs of the episode (t_max <= 2M+1), written out once
+    int16_t act_out[2 * RNP + 2];               // selected actions of the episode
+    int done;
     uint8_t msk[RNP];
     uint8_t vis[RNP];
     // followed by P[M][RE] (context rows of the current node: TSP Pb, CVRP Pa)
 };
 
-template <int ENV, int CP>
+// CP: chunk stride of a w row in LDS (multiple of 4, >= chunk length C); CR: V registers per chunk (C <= CR <= CP)
+template <int ENV, int CP, int CR>
 __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -58,33 +62,39 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
     constexpr int WROW = L::WROW;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = tid & 127, hs = tid >> 7;   // (node, column half) for K / Lp; also (e = n, g = hs) for V
+    const int ve = tid & 127, vg = tid >> 7;   // glimpse layout: column, chunk pair
     const int M = a.M;
     const int64_t r = blockIdx.x;
     const int64_t bi = r % a.B;
     const int64_t ld = a.ld;
     const int C = (M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
+    const int n0 = lane, n1 = lane + 64;
+    const bool in0 = n0 < M, in1 = n1 < M;
 
-    // ---- one-time loads: K, Lp rows (node-major), V columns (chunked), context rows -> LDS -----------------
-    float kreg[64], lreg[64], vreg[2][CP];
-    {
-        const bool valid = n < M;
-        const float* kp = a.K + (bi * M + (valid ? n : 0)) * ld + 64 * hs;
-        const float* lp = a.Lp + (bi * M + (valid ? n : 0)) * ld + 64 * hs;
+    // ---- one-time loads: K, Lp column slices of both nodes, V columns (chunked), context rows -> LDS ------------
+    float kreg[2][32], lreg[2][32], vreg[2][CR];
 #pragma unroll
-        for (int i = 0; i < 64; i += 4) {
-            float4 kk = valid ? *reinterpret_cast<const float4*>(kp + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 ll = valid ? *reinterpret_cast<const float4*>(lp + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-            kreg[i] = kk.x; kreg[i + 1] = kk.y; kreg[i + 2] = kk.z; kreg[i + 3] = kk.w;
-            lreg[i] = ll.x; lreg[i + 1] = ll.y; lreg[i + 2] = ll.z; lreg[i + 3] = ll.w;
+    for (int k = 0; k < 2; ++k) {
+        const int nn = k ? n1 : n0;
+        const bool valid = nn < M;
+        const float* kp = a.K + (bi * M + (valid ? nn : 0)) * ld + 32 * wv;
+        const float* lp = a.Lp + (bi * M + (valid ? nn : 0)) * ld + 32 * wv;
+#pragma unroll
+        for (int i = 0; i < 32; i += 4) {
+            const float4 kk = valid ? *reinterpret_cast<const float4*>(kp + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 ll = valid ? *reinterpret_cast<const float4*>(lp + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            kreg[k][i] = kk.x; kreg[k][i + 1] = kk.y; kreg[k][i + 2] = kk.z; kreg[k][i + 3] = kk.w;
+            lreg[k][i] = ll.x; lreg[k][i + 1] = ll.y; lreg[k][i + 2] = ll.z; lreg[k][i + 3] = ll.w;
         }
-        const float* vp = a.V + bi * M * ld + n;   // column e = n
+    }
+    {
+        const float* vp = a.V + bi * M * ld + ve;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int n0 = (2 * hs + c) * C;
+            const int nb = (2 * vg + c) * C;
 #pragma unroll
-            for (int i = 0; i < CP; ++i) {
-                const int nn = n0 + i;
+            for (int i = 0; i < CR; ++i) {
+                const int nn = nb + i;
                 vreg[c][i] = (i < C && nn < M) ? vp[(int64_t)nn * ld] : 0.0f;
             }
         }
@@ -96,38 +106,45 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
         }
         for (int i = tid; i < RH * WROW; i += RB) l.w[i] = 0.0f;   // chunk padding stays 0 for the whole episode
     }
-    // per-thread constants
-    const int my_pos = (n < M) ? (n / C) * CP + (n - (n / C) * C) : 0;   // slot of node n in a w row
-    const float gq = (a.gctx && tid < RE) ? a.gctx[bi * RE + tid] : 0.0f;
-    const float cv = (tid < RE) ? a.cvec[tid] : 0.0f;
+    const int pos0 = in0 ? (n0 / C) * CP + (n0 - (n0 / C) * C) : 0;   // slots of the two nodes in a w row
+    const int pos1 = in1 ? (n1 / C) * CP + (n1 - (n1 / C) * C) : 0;
     const float sqrtE = __builtin_sqrtf((float)RE);
 
-    // ---- row state (uniform) ---------------------------------------------------------------------------
-    int64_t first = 0, cur = a.cur[r], istep = 1;
-    float used = 0.0f, vcap = 0.0f;
-    if (ENV == EAMRL_ENV_TSP) { first = a.first[r]; istep = a.istep[r]; }
-    else { used = a.used[r]; vcap = a.vcap[r]; }
-    bool done = a.done[r] != 0;
+    // ---- state: mask / visited in LDS; the scalar row state lives in wavefront 0 -----------------------------------------
     if (tid < RNP) {
         l.msk[tid] = (tid < M) ? a.mask[r * M + tid] : 0;
         l.vis[tid] = (ENV == EAMRL_ENV_CVRP && tid < M) ? a.visited[r * M + tid] : 0;
+        if (ENV == EAMRL_ENV_CVRP) l.dem[tid] = (tid < M - 1) ? a.demand[bi * (M - 1) + tid] : 0.0f;
     }
+    if (tid == 0) l.done = a.done[r] != 0;
     __syncthreads();
-    // remaining feasible (TSP) / visited (CVRP) node count, kept incrementally (== the reference's mask.sum / visited.sum)
-    int count = 0;
-    for (int i = 0; i < M; ++i) count += (ENV == EAMRL_ENV_TSP) ? (l.msk[i] != 0) : (l.vis[i] != 0);
-    float p1f = 0.0f;   // TSP: P_first[first][e] once the first node is known
-    if (ENV == EAMRL_ENV_TSP && istep > 0 && tid < RE) p1f = a.Pa[(bi * M + first) * ld + tid];
-    const float my_dem = (ENV == EAMRL_ENV_CVRP && n >= 1 && n < M) ? a.demand[bi * (M - 1) + n - 1] : 0.0f;
-    if (ENV == EAMRL_ENV_CVRP && hs == 0 && n >= 1) l.dem[n - 1] = my_dem;   // demand row staged in LDS
-    const float* dem = l.dem;
 
-    // query for the first step
-    if (tid < RE) {
-        float ctx;
-        if (ENV == EAMRL_ENV_TSP) ctx = (istep == 0) ? cv : p1f + Plds[cur * RE + tid];
-        else ctx = fma_(cv, vcap - used, Plds[cur * RE + tid]);
-        l.q[tid] = ctx + gq;
+    int64_t first = 0, cur = 0, istep = 1;
+    float used = 0.0f, vcap = 0.0f;
+    int count = 0;
+    float gq[2] = {0.f, 0.f}, cv[2] = {0.f, 0.f}, p1f[2] = {0.f, 0.f}, mydem[2] = {0.f, 0.f};
+    bool done = l.done != 0;
+    if (wv == 0) {
+        cur = a.cur[r];
+        if (ENV == EAMRL_ENV_TSP) { first = a.first[r]; istep = a.istep[r]; }
+        else { used = a.used[r]; vcap = a.vcap[r]; }
+        // remaining feasible (TSP) / visited (CVRP) node count, kept incrementally (== the reference's mask.sum / visited.sum)
+        const int c0 = (ENV == EAMRL_ENV_TSP) ? (in0 && l.msk[n0] != 0) : (in0 && l.vis[n0] != 0);
+        const int c1 = (ENV == EAMRL_ENV_TSP) ? (in1 && l.msk[n1] != 0) : (in1 && l.vis[n1] != 0);
+        count = __builtin_popcountll(__ballot(c0)) + __builtin_popcountll(__ballot(c1));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = lane + 64 * k;
+            gq[k] = a.gctx ? a.gctx[bi * RE + e] : 0.0f;
+            cv[k] = a.cvec[e];
+            if (ENV == EAMRL_ENV_TSP && istep > 0) p1f[k] = a.Pa[(bi * M + first) * ld + e];
+            const int nn = lane + 64 * k;
+            if (ENV == EAMRL_ENV_CVRP && nn >= 1 && nn < M) mydem[k] = l.dem[nn - 1];
+            float ctx;
+            if (ENV == EAMRL_ENV_TSP) ctx = (istep == 0) ? cv[k] : p1f[k] + Plds[cur * RE + e];
+            else ctx = fma_(cv[k], vcap - used, Plds[cur * RE + e]);
+            l.q[e] = ctx + gq[k];
+        }
     }
     __syncthreads();
 
@@ -136,185 +153,196 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
     while (!done && t < a.t_max) {
         // prefetch this step's per-row inputs (latency hidden behind the glimpse)
         float nz0 = 1.0f, nz1 = 1.0f;
-        if (a.mode == EAMRL_SAMPLE && wv == 0) {
-            const float* nzp = a.noise + (r * a.t_max + t) * (int64_t)M;
-            if (lane < M) nz0 = nzp[lane];
-            if (lane + 64 < M) nz1 = nzp[lane + 64];
-        }
         int64_t given = 0;
-        if (a.mode == EAMRL_EVALUATE) given = (t < a.t_given) ? a.given[r * a.t_given + t] : 0;
-
-        // ---- S1: scores of 4 heads for node n, per-head max ------------------------------------------------
-        const bool feas = (n < M) && l.msk[n] != 0;
-        float sc[4];
-#pragma unroll
-        for (int hh = 0; hh < 4; ++hh) {
-            const float* qp = l.q + (4 * hs + hh) * RD;
-            float acc = 0.0f;
-#pragma unroll
-            for (int d = 0; d < RD; d += 4) {
-                const float4 qq = *reinterpret_cast<const float4*>(qp + d);
-                acc = fma_(qq.x, kreg[hh * RD + d], acc);
-                acc = fma_(qq.y, kreg[hh * RD + d + 1], acc);
-                acc = fma_(qq.z, kreg[hh * RD + d + 2], acc);
-                acc = fma_(qq.w, kreg[hh * RD + d + 3], acc);
+        if (wv == 0) {
+            if (a.mode == EAMRL_SAMPLE) {
+                const float* nzp = a.noise + (r * a.t_max + t) * (int64_t)M;
+                if (in0) nz0 = nzp[n0];
+                if (in1) nz1 = nzp[n1];
             }
-            sc[hh] = feas ? acc * 0.25f : -INFINITY;      // 1/sqrt(16)
-            const float m = wave_max(sc[hh]);
-            if (lane == 0) l.redmax[wv * 4 + hh] = m;
+            if (a.mode == EAMRL_EVALUATE) given = (t < a.t_given) ? a.given[r * a.t_given + t] : 0;
         }
-        __syncthreads();
+
+        // ---- S1: scores, per-head max and softmax weights of heads 2w, 2w+1 for both nodes (all inside the wave) ----
+        if (!(a.dbg & 1)) {
+            const bool f0 = in0 && l.msk[n0] != 0, f1 = in1 && l.msk[n1] != 0;
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) {
-            const float m = __builtin_fmaxf(l.redmax[(2 * hs) * 4 + hh], l.redmax[(2 * hs + 1) * 4 + hh]);
-            if (n < M) l.w[(4 * hs + hh) * WROW + my_pos] = feas ? d_expf(sc[hh] - m) : 0.0f;
+            for (int hh = 0; hh < 2; ++hh) {
+                const float* qp = l.q + (2 * wv + hh) * RD;
+                float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                for (int d = 0; d < RD; d += 4) {
+                    const float4 qq = *reinterpret_cast<const float4*>(qp + d);
+                    s0 = fma_(qq.x, kreg[0][hh * RD + d], s0);     s1 = fma_(qq.x, kreg[1][hh * RD + d], s1);
+                    s0 = fma_(qq.y, kreg[0][hh * RD + d + 1], s0); s1 = fma_(qq.y, kreg[1][hh * RD + d + 1], s1);
+                    s0 = fma_(qq.z, kreg[0][hh * RD + d + 2], s0); s1 = fma_(qq.z, kreg[1][hh * RD + d + 2], s1);
+                    s0 = fma_(qq.w, kreg[0][hh * RD + d + 3], s0); s1 = fma_(qq.w, kreg[1][hh * RD + d + 3], s1);
+                }
+                s0 = f0 ? s0 * 0.25f : -INFINITY;              // 1/sqrt(16)
+                s1 = f1 ? s1 * 0.25f : -INFINITY;
+                const float m = wave_max(__builtin_fmaxf(s0, s1));
+                float* wrow = l.w + (2 * wv + hh) * WROW;
+                if (in0) wrow[pos0] = f0 ? d_expf(s0 - m) : 0.0f;
+                if (in1) wrow[pos1] = f1 ? d_expf(s1 - m) : 0.0f;
+            }
         }
         __syncthreads();
 
-        // ---- S2: glimpse partials, column e = n, chunks 2hs and 2hs+1 -------------------------------------------
-        {
-            const int h = n >> 4;
+        // ---- S2: glimpse partials, column ve, chunks 2vg and 2vg+1 ----------------------------------------------------
+        if (!(a.dbg & 2)) {
+            const int h = ve >> 4;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const float* wp = l.w + h * WROW + (2 * hs + c) * CP;
+                const float* wp = l.w + h * WROW + (2 * vg + c) * CP;
                 float zg = 0.0f, ag = 0.0f;
 #pragma unroll
-                for (int i = 0; i < CP; i += 4) {
+                for (int i = 0; i < CR; i += 4) {          // slots >= C hold w = 0 (and are skipped beyond CR)
                     const float4 ww = *reinterpret_cast<const float4*>(wp + i);
                     zg = zg + ww.x; ag = fma_(ww.x, vreg[c][i], ag);
-                    zg = zg + ww.y; ag = fma_(ww.y, vreg[c][i + 1], ag);
-                    zg = zg + ww.z; ag = fma_(ww.z, vreg[c][i + 2], ag);
-                    zg = zg + ww.w; ag = fma_(ww.w, vreg[c][i + 3], ag);
+                    if (i + 1 < CR) { zg = zg + ww.y; ag = fma_(ww.y, vreg[c][i + 1], ag); }
+                    if (i + 2 < CR) { zg = zg + ww.z; ag = fma_(ww.z, vreg[c][i + 2], ag); }
+                    if (i + 3 < CR) { zg = zg + ww.w; ag = fma_(ww.w, vreg[c][i + 3], ag); }
                 }
-                l.partA[(2 * hs + c) * RE + n] = ag;
-                if ((n & 15) == 0) l.partZ[(2 * hs + c) * RH + h] = zg;
+                l.partA[(2 * vg + c) * RE + ve] = ag;
+                if ((ve & 15) == 0) l.partZ[(2 * vg + c) * RH + h] = zg;
             }
         }
         __syncthreads();
-        if (tid < RE) {
-            const int h = tid >> 4;
-            float A = l.partA[tid], Z = l.partZ[h];
-#pragma unroll
-            for (int g = 1; g < EAMRL_NCHUNK; ++g) { A = A + l.partA[g * RE + tid]; Z = Z + l.partZ[g * RH + h]; }
-            l.heads[tid] = A / Z;
-        }
-        __syncthreads();
 
-        // ---- S4: logit partials of column chunks 2hs, 2hs+1 for node n -------------------------------------------
-        {
-            float cp2[2];
+        // ---- S4: lanes 0-31 finish the 32 glimpse values of column chunk w; then the logit partials of both nodes ----
+        if (!(a.dbg & 4)) {
+            float* hw = l.headsw + wv * 32;
+            if (lane < 32) {
+                const int e = wv * 32 + lane, h = e >> 4;
+                float A = l.partA[e], Z = l.partZ[h];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const float* hp = l.heads + (2 * hs + c) * 32;
-                float cg = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 32; e += 4) {
-                    const float4 hh4 = *reinterpret_cast<const float4*>(hp + e);
-                    cg = fma_(hh4.x, lreg[c * 32 + e], cg);
-                    cg = fma_(hh4.y, lreg[c * 32 + e + 1], cg);
-                    cg = fma_(hh4.z, lreg[c * 32 + e + 2], cg);
-                    cg = fma_(hh4.w, lreg[c * 32 + e + 3], cg);
-                }
-                cp2[c] = cg;
+                for (int g = 1; g < EAMRL_NCHUNK; ++g) { A = A + l.partA[g * RE + e]; Z = Z + l.partZ[g * RH + h]; }
+                hw[lane] = A / Z;
             }
-            *reinterpret_cast<float2*>(l.cpart + n * 4 + 2 * hs) = make_float2(cp2[0], cp2[1]);
+            __builtin_amdgcn_wave_barrier();        // same wavefront: LDS executes its accesses in order
+            float c0 = 0.0f, c1 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 32; e += 4) {
+                const float4 h4 = *reinterpret_cast<const float4*>(hw + e);
+                c0 = fma_(h4.x, lreg[0][e], c0);     c1 = fma_(h4.x, lreg[1][e], c1);
+                c0 = fma_(h4.y, lreg[0][e + 1], c0); c1 = fma_(h4.y, lreg[1][e + 1], c1);
+                c0 = fma_(h4.z, lreg[0][e + 2], c0); c1 = fma_(h4.z, lreg[1][e + 2], c1);
+                c0 = fma_(h4.w, lreg[0][e + 3], c0); c1 = fma_(h4.w, lreg[1][e + 3], c1);
+            }
+            l.cpart[n0 * 4 + wv] = c0;
+            l.cpart[n1 * 4 + wv] = c1;
         }
         __syncthreads();
 
-        // ---- S5: wavefront 0 finishes the step: clip, mask, log-softmax, selection -----------------------------------
+        // ---- S5: wavefront 0 finishes the step: clip, mask, log-softmax, selection, env transition, next query -------
         if (wv == 0) {
+            if (!(a.dbg & 32)) __builtin_amdgcn_s_setprio(3);   // the serial section of the step: let it win issue arbitration
+            // both nodes of the lane go through the elementwise math side by side (packed fp32 instructions:
+            // half the issue slots and two independent dependency chains for this single wavefront)
             float x[2], lpv[2];
             bool fe[2];
-            bool nan_seen = false;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int nn = lane + 64 * k;
-                fe[k] = (nn < M) && l.msk[nn] != 0;
-                const float4 cp4 = *reinterpret_cast<const float4*>(l.cpart + nn * 4);
-                const float u = ((cp4.x + cp4.y) + cp4.z) + cp4.w;
-                const float logit = u / sqrtE;
-                if (fe[k] && logit != logit) nan_seen = true;
-                float v = (a.clip > 0.0f) ? d_tanhf(logit) * a.clip : logit;
-                if (!fe[k]) v = -INFINITY;
-                x[k] = v / a.temp;
-            }
+            fe[0] = in0 && l.msk[n0] != 0;
+            fe[1] = in1 && l.msk[n1] != 0;
+            const float4 cpa = *reinterpret_cast<const float4*>(l.cpart + n0 * 4);
+            const float4 cpb = *reinterpret_cast<const float4*>(l.cpart + n1 * 4);
+            f32x2 u2 = (f32x2){cpa.x, cpb.x} + (f32x2){cpa.y, cpb.y};
+            u2 = u2 + (f32x2){cpa.z, cpb.z};
+            u2 = u2 + (f32x2){cpa.w, cpb.w};
+            const f32x2 logit2 = u2 / splat2(sqrtE);
+            const bool nan_seen = (fe[0] && logit2.x != logit2.x) || (fe[1] && logit2.y != logit2.y);
+            f32x2 v2 = (a.clip > 0.0f) ? d_tanhf2(logit2) * splat2(a.clip) : logit2;
+            v2.x = fe[0] ? v2.x : -INFINITY;
+            v2.y = fe[1] ? v2.y : -INFINITY;
+            if (a.temp != 1.0f) v2 = v2 / splat2(a.temp);       // v / 1 == v exactly
+            x[0] = v2.x; x[1] = v2.y;
             const float mx = wave_max(__builtin_fmaxf(x[0], x[1]));
-            const float e0 = fe[0] ? d_expf(x[0] - mx) : 0.0f;
-            const float e1 = fe[1] ? d_expf(x[1] - mx) : 0.0f;
+            const f32x2 ex2 = d_expf2(v2 - splat2(mx));
+            const float e0 = fe[0] ? ex2.x : 0.0f;
+            const float e1 = fe[1] ? ex2.y : 0.0f;
             float Zl = wave_tree_sum(e0);
             if (M > 64) Zl = Zl + wave_tree_sum(e1);
             const float lse = d_logf(Zl);
-            lpv[0] = fe[0] ? (x[0] - mx) - lse : -INFINITY;
-            lpv[1] = fe[1] ? (x[1] - mx) - lse : -INFINITY;
+            const f32x2 lp2 = (v2 - splat2(mx)) - splat2(lse);
+            lpv[0] = fe[0] ? lp2.x : -INFINITY;
+            lpv[1] = fe[1] ? lp2.y : -INFINITY;
             float key0 = lpv[0], key1 = lpv[1];
-            if (a.mode == EAMRL_SAMPLE) { key0 = d_expf(lpv[0]) / nz0; key1 = d_expf(lpv[1]) / nz1; }
-            float best = (lane < M) ? key0 : -INFINITY;
-            int besti = (lane < M) ? lane : 0x7fffffff;
-            if (lane + 64 < M && key1 > best) { best = key1; besti = lane + 64; }
+            if (a.mode == EAMRL_SAMPLE) {
+                const f32x2 k2 = d_expf2((f32x2){lpv[0], lpv[1]}) / (f32x2){nz0, nz1};
+                key0 = k2.x; key1 = k2.y;
+            }
+            float best = in0 ? key0 : -INFINITY;
+            int besti = in0 ? n0 : 0x7fffffff;
+            if (in1 && key1 > best) { best = key1; besti = n1; }
             wave_argmax(best, besti);
             int sel = besti;
+            if (a.dbg & 8) sel = t;
             if (a.mode == EAMRL_EVALUATE) sel = (int)given;
             sel = __builtin_amdgcn_readfirstlane(sel);
-            uint32_t fl = 0;
-            if (__ballot(nan_seen) != 0ull) fl |= EAMRL_ST_NAN_LOGITS;
-            if (sel < 0 || sel >= M) { fl |= EAMRL_ST_INFEASIBLE; sel = 0; }
-            else if (!l.msk[sel]) fl |= EAMRL_ST_INFEASIBLE;
+            if (__ballot(nan_seen) != 0ull) st_flags |= EAMRL_ST_NAN_LOGITS;
+            if (sel < 0 || sel >= M) { st_flags |= EAMRL_ST_INFEASIBLE; sel = 0; }
+            else if (!l.msk[sel]) st_flags |= EAMRL_ST_INFEASIBLE;
             const float lp_sel = __int_as_float(
                 (sel < 64) ? __builtin_amdgcn_readlane(__float_as_int(lpv[0]), sel)
                            : __builtin_amdgcn_readlane(__float_as_int(lpv[1]), sel - 64));
-            if (lane == 0) {
-                l.sel = sel;
-                l.flags = (int)fl;
-                a.action[r * a.t_max + t] = sel;
-                a.logp[r * a.t_max + t] = lp_sel;
+            if (lane == 0) {      // kept in LDS: a global store here would sit on every later vmcnt wait of the loop
+                l.act_out[t] = (int16_t)sel;
+                l.lp_out[t] = lp_sel;
             }
+            // ---- env transition (TSPEnv._step / CVRPEnv._step + get_action_mask) and the next context query ----
+            if (ENV == EAMRL_ENV_TSP) {
+                if (istep == 0) {
+                    first = sel;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) p1f[k] = a.Pa[(bi * M + first) * ld + lane + 64 * k];
+                }
+                cur = sel;
+                istep += 1;
+                count -= (l.msk[sel] != 0);
+                done = (count == 0);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) { l.msk[sel] = 0; l.done = done; }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) l.q[lane + 64 * k] = (p1f[k] + Plds[cur * RE + lane + 64 * k]) + gq[k];
+            } else {
+                const int N = M - 1;
+                int di = sel - 1;
+                di = di < 0 ? 0 : (di > N - 1 ? N - 1 : di);
+                used = (used + l.dem[di]) * (sel != 0 ? 1.0f : 0.0f);
+                cur = sel;
+                count += (l.vis[sel] == 0);
+                done = (count == M);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) { l.vis[sel] = 1; l.done = done; }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 2; ++k) l.q[lane + 64 * k] = fma_(cv[k], vcap - used, Plds[cur * RE + lane + 64 * k]) + gq[k];
+                const float lim = vcap + 1e-5f;
+                int free_n = 0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int nn = lane + 64 * k;
+                    if (nn >= 1 && nn < M) {
+                        const int blocked = (l.vis[nn] != 0) | ((mydem[k] + used) > lim);
+                        l.msk[nn] = !blocked;
+                        free_n |= !blocked;
+                    }
+                }
+                const bool any_free = __ballot(free_n) != 0ull;
+                if (lane == 0) l.msk[0] = !((cur == 0) && any_free);
+            }
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
-
-        // ---- S6: env transition + next query -----------------------------------------------------------------------------
-        const int act = l.sel;
-        st_flags |= (uint32_t)l.flags;
-        if (ENV == EAMRL_ENV_TSP) {
-            if (istep == 0) {
-                first = act;
-                if (tid < RE) p1f = a.Pa[(bi * M + first) * ld + tid];
-            }
-            cur = act;
-            istep += 1;
-            count -= (l.msk[act] != 0);
-            done = (count == 0);
-            __syncthreads();                       // everyone has read msk[act]
-            if (tid == 0) l.msk[act] = 0;
-            if (tid < RE) l.q[tid] = (p1f + Plds[cur * RE + tid]) + gq;
-            __syncthreads();
-        } else {
-            const int N = M - 1;
-            int di = act - 1;
-            di = di < 0 ? 0 : (di > N - 1 ? N - 1 : di);
-            used = (used + dem[di]) * (act != 0 ? 1.0f : 0.0f);
-            cur = act;
-            count += (l.vis[act] == 0);
-            done = (count == M);
-            __syncthreads();                       // everyone has read vis[act]
-            if (tid == 0) l.vis[act] = 1;
-            if (tid < RE) l.q[tid] = fma_(cv, vcap - used, Plds[cur * RE + tid]) + gq;
-            __syncthreads();
-            const float lim = vcap + 1e-5f;
-            int free_n = 0;
-            if (hs == 0 && n >= 1 && n < M) {
-                const int blocked = (l.vis[n] != 0) | ((my_dem + used) > lim);
-                l.msk[n] = !blocked;
-                free_n = !blocked;
-            }
-            const int any_free = __syncthreads_or(free_n);
-            if (tid == 0) l.msk[0] = !((cur == 0) && any_free);
-            __syncthreads();
-        }
+        done = l.done != 0;
         ++t;
     }
 
-    // ---- write back the final state -----------------------------------------------------------------------------------
+    // ---- write back the episode and the final state ---------------------------------------------------------------
     __syncthreads();
+    for (int i = tid; i < t; i += RB) {
+        a.action[r * a.t_max + i] = l.act_out[i];
+        a.logp[r * a.t_max + i] = l.lp_out[i];
+    }
     if (tid < M) {
         a.mask[r * M + tid] = l.msk[tid];
         if (ENV == EAMRL_ENV_CVRP) a.visited[r * M + tid] = l.vis[tid];
@@ -342,11 +370,11 @@ __global__ void k_rollout_pad_cvrp_res(DecArgs a)
     }
 }
 
-template <int ENV, int CP>
+template <int ENV, int CP, int CR>
 int launch_cp(const DecArgs& a, hipStream_t st)
 {
     const size_t lds = ((sizeof(ResLds<CP>) + 15) & ~size_t(15)) + (size_t)a.M * RE * sizeof(float);
-    auto k = k_rollout_resident<ENV, CP>;
+    auto k = k_rollout_resident<ENV, CP, CR>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return EAMRL_E_LAUNCH;
@@ -360,17 +388,20 @@ template <int ENV>
 int launch_env(const DecArgs& a, hipStream_t st)
 {
     const int C = (a.M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
-    if (C <= 8) return launch_cp<ENV, 8>(a, st);
-    if (C <= 16) return launch_cp<ENV, 16>(a, st);
-    if (C <= 28) return launch_cp<ENV, 28>(a, st);
-    return launch_cp<ENV, 32>(a, st);
+    if (a.t_max > 2 * RNP + 2) return EAMRL_E_ARG;
+    if (C <= 8) return launch_cp<ENV, 8, 8>(a, st);
+    if (C <= 16) return launch_cp<ENV, 16, 16>(a, st);
+    if (C <= 25) return launch_cp<ENV, 28, 25>(a, st);      // M <= 100
+    if (C <= 26) return launch_cp<ENV, 28, 26>(a, st);      // M <= 104 (CVRP-100: M = 101)
+    if (C <= 28) return launch_cp<ENV, 28, 28>(a, st);
+    return launch_cp<ENV, 32, 32>(a, st);
 }
 
 }  // namespace
 
 bool rollout_resident_supports(int env, const DecArgs& a)
 {
-    return a.E == RE && a.H == RH && a.M <= RNP && a.M >= 2 && a.ld % 4 == 0;
+    return a.E == RE && a.H == RH && a.M <= RNP && a.M >= 2 && a.ld % 4 == 0 && a.t_max <= 2 * RNP + 2;
 }
 
 int launch_rollout_resident(int env, const DecArgs& a, hipStream_t st)

@@ -52,6 +52,35 @@ def bench_mha(iters):
     print(f"mha_encoder B=1024 N=100: {us:8.1f} us")
 
 
+def bench_decode(iters, dbg, t_max=None):
+    """Resident rollout kernel alone at TSP-100 B=1024 with random cache contents (timing only)."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import _lib
+    from eam_rl4co_amd.policy import state_from_td
+
+    dev = "cuda"
+    B, M, E = 1024, 100, 128
+    env = ea.get_env("tsp", generator_params=dict(num_loc=M))
+    td0 = env.reset(batch_size=[B]).to(dev)
+    buf = torch.randn(B, M, 6 * E, device=dev) * 0.3
+    emb = torch.randn(B, M, E, device=dev)
+    cache = ops.DecodeCache("tsp", buf, torch.randn(E, device=dev), torch.randn(B, E, device=dev), emb, 8)
+    _lib.load().eamrl_debug_set(5, dbg)
+
+    states = [state_from_td("tsp", td0.clone(), 0) for _ in range(iters + 2)]
+    torch.cuda.synchronize()
+    times = []
+    for st in states:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        ops.rollout(st, cache, "greedy", t_max=t_max or M)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e3)
+    print(f"decode resident dbg={dbg:2d} t_max={t_max or M}: {sorted(times[2:])[len(times[2:]) // 2]:8.1f} us (median, events around ops.rollout)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
@@ -66,6 +95,9 @@ def main():
         bench_gemm(a.iters)
     if a.what in ("mha", "all"):
         bench_mha(a.iters)
+    if a.what in ("decode",):
+        for d, tm in ((0, None), (0, 1), (0, 11), (0, 51), (15, 1), (15, 51), (15, None)):
+            bench_decode(a.iters, d, tm)
 
 
 if __name__ == "__main__":
