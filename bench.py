@@ -49,6 +49,18 @@ def algorithmic_bytes_per_decode_step(env, M, E=128):
     return 12 * M * E + 4 * E * 1 + 2 * M + 32 + 2 * M
 
 
+def measured_traffic(workload, batch):
+    """HBM bytes per decode-loop launch from the committed PMC passes (profiles/r01_traffic.json): rocprofv3
+    counters cannot be collected from inside the timed run, so `traffic` is the separately profiled value for
+    exactly this workload, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)
+        return t.get(f"{workload}_b{batch}", {}).get("traffic_bytes")
+    except (OSError, ValueError):
+        return None
+
+
 def build_policy(env_name, device):
     import eam_rl4co_amd as ea
     from _util import golden_weights
@@ -178,7 +190,7 @@ def main():
                                    f"(encoder + cache + decode loop + reward)",
                        "decode_steps": T, "reward_mean": round(float(out["reward"].mean()), 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, batch),
                          "kernel": "decode loop (eamrl_am_rollout)", "kernel_ms": round(kern, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }

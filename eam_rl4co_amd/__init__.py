@@ -1,8 +1,9 @@
 """eam_rl4co_amd: MI355X-native construction rollout (TSP / CVRP + AttentionModel decode) behind the
 RL4CO interfaces of Tarseus/eam-rl4co.  See DESIGN.md."""
 from .envs import CVRPEnv, CVRPGenerator, RL4COEnvBase, TSPEnv, TSPGenerator, get_env  # noqa: F401
-from .policy import (AttentionModelDecoder, AttentionModelEncoder, AttentionModelPolicy, random_policy,  # noqa: F401
-                     rollout)
+from .policy import (AttentionModelDecoder, AttentionModelEncoder, AttentionModelPolicy,  # noqa: F401
+                     load_reference_checkpoint, random_policy, rollout)
 from .tensordict_lite import TensorDict  # noqa: F401
+from .utils import batchify, gather_by_index, unbatchify  # noqa: F401
 
 __version__ = "0.1.0"

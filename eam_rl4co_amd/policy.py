@@ -22,6 +22,7 @@ import torch.nn as nn
 from . import ops
 from .envs import RL4COEnvBase, get_env
 from .tensordict_lite import TensorDict  # noqa: F401
+from .utils import unbatchify, unbatchify_and_gather
 
 log = logging.getLogger(__name__)
 
@@ -454,8 +455,13 @@ class AttentionModelPolicy(nn.Module):
         logprobs = torch.cat(pre_logps + [lps[:, :T]], 1)
         td_out = state_to_td(self.env_name, st, td)
 
-        if S > 0 and select_best:
-            raise NotImplementedError("select_best is outside the MI355X rollout path (use unbatchify + max on reward)")
+        if S > 0 and select_best:   # DecodingStrategy._select_best (decoding.py:419-427)
+            rewards = env.get_reward(td_out, actions_out)
+            _, max_idxs = unbatchify(rewards, S).max(dim=-1)
+            actions_out = unbatchify_and_gather(actions_out, max_idxs, S)
+            logprobs = unbatchify_and_gather(logprobs, max_idxs, S)
+            td_out = TensorDict({k: unbatchify_and_gather(v, max_idxs, S) for k, v in td_out.items()},
+                                batch_size=[max_idxs.shape[0]])
 
         if calc_reward:
             td_out.set("reward", env.get_reward(td_out, actions_out))
@@ -499,6 +505,29 @@ class AttentionModelPolicy(nn.Module):
         lps = torch.stack(lps, 1) if lps else torch.zeros(R, 0, dtype=torch.float32, device=dev)
         alls = torch.stack(alls, 1) if alls else torch.zeros(R, 0, M, dtype=torch.float32, device=dev)
         return acts, lps, alls, t, int(status.item())
+
+
+def load_reference_checkpoint(policy: AttentionModelPolicy, ckpt, strict: bool = True):
+    """Load the policy weights of a reference Lightning checkpoint.
+
+    `ckpt` is a path (read with torch.load(weights_only=True): nothing from the file is executed), a Lightning
+    checkpoint dict (`{"state_dict": {...}}`) or a plain state_dict.  Keys of the LitModule carry the prefix
+    `policy.` (rl4co/models/rl/common/base.py); `baseline.*` entries (rollout-baseline copy of the policy,
+    reinforce.py:198-210) and anything else outside the policy are ignored."""
+    if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
+        ckpt = torch.load(ckpt, map_location="cpu", weights_only=True)
+    sd = ckpt.get("state_dict", ckpt) if isinstance(ckpt, dict) else ckpt
+    has_prefix = any(k.startswith("policy.") for k in sd)
+    own = {}
+    for k, v in sd.items():
+        if has_prefix:
+            if not k.startswith("policy."):
+                continue
+            k = k[len("policy."):]
+        elif k.startswith("baseline."):
+            continue
+        own[k] = v
+    return policy.load_state_dict(own, strict=strict)
 
 
 def rollout(env, td, policy, max_steps: int = None):

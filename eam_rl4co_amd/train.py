@@ -1,0 +1,193 @@
+"""Training companion of the native rollout: gradients by teacher-forced re-evaluation.
+
+The rollout itself (`AttentionModelPolicy.forward`) runs on the HIP kernels and produces no gradients.  For
+REINFORCE / POMO / EAM the log-likelihood of the *chosen* actions is what must be differentiated; because the
+actions are known after the rollout, every decode step's state (current / first node, visited set, used
+capacity) is a prefix function of the action sequence, so all T steps are re-evaluated AT ONCE as dense batched
+contractions with PyTorch autograd -- the same trick serves EAM's `policy(..., actions=improved)` pass
+(rl4co/models/zoo/earl/model.py:179-195).  This module is the gradient path only: it is not used by inference,
+benchmarks or parity tests of the rollout, and its forward values are checked against the native log-probs
+(tests/test_gpu_train.py, tolerance 1e-4).
+
+Reference call sites: rl4co/models/rl/reinforce/reinforce.py:59-106 (REINFORCE.shared_step / calculate_loss),
+rl4co/models/rl/reinforce/baselines.py:57-61 (SharedBaseline), rl4co/models/zoo/pomo/model.py:89-148.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .utils import unbatchify
+
+
+# ------------------------------------------------------------------------------------------------------------
+# differentiable encoder + cache (same parameters as the native path)
+# ------------------------------------------------------------------------------------------------------------
+def _normalize(norm: nn.Module, x: torch.Tensor, training: bool) -> torch.Tensor:
+    n = norm.normalizer
+    if isinstance(n, nn.BatchNorm1d):   # batch statistics when training, as the reference (nn/ops.py:45-47)
+        y = F.batch_norm(x.reshape(-1, x.size(-1)), n.running_mean, n.running_var, n.weight, n.bias, training,
+                         n.momentum if n.momentum is not None else 0.1, n.eps)
+        return y.view_as(x)
+    return F.instance_norm(x.permute(0, 2, 1), weight=n.weight, bias=n.bias, eps=n.eps).permute(0, 2, 1)
+
+
+def encode_autograd(policy, td):
+    enc = policy.encoder
+    ie = enc.init_embedding
+    locs = td["locs"]
+    if policy.env_name == "tsp":
+        h = F.linear(locs, ie.init_embed.weight, ie.init_embed.bias)
+    else:
+        depot = F.linear(locs[:, :1], ie.init_embed_depot.weight, ie.init_embed_depot.bias)
+        feat = torch.cat((locs[:, 1:], td["demand"][..., None]), -1)
+        h = torch.cat((depot, F.linear(feat, ie.init_embed.weight, ie.init_embed.bias)), 1)
+    training = policy.training
+    for layer in enc.net.layers:
+        mha, ffn = layer[0].module, layer[2].module
+        B, N, E = h.shape
+        H = mha.num_heads
+        qkv = F.linear(h, mha.Wqkv.weight, mha.Wqkv.bias).view(B, N, 3, H, E // H).permute(2, 0, 3, 1, 4)
+        att = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).permute(0, 2, 1, 3).reshape(B, N, E)
+        h = _normalize(layer[1], h + F.linear(att, mha.out_proj.weight, mha.out_proj.bias), training)
+        x = h
+        for lin in ffn.lins[:-1]:
+            x = F.relu(F.linear(x, lin.weight, lin.bias))
+        h = _normalize(layer[3], h + F.linear(x, ffn.lins[-1].weight, ffn.lins[-1].bias), training)
+    return h
+
+
+# ------------------------------------------------------------------------------------------------------------
+# per-step states from the action sequence
+# ------------------------------------------------------------------------------------------------------------
+def _tsp_states(actions, M, multistart):
+    """-> first [R,T], cur [R,T], step0 [T] bool (placeholder context), mask [R,T,M] (True = feasible)."""
+    R, T = actions.shape
+    onehot = F.one_hot(actions, M).to(torch.int32)
+    visited_before = torch.cumsum(onehot, 1) - onehot          # exclusive prefix
+    cur = torch.cat((actions[:, :1], actions[:, :-1]), 1)       # a_{t-1}; column 0 unused at the placeholder step
+    first = actions[:, :1].expand(R, T)
+    return first, cur, visited_before == 0
+
+
+def _cvrp_states(actions, demand_rows, vcap, M):
+    """-> cur [R,T], remaining capacity [R,T] before each step, mask [R,T,M] (cvrp/env.py:68-100,132-144)."""
+    R, T = actions.shape
+    N = M - 1
+    dev = actions.device
+    visited = torch.zeros(R, M, dtype=torch.bool, device=dev)
+    used = torch.zeros(R, dtype=torch.float32, device=dev)
+    cur = torch.zeros(R, dtype=torch.int64, device=dev)
+    lim = vcap + 1e-5
+    curs, rems, masks = [], [], []
+    ar = torch.arange(R, device=dev)
+    for t in range(T):
+        blocked = visited[:, 1:] | ((demand_rows + used[:, None]) > lim[:, None])
+        depot_blocked = (cur == 0) & (~blocked).any(-1)
+        masks.append(~torch.cat((depot_blocked[:, None], blocked), 1))
+        curs.append(cur)
+        rems.append(vcap - used)
+        a = actions[:, t]
+        d = demand_rows[ar, (a - 1).clamp(0, N - 1)]
+        used = (used + d) * (a != 0).float()
+        visited = visited.clone()
+        visited[ar, a] = True
+        cur = a
+    return torch.stack(curs, 1), torch.stack(rems, 1), torch.stack(masks, 1)
+
+
+# ------------------------------------------------------------------------------------------------------------
+def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, temperature=None, tanh_clipping=None,
+                            chunk_rows: int = 4096):
+    """Differentiable per-step log-probabilities of `actions` [R, T] (R = B or S*B rows in (s b) order; for
+    multistart the first column is the start node and gets log-prob 0).  Returns logp [R, T]."""
+    temperature = policy.temperature if temperature is None else temperature
+    clip = policy.tanh_clipping if tanh_clipping is None else tanh_clipping
+    dec = policy.decoder
+    E, H = dec.embed_dim, dec.num_heads
+    D = E // H
+    emb = encode_autograd(policy, td)
+    B, M, _ = emb.shape
+    kvl = F.linear(emb, dec.project_node_embeddings.weight)
+    K, V, L = kvl.chunk(3, dim=-1)
+    gctx = F.linear(emb.mean(1), dec.project_fixed_context.weight) if dec.use_graph_context else None
+    Wctx = dec.context_embedding.project_context.weight
+    R, T = actions.shape
+    S = max(int(num_starts), 1)
+    assert R == S * B
+    multistart = S > 1
+    out = []
+    # rows are processed in chunks of whole start-groups so that memory stays bounded ([rows, H, T, M] scores)
+    starts_per_chunk = max(1, chunk_rows // B)
+    for s0 in range(0, S, starts_per_chunk):
+        s1 = min(S, s0 + starts_per_chunk)
+        rows = slice(s0 * B, s1 * B)
+        act = actions[rows]
+        nrep = s1 - s0
+        rep = lambda x: x.repeat(nrep, *([1] * (x.dim() - 1)))   # (s b) order: instance index = row % B
+        embr, Kr, Vr, Lr = rep(emb), rep(K), rep(V), rep(L)
+        Rc = act.shape[0]
+        ar = torch.arange(Rc, device=act.device)[:, None]
+        if policy.env_name == "tsp":
+            first, cur, mask = _tsp_states(act, M, multistart)
+            ctx_in = torch.cat((embr[ar, first], embr[ar, cur]), -1)                       # [Rc, T, 2E]
+            if not multistart:   # step 0 uses the learned placeholder (context.py:118-131)
+                ctx_in = torch.cat((dec.context_embedding.W_placeholder.expand(Rc, 1, 2 * E), ctx_in[:, 1:]), 1)
+        else:
+            cur, rem, mask = _cvrp_states(act, rep(td["demand"]), rep(td["vehicle_capacity"].reshape(-1)), M)
+            ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)                          # [Rc, T, E+1]
+        q = F.linear(ctx_in, Wctx)
+        if gctx is not None:
+            q = q + rep(gctx)[:, None, :]
+        qh = q.view(Rc, T, H, D).permute(0, 2, 1, 3)
+        kh = Kr.view(Rc, M, H, D).permute(0, 2, 1, 3)
+        vh = Vr.view(Rc, M, H, D).permute(0, 2, 1, 3)
+        heads = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=mask[:, None])         # [Rc, H, T, D]
+        glimpse = F.linear(heads.permute(0, 2, 1, 3).reshape(Rc, T, E), dec.pointer.project_out.weight)
+        logits = torch.bmm(glimpse, Lr.transpose(1, 2)) / math.sqrt(E)
+        if clip > 0:
+            logits = torch.tanh(logits) * clip
+        logits = logits.masked_fill(~mask, float("-inf")) / temperature
+        logp = F.log_softmax(logits, dim=-1).gather(-1, act[..., None]).squeeze(-1)
+        if multistart:   # the start node is not a decision (decoding.py:318-324)
+            logp = torch.cat((torch.zeros_like(logp[:, :1]), logp[:, 1:]), 1)
+            # steps t >= 1 were evaluated with the state after the start action: column t uses prefix a_{<t} as built
+        out.append(logp)
+    return torch.cat(out, 0)
+
+
+def reinforce_loss(policy, env, td, baseline: str = "shared", num_starts: int = 0, decode_type: str = None,
+                   **rollout_kwargs):
+    """One REINFORCE forward: native sampled rollout (no grad) -> differentiable log-likelihood -> loss.
+
+    baseline: "shared" (POMO: mean over the starts of an instance, needs num_starts > 1), "mean" (batch mean) or
+    "no".  Returns dict(loss, reward, log_likelihood, actions).  loss = -((reward - bl) * ll).mean()
+    (reinforce.py:103-106)."""
+    if decode_type is None:
+        decode_type = "multistart_sampling" if num_starts > 1 else "sampling"
+    kw = dict(rollout_kwargs)
+    if num_starts > 1:
+        kw["num_starts"] = num_starts
+    was_training = policy.training
+    policy.eval()            # the native rollout uses running statistics
+    with torch.no_grad():
+        out = policy(td, env, phase="train", decode_type=decode_type, **kw)
+    policy.train(was_training)
+    actions, reward = out["actions"], out["reward"]
+    # finished CVRP rows are padded with depot visits of probability 1: their log-prob is 0 and carries no gradient
+    logp = evaluate_log_likelihood(policy, td, env, actions, num_starts=num_starts)
+    ll = logp.sum(1)
+    if baseline == "shared":
+        assert num_starts > 1, "shared baseline needs multistart"
+        r = unbatchify(reward, num_starts)
+        adv = (r - r.mean(1, keepdim=True))
+        loss = -(adv * unbatchify(ll, num_starts)).mean()
+    elif baseline == "mean":
+        loss = -((reward - reward.mean()) * ll).mean()
+    else:
+        loss = -(reward * ll).mean()
+    return {"loss": loss, "reward": reward, "log_likelihood": ll, "actions": actions, "logp_steps": logp,
+            "native_log_likelihood": out["log_likelihood"]}

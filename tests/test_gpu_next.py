@@ -1,0 +1,181 @@
+"""GPU: the "next" rows of SURVEY.md 8f built on the native path -- evaluation harness (N2), checkpoint
+loading (N1), gradient path by teacher-forced re-evaluation (N3) -- plus rollout edge cases."""
+import numpy as np
+import pytest
+import torch
+
+from _util import golden, golden_weights
+from test_gpu_parity import DEV, assert_bits_equal, make_policy, make_td, t
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------------------------------------------------
+# edge cases of the rollout kernels (resident <-> streaming boundary, tiny instances, options)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("env_name,N,B", [("tsp", 2, 3), ("tsp", 5, 1), ("cvrp", 3, 2), ("tsp", 64, 5), ("tsp", 65, 5),
+                                          ("tsp", 128, 4), ("tsp", 129, 4), ("cvrp", 127, 3), ("cvrp", 128, 3),
+                                          ("cvrp", 50, 7)])
+@pytest.mark.parametrize("mode", ["greedy", "sampling"])
+def test_rollout_shapes_and_kernel_boundaries(oracle, env_name, N, B, mode):
+    """M = 2 .. 129: every register-resident instantiation and the streaming kernel against the oracle."""
+    import eam_rl4co_amd as ea
+
+    cfg = "am_" + env_name
+    pol = make_policy(cfg)
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=N)
+    torch.manual_seed(100 + N)
+    td_cpu = env.reset(batch_size=[B])
+    locs = td_cpu["locs"].numpy()
+    demand = td_cpu["demand"].numpy() if env_name == "cvrp" else None
+    M = locs.shape[1]
+    kw, noise = {}, None
+    if mode == "sampling":
+        noise = torch.empty(B, 2 * M + 1, M).exponential_(1, generator=torch.Generator().manual_seed(N))
+        kw["noise"] = noise.to(DEV)
+    out = pol(td_cpu.to(DEV), env, phase="test", decode_type=mode, return_sum_log_likelihood=False, **kw)
+    o = oracle.policy_rollout(golden_weights(cfg), env_name, locs, demand, decode_type=mode,
+                              noise=None if noise is None else noise.numpy())
+    assert_bits_equal(out["actions"], o["actions"], "tours")
+    assert_bits_equal(out["log_likelihood"], o["logp_steps"], "logp")
+    assert_bits_equal(out["reward"], o["reward"], "reward")
+
+
+@pytest.mark.parametrize("clip,temp", [(0.0, 1.0), (10.0, 0.7), (5.0, 2.5)])
+def test_temperature_and_clipping_options(oracle, clip, temp):
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import _lib
+
+    fx = golden("cvrp20_greedy")
+    sd = golden_weights("am_cvrp")
+    for stream in (0, 1):
+        pol = make_policy("am_cvrp")
+        env, td = make_td("cvrp", fx["locs"], fx["demand"])
+        _lib.load().eamrl_debug_set(1, stream)
+        try:
+            out = pol(td, env, phase="test", decode_type="greedy", tanh_clipping=clip, temperature=temp,
+                      return_sum_log_likelihood=False)
+        finally:
+            _lib.load().eamrl_debug_set(1, 0)
+        o = oracle.policy_rollout(sd, "cvrp", fx["locs"], fx["demand"], decode_type="greedy", clip=clip, temp=temp)
+        assert_bits_equal(out["actions"], o["actions"], "tours")
+        assert_bits_equal(out["log_likelihood"], o["logp_steps"], "logp")
+
+
+def test_max_steps_overrun_is_reported_not_fatal(caplog):
+    fx = golden("tsp20_greedy")
+    pol = make_policy("am_tsp")
+    env, td = make_td("tsp", fx["locs"])
+    with caplog.at_level("ERROR"):
+        out = pol(td, env, phase="test", decode_type="greedy", max_steps=7, calc_reward=False)
+    assert out["actions"].shape[1] == 7
+    assert any("Exceeded maximum number of steps" in r.message for r in caplog.records)
+
+
+def test_multistart_sampling_cvrp_and_select_best(oracle):
+    import eam_rl4co_amd as ea
+
+    fx = golden("cvrp20_greedy")
+    pol = make_policy("am_cvrp")
+    env, td = make_td("cvrp", fx["locs"], fx["demand"])
+    B, M = fx["locs"].shape[:2]
+    S = 6
+    noise = torch.empty(B * S, 2 * M + 1, M).exponential_(1, generator=torch.Generator().manual_seed(3))
+    out = pol(td.clone(), env, phase="test", decode_type="multistart_sampling", num_starts=S, noise=noise.to(DEV),
+              return_sum_log_likelihood=False)
+    o = oracle.policy_rollout(golden_weights("am_cvrp"), "cvrp", fx["locs"], fx["demand"],
+                              decode_type="multistart_sampling", num_starts=S, noise=noise.numpy())
+    assert_bits_equal(out["actions"], o["actions"], "tours")
+    assert_bits_equal(out["reward"], o["reward"], "reward")
+    best = pol(td.clone(), env, phase="test", decode_type="multistart_sampling", num_starts=S, noise=noise.to(DEV),
+               select_best=True)
+    r = ea.unbatchify(out["reward"], S)
+    assert torch.equal(best["reward"], r.max(1).values) and best["actions"].shape[0] == B
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N2: evaluation harness
+# ---------------------------------------------------------------------------------------------------------
+def test_evaluators_improve_monotonically():
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd.eval import evaluate_policy
+
+    env = ea.get_env("tsp", generator_params=dict(num_loc=20), seed=11)
+    pol = make_policy("am_tsp")
+    ds = env.dataset(batch_size=[6], phase="test")
+    res = {m: evaluate_policy(env, pol, ds, method=m, samples=8) for m in
+           ("greedy", "multistart_greedy", "augment_dihedral_8", "multistart_greedy_augment_dihedral_8", "sampling")}
+    for m, r in res.items():
+        assert r["rewards"].shape == (6,) and r["actions"].shape[0] == 6, m   # tests/test_tasks.py:62-70 shape contract
+    g = res["greedy"]["rewards"]
+    assert (res["multistart_greedy"]["rewards"] >= g - 1e-6).all()            # start node 0 reproduces ... a superset
+    assert (res["augment_dihedral_8"]["rewards"] >= g - 1e-6).all()           # identity augmentation comes first
+    assert (res["multistart_greedy_augment_dihedral_8"]["rewards"] >= res["multistart_greedy"]["rewards"] - 1e-6).all()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N1: reference checkpoints
+# ---------------------------------------------------------------------------------------------------------
+def test_reference_lightning_checkpoint_loads(tmp_path):
+    import eam_rl4co_amd as ea
+
+    src = make_policy("am_cvrp")
+    ckpt = {"state_dict": {**{"policy." + k: v.cpu() for k, v in src.state_dict().items()},
+                           **{"baseline.baseline.policy." + k: v.cpu() for k, v in src.state_dict().items()},
+                           "baseline.baseline.mean": torch.tensor(0.0)},
+            "epoch": 3, "global_step": 100}
+    path = tmp_path / "last.ckpt"
+    torch.save(ckpt, path)
+    dst = ea.AttentionModelPolicy(env_name="cvrp").eval()
+    ea.load_reference_checkpoint(dst, str(path))
+    dst = dst.to(DEV)
+    fx = golden("cvrp20_greedy")
+    env, td = make_td("cvrp", fx["locs"], fx["demand"])
+    out = dst(td, env, phase="test", decode_type="greedy")
+    assert_bits_equal(out["actions"], fx["actions"], "tours from the loaded checkpoint")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N3: gradients by teacher-forced re-evaluation
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,cfg", [("tsp20_sampling", "am_tsp"), ("cvrp20_sampling", "am_cvrp"),
+                                      ("pomo_tsp20_multistart_sampling", "pomo_tsp")])
+def test_reevaluation_matches_native_logp_and_reference(name, cfg):
+    """evaluate_log_likelihood (autograd, all steps at once) == native per-step log-probs (atol 1e-4) == reference."""
+    from eam_rl4co_amd.train import evaluate_log_likelihood
+
+    fx = golden(name)
+    pol = make_policy(cfg)
+    env_name = str(fx["env_name"])
+    env, td = make_td(env_name, fx["locs"], fx.get("demand"))
+    ns = int(fx["num_starts"])
+    logp = evaluate_log_likelihood(pol, td, env, t(fx["actions"]), num_starts=ns)
+    assert logp.requires_grad
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), fx["logp_steps"], rtol=0, atol=1e-4)
+
+
+def test_reinforce_step_pomo_and_flat_allreduce():
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd.dist import allreduce_gradients
+    from eam_rl4co_amd.train import reinforce_loss
+
+    torch.manual_seed(0)
+    env = ea.get_env("tsp", generator_params=dict(num_loc=20), seed=5)
+    pol = ea.AttentionModelPolicy(env_name="tsp", num_encoder_layers=2, normalization="instance",
+                                  use_graph_context=False).to(DEV)
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-3)
+    td = env.reset(batch_size=[16]).to(DEV)
+    first = None
+    for it in range(3):
+        out = reinforce_loss(pol, env, td.clone(), baseline="shared", num_starts=20)
+        np.testing.assert_allclose(out["log_likelihood"].detach().cpu().numpy(),
+                                   out["native_log_likelihood"].cpu().numpy(), rtol=0, atol=2e-3)
+        opt.zero_grad()
+        out["loss"].backward()
+        n = allreduce_gradients(pol)          # single process: identity, exercises the flat-buffer path
+        assert n == sum(p.numel() for p in pol.parameters())
+        gnorm = torch.nn.utils.clip_grad_norm_(pol.parameters(), 1.0)
+        assert torch.isfinite(gnorm) and gnorm > 0
+        opt.step()
+        first = out["reward"].mean().item() if first is None else first
+    assert np.isfinite(first)
