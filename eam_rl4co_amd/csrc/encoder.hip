@@ -362,7 +362,7 @@ int launch_linear(const GemmArgs& g0, hipStream_t st)
     if (g.in_dim <= 4) {
         const int64_t n = g.rows * g.out_dim;
         hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
-    } else if (!force_valu && g.rows * g.out_dim <= 262144) {
+    } else if (!force_valu && g.rows * g.out_dim <= 16384) {
         const int64_t n = g.rows * g.out_dim;
         hipLaunchKernelGGL(k_thin_linear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
     } else if (force_valu || (g.in_dim % GK) || (g.ldx & 3) || ((uintptr_t)g.x & 15) || (g.ldw & 3) ||
@@ -605,7 +605,15 @@ __global__ void k_mean_nodes(const float* emb, float* out, int M, int E)
     const float* xb = emb + (int64_t)blockIdx.x * M * E;
     for (int e = threadIdx.x; e < E; e += blockDim.x) {
         float s = 0.0f;
-        for (int n = 0; n < M; ++n) s = s + xb[(int64_t)n * E + e];
+        int n = 0;
+        for (; n + 8 <= M; n += 8) {            // 8 loads in flight, added in node order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = xb[(int64_t)(n + u) * E + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = s + v[u];
+        }
+        for (; n < M; ++n) s = s + xb[(int64_t)n * E + e];
         out[(int64_t)blockIdx.x * E + e] = s / (float)M;
     }
 }

@@ -222,21 +222,36 @@ class AttentionModelDecoder(nn.Module):
         slots = ops.slot_map(self.env_name)
         buf = torch.empty(B, M, len(slots) * E, device=emb.device, dtype=torch.float32)
         flat = buf.view(B * M, -1)
-        Wctx = self.context_embedding.project_context.weight
+        Wa, Wb, cvec = self._weight_constants()
         ops.linear(emb, self.project_node_embeddings.weight, out=flat[:, 0:3 * E])
-        # (weight slices are made contiguous so that the GEMM fetches them as aligned float4 rows)
-        ops.linear(emb, Wctx[:, 0:E].contiguous(), out=flat[:, slots["Pa"] * E:(slots["Pa"] + 1) * E])
+        ops.linear(emb, Wa, out=flat[:, slots["Pa"] * E:(slots["Pa"] + 1) * E])
         if self.env_name == "tsp":
-            ops.linear(emb, Wctx[:, E:2 * E].contiguous(), out=flat[:, slots["Pb"] * E:(slots["Pb"] + 1) * E])
-            cvec = ops.linear(self.context_embedding.W_placeholder[None, :], Wctx)[0]
-        else:
-            cvec = Wctx[:, E].contiguous()
+            ops.linear(emb, Wb, out=flat[:, slots["Pb"] * E:(slots["Pb"] + 1) * E])
         ops.matmul_right(flat[:, slots["L"] * E:(slots["L"] + 1) * E], self.pointer.project_out.weight.contiguous(),
                          out=flat[:, slots["Lp"] * E:(slots["Lp"] + 1) * E])
         gctx = None
         if self.use_graph_context:
             gctx = ops.linear(ops.mean_nodes(emb), self.project_fixed_context.weight)
         return ops.DecodeCache(self.env_name, buf, cvec.contiguous(), gctx, emb, self.num_heads)
+
+    def _weight_constants(self):
+        """Tensors that depend on the weights only, recomputed when a parameter changes (optimizer step, load):
+        the two halves of project_context as contiguous matrices (aligned float4 rows for the GEMM) and the
+        constant part of the query (TSP: project_context(W_placeholder); CVRP: the capacity column)."""
+        E = self.embed_dim
+        Wctx = self.context_embedding.project_context.weight
+        ph = getattr(self.context_embedding, "W_placeholder", None)
+        key = (Wctx.data_ptr(), Wctx._version, None if ph is None else (ph.data_ptr(), ph._version))
+        if getattr(self, "_wc_key", None) != key:
+            Wa = Wctx[:, 0:E].contiguous()
+            if self.env_name == "tsp":
+                Wb = Wctx[:, E:2 * E].contiguous()
+                cvec = ops.linear(ph[None, :].detach(), Wctx.detach())[0].contiguous()
+            else:
+                Wb = None
+                cvec = Wctx[:, E].contiguous()
+            self._wc, self._wc_key = (Wa.detach(), None if Wb is None else Wb.detach(), cvec.detach()), key
+        return self._wc
 
     def pre_decoder_hook(self, td, env, embeddings, num_starts: int = 0):
         return td, env, self._precompute_cache(embeddings, num_starts=num_starts)
@@ -356,7 +371,15 @@ class AttentionModelPolicy(nn.Module):
                 return_init_embeds: bool = False, return_sum_log_likelihood: bool = True, actions=None,
                 max_steps=1_000_000, **decoding_kwargs) -> dict:
         """The construction rollout (constructive/base.py:157-275): encode once, precompute the cache, run the
-        whole decode loop on the device, compute reward and log-likelihood.  Gradients are not produced here."""
+        whole decode loop on the device, compute reward and log-likelihood.  Gradients are not produced here.
+        Two halves: `_enqueue` launches every kernel without touching the host (it can be captured into a HIP
+        graph, see GraphedRollout), `_finish` performs the rollout's single device->host sync and slices."""
+        return self._finish(self._enqueue(td, env, phase, calc_reward, return_actions, return_entropy, return_hidden,
+                                          return_init_embeds, return_sum_log_likelihood, actions, max_steps,
+                                          **decoding_kwargs))
+
+    def _enqueue(self, td, env, phase, calc_reward, return_actions, return_entropy, return_hidden, return_init_embeds,
+                 return_sum_log_likelihood, actions, max_steps, **decoding_kwargs) -> dict:
         if isinstance(env, str) or env is None:
             env = get_env(self.env_name if env is None else env)
         if env.name != self.env_name:
@@ -427,8 +450,9 @@ class AttentionModelPolicy(nn.Module):
 
         # main decoding loop: one launch
         M = st.M
-        t_max = M if self.env_name == "tsp" else 2 * M + 1
-        t_max = int(min(t_max, max_steps))
+        # TSP: one step per remaining node; CVRP: every customer visit is followed by at most one depot visit
+        t_max = (M - len(pre_actions)) if self.env_name == "tsp" else 2 * M + 1
+        t_max = int(max(1, min(t_max, max_steps)))
         given = None
         if actions is not None:
             given = actions.to(torch.int64).contiguous()
@@ -437,25 +461,65 @@ class AttentionModelPolicy(nn.Module):
             if noise is None:
                 noise = torch.empty(st.R, t_max, M, dtype=torch.float32, device=st.mask.device).exponential_(1)
             else:
-                noise = noise.to(device=st.mask.device, dtype=torch.float32).contiguous()
+                noise = noise.to(device=st.mask.device, dtype=torch.float32)
+                if noise.dim() != 3 or noise.shape[0] != st.R or noise.shape[2] != M:
+                    raise ValueError(f"noise must be [R={st.R}, T, M={M}], got {tuple(noise.shape)}")
+                t_max = min(t_max, noise.shape[1])        # a shorter noise tensor bounds the episode length
+                noise = noise[:, :t_max].contiguous()     # the kernel strides rows by t_max * M
         all_logp = None
+        dev = st.mask.device
         if store_all_logp:
             acts, lps, all_logp, T, status = self._rollout_stepwise(st, cache, mode, noise, given, tanh_clipping,
                                                                     temperature, t_max)
+            info = None
         else:
             acts, lps, info = ops.rollout(st, cache, mode, noise=noise, given=given, clip=tanh_clipping,
                                           temp=temperature, t_max=t_max)
-            T, status = info.tolist()   # the rollout's single device->host sync
+        # Everything below is enqueued on the PADDED [R, t_max] arrays before the rollout's single host sync:
+        # padding is depot visits with log-prob 0, which change neither the tour length (zero-length legs, and
+        # x + 0 is exact in the lane tree), nor the log-likelihood sum, nor validity.
+        actions_pad = torch.cat(pre_actions + [acts], 1) if pre_actions else acts
+        logp_pad = torch.cat(pre_logps + [lps], 1) if pre_logps else lps
+        native_env = type(env).__name__ in ("TSPEnv", "CVRPEnv") and type(env).__module__ == RL4COEnvBase.__module__
+        fast = info is not None and native_env and not select_best
+        reward_pad = ll_pad = bad = None
+        if fast:
+            locs = td["locs"].contiguous()
+            if calc_reward:
+                reward_pad = ops.tour_length_reward(locs, actions_pad, with_depot=(self.env_name == "cvrp"))
+                if env.check_solution:
+                    bad = (ops.check_solution("tsp", actions_pad) if self.env_name == "tsp" else
+                           ops.check_solution("cvrp", actions_pad, td["demand"].contiguous(), st.vcap))
+            if return_sum_log_likelihood and "mask" not in td.keys():
+                ll_pad = ops.sum_logp(logp_pad)
+        flags = None
+        if info is not None:
+            flags = torch.cat((info, bad)) if bad is not None else info
+        else:
+            flags = torch.tensor([T, status], dtype=torch.int32)
+        return dict(flags=flags, has_bad=bad is not None, pre=1 if pre_actions else 0, t_max=t_max, M=M, S=S,
+                    select_best=select_best, calc_reward=calc_reward, env=env, st=st, td=td, cache=cache,
+                    actions_pad=actions_pad, logp_pad=logp_pad, reward_pad=reward_pad, ll_pad=ll_pad,
+                    all_logp=all_logp, init_embeds=init_embeds, return_actions=return_actions,
+                    return_entropy=return_entropy, return_hidden=return_hidden, return_init_embeds=return_init_embeds,
+                    return_sum_log_likelihood=return_sum_log_likelihood)
+
+    def _finish(self, p: dict) -> dict:
+        vals = p["flags"].tolist()               # the rollout's single device->host sync
+        T, status = vals[0], vals[1]
+        bad_counts = vals[2:] if p["has_bad"] else None
+        env, st, td, S, M = p["env"], p["st"], p["td"], p["S"], p["M"]
         ops.raise_on_status(status)
         if status & ops.ST_STEP_OVERRUN:
-            log.error("Exceeded maximum number of steps (%d) during decoding", t_max)
-        assert T > 0 or pre_actions, \
+            log.error("Exceeded maximum number of steps (%d) during decoding", p["t_max"])
+        npre = p["pre"]
+        assert T > 0 or npre, \
             "No logprobs were collected because all environments were done. Check your initial state"
-        actions_out = torch.cat(pre_actions + [acts[:, :T]], 1)
-        logprobs = torch.cat(pre_logps + [lps[:, :T]], 1)
+        actions_out = p["actions_pad"][:, :npre + T]
+        logprobs = p["logp_pad"][:, :npre + T]
         td_out = state_to_td(self.env_name, st, td)
 
-        if S > 0 and select_best:   # DecodingStrategy._select_best (decoding.py:419-427)
+        if S > 0 and p["select_best"]:   # DecodingStrategy._select_best (decoding.py:419-427)
             rewards = env.get_reward(td_out, actions_out)
             _, max_idxs = unbatchify(rewards, S).max(dim=-1)
             actions_out = unbatchify_and_gather(actions_out, max_idxs, S)
@@ -463,23 +527,40 @@ class AttentionModelPolicy(nn.Module):
             td_out = TensorDict({k: unbatchify_and_gather(v, max_idxs, S) for k, v in td_out.items()},
                                 batch_size=[max_idxs.shape[0]])
 
-        if calc_reward:
-            td_out.set("reward", env.get_reward(td_out, actions_out))
+        if p["calc_reward"]:
+            if p["reward_pad"] is not None:
+                if bad_counts is not None:
+                    if self.env_name == "tsp" and npre + T != p["actions_pad"].shape[1]:
+                        # node 0 is a real city in TSP, so zero padding cannot be checked in place: the (rare)
+                        # short episode is re-checked on the exact slice
+                        env.check_solution_validity(td_out, actions_out.contiguous())
+                    else:
+                        assert bad_counts[0] == 0, "Invalid tour"
+                        assert bad_counts[1] == 0, "Used more than capacity"
+                if self.env_name == "tsp" and npre + T != p["actions_pad"].shape[1]:
+                    td_out.set("reward", env.get_reward(td_out, actions_out.contiguous(), check_solution=False))
+                else:
+                    td_out.set("reward", p["reward_pad"])
+            else:
+                td_out.set("reward", env.get_reward(td_out, actions_out.contiguous()))
         td_mask = td_out.get("mask", None)
         if td_mask is not None:
             logprobs = logprobs.masked_fill(~td_mask, 0)
         # get_log_likelihood (decoding.py:38-64); -inf would mean an infeasible action slipped through
-        ll = ops.sum_logp(logprobs) if return_sum_log_likelihood else logprobs
+        if p["return_sum_log_likelihood"]:
+            ll = p["ll_pad"] if p["ll_pad"] is not None else ops.sum_logp(logprobs)
+        else:
+            ll = logprobs
         out = {"reward": td_out["reward"], "log_likelihood": ll}
-        if return_actions:
+        if p["return_actions"]:
             out["actions"] = actions_out
-        if return_entropy:
-            lp = torch.nan_to_num(all_logp, nan=0.0, neginf=0.0)
+        if p["return_entropy"]:
+            lp = torch.nan_to_num(p["all_logp"], nan=0.0, neginf=0.0)
             out["entropy"] = -(lp.exp() * lp).sum(-1).sum(1)
-        if return_hidden:
-            out["hidden"] = cache
-        if return_init_embeds:
-            out["init_embeds"] = init_embeds
+        if p["return_hidden"]:
+            out["hidden"] = p["cache"]
+        if p["return_init_embeds"]:
+            out["init_embeds"] = p["init_embeds"]
         self._last_td = td_out   # final env state of the last rollout (the reference keeps it in a local)
         return out
 
@@ -550,3 +631,47 @@ def random_policy(td):
     """Uniform choice among feasible actions (utils/decoding.py:80-84)."""
     td.set("action", torch.multinomial(td["action_mask"].float(), 1).squeeze(-1))
     return td
+
+
+class GraphedRollout:
+    """`policy(td, env, **kwargs)` for a fixed batch shape, captured once into a HIP graph and replayed.
+
+    A rollout is ~45 short launches (encoder GEMMs, attention, cache, the decode loop, reward); replaying them as
+    one graph removes the per-launch host cost, which dominates small problems (TSP-20) and is ~8 % at TSP-100
+    B=1024.  Only the device half of `forward` (`_enqueue`) is captured; the single host sync and the output
+    slicing (`_finish`) run after every replay.  Outputs are copies, so they stay valid across replays.
+    Not capturable: return_entropy / store_all_logp (host-driven step loop) and select_best.
+    """
+
+    def __init__(self, policy: AttentionModelPolicy, env: RL4COEnvBase, td_example, warmup: int = 2, phase="test",
+                 **forward_kwargs):
+        if forward_kwargs.get("return_entropy") or forward_kwargs.get("store_all_logp") or forward_kwargs.get("select_best"):
+            raise NotImplementedError("GraphedRollout: step-wise / select_best rollouts are not capturable")
+        self.policy, self.env = policy, env
+        self.kw = dict(phase=phase, calc_reward=True, return_actions=True, return_entropy=False, return_hidden=False,
+                       return_init_embeds=False, return_sum_log_likelihood=True, actions=None, max_steps=1_000_000)
+        self.kw.update(forward_kwargs)
+        self.static_td = td_example.clone()
+        self._keys = [k for k, v in self.static_td.items() if isinstance(v, torch.Tensor)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(max(1, warmup)):      # sets kernel attributes, fills caches, warms the allocator
+                policy._finish(policy._enqueue(self.static_td.clone(), env, **self.kw))
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self._work = self.static_td.clone()          # the rollout updates its state tensors in place
+            self._pending = policy._enqueue(self._work, env, **self.kw)
+
+    @torch.no_grad()
+    def __call__(self, td) -> dict:
+        for k in self._keys:
+            src = td[k]
+            dst = self.static_td[k]
+            if src.shape != dst.shape or src.dtype != dst.dtype:
+                raise ValueError(f"GraphedRollout was captured for {k}: {tuple(dst.shape)} {dst.dtype}")
+            dst.copy_(src)
+        self.graph.replay()
+        out = self.policy._finish(self._pending)
+        return {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}

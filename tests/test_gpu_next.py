@@ -179,3 +179,27 @@ def test_reinforce_step_pomo_and_flat_allreduce():
         opt.step()
         first = out["reward"].mean().item() if first is None else first
     assert np.isfinite(first)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# HIP graph replay of the whole rollout
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("env_name,mode", [("tsp", "greedy"), ("cvrp", "greedy"), ("cvrp", "sampling")])
+def test_graphed_rollout_equals_eager(env_name, mode):
+    import eam_rl4co_amd as ea
+
+    cfg = "am_" + env_name
+    pol = make_policy(cfg)
+    env = ea.get_env(env_name, generator_params=dict(num_loc=20), seed=3)
+    tds = [env.reset(batch_size=[16]).to(DEV) for _ in range(3)]
+    M = tds[0]["locs"].shape[1]
+    kw = {}
+    if mode == "sampling":
+        kw["noise"] = torch.empty(16, 2 * M + 1, M, device=DEV).exponential_(1)
+    g = ea.GraphedRollout(pol, env, tds[0], decode_type=mode, **kw)
+    for td in tds + [tds[0]]:
+        a = g(td)
+        b = pol(td.clone(), env, phase="test", decode_type=mode, **kw)
+        assert_bits_equal(a["actions"], b["actions"], "actions")
+        assert_bits_equal(a["reward"], b["reward"], "reward")
+        assert_bits_equal(a["log_likelihood"], b["log_likelihood"], "ll")
