@@ -120,13 +120,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("EAMRL_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm; gloo only for rehearsals
+    if os.environ.get("EAMRL_BENCH_SINGLE_DEVICE") == "1":      # rehearse N ranks on a 1-GPU box (with gloo)
+        local_rank = 0
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import eam_rl4co_amd as ea
     from eam_rl4co_amd import ops
@@ -178,8 +184,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:      # the slowest rank defines the step time
+        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -122,25 +122,28 @@ __global__ __launch_bounds__(EB) void k_tour_length(const float* locs, const int
     if (lane == 0) reward[r] = -total;
 }
 
-// 64 rows per block; tiles of 64 steps are staged through LDS so that the global reads are row-contiguous while
-// each thread still adds its own row strictly in step order.
-__global__ __launch_bounds__(64) void k_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T)
+// 64 rows per 256-thread block; tiles of 64 steps are staged through LDS so that the global reads are
+// row-contiguous while thread r still adds row r strictly in step order.
+__global__ __launch_bounds__(256) void k_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T)
 {
     __shared__ float tile[64][65];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     float s = 0.0f;
     for (int t0 = 0; t0 < T; t0 += 64) {
-        for (int rr = 0; rr < 64; ++rr) {
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int rr = i >> 6, tt = i & 63;
             const int64_t r = r0 + rr;
-            tile[rr][lane] = (r < R && t0 + lane < T) ? logp[r * ld + t0 + lane] : 0.0f;
+            tile[rr][tt] = (r < R && t0 + tt < T) ? logp[r * ld + t0 + tt] : 0.0f;
         }
         __syncthreads();
-        const int tn = min(64, T - t0);
-        for (int t = 0; t < tn; ++t) s = s + tile[lane][t];
+        if (tid < 64) {
+            const int tn = min(64, T - t0);
+            for (int t = 0; t < tn; ++t) s = s + tile[tid][t];
+        }
         __syncthreads();
     }
-    if (r0 + lane < R) out[r0 + lane] = s;
+    if (tid < 64 && r0 + tid < R) out[r0 + tid] = s;
 }
 
 // One wavefront per row; "seen" bitmap in LDS (M <= 4096).
@@ -219,7 +222,7 @@ int launch_tour_length(const float* locs, const int64_t* actions, float* reward,
 
 int launch_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_sum_logp, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, st, logp, ld, out, R, T);
+    hipLaunchKernelGGL(k_sum_logp, dim3((unsigned)((R + 63) / 64)), dim3(256), 0, st, logp, ld, out, R, T);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 
