@@ -38,12 +38,18 @@ WORKLOADS = {
     "tsp20": ("tsp", 20, 128, "greedy"),           # configs[0]
     "cvrp100": ("cvrp", 100, 1024, "sampling"),    # configs[2]
     "cvrp500": ("cvrp", 500, 512, "greedy"),       # configs[4]
+    # configs[3], per-GPU share: POMO policy (6 layers, instance norm, no graph context), num_starts = num_loc
+    "pomo100": ("tsp", 100, 1024, "multistart_sampling"),
 }
+POMO_KW = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def algorithmic_bytes_per_decode_step(env, M, E=128):
-    """12*M*E (K,V,L) + 4*E*g (context rows) + 2*M (mask r/w) + c."""
+def algorithmic_bytes_per_decode_step(env, M, E=128, S=1):
+    """12*M*E (K,V,L) + 4*E*g (context rows) + 2*M (mask r/w) + c; multistart (per
+    instance-step, S queries sharing K/V/L): 12*M*E + S*(8*E + 2*M + 28)."""
+    if S > 1:
+        return 12 * M * E + S * (8 * E + 2 * M + 28)
     if env == "tsp":
         return 12 * M * E + 4 * E * 2 + 2 * M + 28
     return 12 * M * E + 4 * E * 1 + 2 * M + 32 + 2 * M
@@ -61,27 +67,28 @@ def measured_traffic(workload, batch):
         return None
 
 
-def build_policy(env_name, device):
+def build_policy(env_name, device, pomo=False):
     import eam_rl4co_amd as ea
     from _util import golden_weights
 
-    pol = ea.AttentionModelPolicy(env_name=env_name).eval()
+    pol = ea.AttentionModelPolicy(env_name=env_name, **(POMO_KW if pomo else {})).eval()
     torch.manual_seed(0)
     sd = pol.state_dict()
-    for k, v in golden_weights("am_" + env_name).items():   # deterministic closed-form weights (untrained)
+    for k, v in golden_weights(("pomo_" if pomo else "am_") + env_name).items():   # closed-form weights (untrained)
         sd[k].copy_(torch.from_numpy(v))
     return pol.to(device)
 
 
-def cpu_baseline(env_name, num_loc, decode_type, seconds_budget=20.0):
+def cpu_baseline(env_name, num_loc, decode_type, num_starts=0, pomo=False, seconds_budget=20.0):
     """Time the CPU oracle on a bounded sample (batch chosen so the run takes ~10-30 s)."""
     from _util import golden_weights
     from oracle import oracle as orc
     import eam_rl4co_amd as ea
 
     threads = orc.set_threads(min(orc.usable_cpus(), 64))   # the box's CPU share, not its core count
-    sd = golden_weights("am_" + env_name)
+    sd = golden_weights(("pomo_" if pomo else "am_") + env_name)
     env = ea.get_env(env_name, generator_params=dict(num_loc=num_loc), seed=1234)
+    S = max(num_starts, 1)
 
     def run(batch):
         torch.manual_seed(1234)
@@ -89,20 +96,21 @@ def cpu_baseline(env_name, num_loc, decode_type, seconds_budget=20.0):
         locs = td["locs"].numpy()
         demand = td["demand"].numpy() if env_name == "cvrp" else None
         noise = None
-        if decode_type == "sampling":
+        if "sampling" in decode_type:
             M = locs.shape[1]
-            noise = torch.empty(batch, 2 * M + 1, M).exponential_(1).numpy()
+            noise = torch.empty(batch * S, 2 * M + 1, M).exponential_(1).numpy()
         t0 = time.perf_counter()
-        out = orc.policy_rollout(sd, env_name, locs, demand, decode_type=decode_type, noise=noise)
+        out = orc.policy_rollout(sd, env_name, locs, demand, decode_type=decode_type, num_starts=num_starts, noise=noise)
         return time.perf_counter() - t0, out["steps"]
 
-    b = 16
+    b = 16 if S == 1 else 2
     t, _ = run(b)                                  # calibration (also warms the library)
     target = max(b, int(b * min(seconds_budget / max(t, 1e-3), 64)))
     target = min(target, 1024)
     t, steps = run(target)
-    return {"value": round(target * num_loc / t, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{env_name.upper()}-{num_loc} {decode_type} rollout, batch={target}, {steps} decode steps, "
+    return {"value": round(target * S * num_loc / t, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{env_name.upper()}-{num_loc} {decode_type} rollout, batch={target}"
+                      + (f" x {S} starts" if S > 1 else "") + f", {steps} decode steps, "
                       f"{t:.2f} s on {threads} OpenMP threads (oracle/eamrl_oracle.c)"}
 
 
@@ -137,13 +145,20 @@ def main():
     import eam_rl4co_amd as ea
     from eam_rl4co_amd import ops
 
+    for kv in filter(None, os.environ.get("EAMRL_DEBUG_KEYS", "").split(",")):   # kernel A/B experiments only
+        from eam_rl4co_amd import _lib
+        _lib.load().eamrl_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
+
     env_name, num_loc, batch, decode_type = WORKLOADS[args.workload]
     batch = args.batch or batch
     env = ea.get_env(env_name, generator_params=dict(num_loc=num_loc), seed=1234 + rank)
     torch.manual_seed(1234 + rank)
     td0 = env.reset(batch_size=[batch]).to(device)         # synthetic uniform-[0,1]^2 instances, resident in HBM
-    policy = build_policy(env_name, device)
+    pomo = args.workload.startswith("pomo")
+    policy = build_policy(env_name, device, pomo=pomo)
     M = td0["locs"].shape[1]
+    S = num_loc if "multistart" in decode_type else 1
+    dkw = dict(num_starts=S) if S > 1 else {}
 
     # time the decode-loop kernel with HIP events on the launch stream (torch's current stream)
     kernel_ms, decode_steps = [], []
@@ -157,17 +172,17 @@ def main():
         kernel_ms.append((e0, e1))
         return r
 
-    graphed = None if args.no_graph else ea.GraphedRollout(policy, env, td0, decode_type=decode_type)
+    graphed = None if args.no_graph else ea.GraphedRollout(policy, env, td0, decode_type=decode_type, **dkw)
 
     def one_step():
         if graphed is not None:
             return graphed(td0)                      # copy inputs into the captured buffers + one graph replay
-        return policy(td0.clone(), env, phase="test", decode_type=decode_type)
+        return policy(td0.clone(), env, phase="test", decode_type=decode_type, **dkw)
 
     # duration of the decode-loop launch: HIP events around it on the launch stream, in eager passes before the timed region
     ops.rollout = timed_rollout
     for _ in range(5):
-        policy(td0.clone(), env, phase="test", decode_type=decode_type)
+        policy(td0.clone(), env, phase="test", decode_type=decode_type, **dkw)
     torch.cuda.synchronize()
     ops.rollout = orig_rollout
     kernel_ms = kernel_ms[2:]
@@ -191,17 +206,18 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * batch * num_loc * args.steps / elapsed
+        value = world * batch * S * num_loc * args.steps / elapsed
         kern = float(np.mean([a.elapsed_time(b) for a, b in kernel_ms]))
         T = float(np.mean(decode_steps))
-        alg_bytes = algorithmic_bytes_per_decode_step(env_name, M) * batch * T
+        alg_bytes = algorithmic_bytes_per_decode_step(env_name, M, S=S) * batch * T
         achieved = alg_bytes / (kern * 1e-3) / 1e9
         line = {
             "metric": "env-steps/sec (batch x num_loc / s), AttentionModel construction rollout",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{env_name.upper()} num_loc={num_loc} batch={batch}/GPU AM {decode_type} rollout "
+            "config": {"workload": f"{env_name.upper()} num_loc={num_loc} batch={batch}/GPU "
+                                   + (f"x {S} starts POMO" if pomo else "AM") + f" {decode_type} rollout "
                                    f"(encoder + cache + decode loop + reward)",
                        "decode_steps": T, "reward_mean": round(float(out["reward"].mean()), 4),
                        "launch": "eager" if args.no_graph else "hipGraph replay"},
@@ -211,7 +227,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(env_name, num_loc, decode_type)
+            line["cpu_baseline"] = cpu_baseline(env_name, num_loc, decode_type, num_starts=S if S > 1 else 0, pomo=pomo)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

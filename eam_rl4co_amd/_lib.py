@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libeamrl_hip.so")
+# EAMRL_HIP_LIB: development override (instrumented builds made by tools/); the default is the in-tree library
+LIB_PATH = os.environ.get("EAMRL_HIP_LIB") or os.path.join(_PKG, "lib", "libeamrl_hip.so")
 
 ENV_TSP, ENV_CVRP = 0, 1
 GREEDY, SAMPLE, EVALUATE = 0, 1, 2

@@ -181,22 +181,35 @@ __device__ __forceinline__ float wave_tree_sum(float v)
     return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
+// max(a, b) as the single v_max_f32 it is (the builtin adds two canonicalising v_max x,x per call)
+__device__ __forceinline__ float vmax_raw(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// one butterfly level of a max: max(v, v of the DPP partner lane); s_nop 1 = the 2 wait states a DPP read needs
+// after the VALU write of its source (the compiler does not see hazards inside inline asm)
+#define EAMRL_MAX_DPP(v, ctrl) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(v))
+
 __device__ __forceinline__ float wave_max(float v)
 {
-    v = __builtin_fmaxf(v, dpp_f<DPP_XOR1>(v));
-    v = __builtin_fmaxf(v, dpp_f<DPP_XOR2>(v));
-    v = __builtin_fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
-    v = __builtin_fmaxf(v, dpp_f<DPP_MIRROR>(v));
+    EAMRL_MAX_DPP(v, "quad_perm:[1,0,3,2]");
+    EAMRL_MAX_DPP(v, "quad_perm:[2,3,0,1]");
+    EAMRL_MAX_DPP(v, "row_half_mirror");
+    EAMRL_MAX_DPP(v, "row_mirror");
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    v = vmax_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
     auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __builtin_fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+    return vmax_raw(__uint_as_float(s[0]), __uint_as_float(s[1]));
 }
 
 // argmax with torch.argmax's tie rule (lowest index); every lane gets the winner.
 __device__ __forceinline__ void argmax_pick(float& v, int& i, float ov, int oi)
 {
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    const bool take = (ov > v) | ((ov == v) & (oi < i));     // branch-free: two selects
+    v = take ? ov : v;
+    i = take ? oi : i;
 }
 __device__ __forceinline__ void wave_argmax(float& v, int& i)
 {

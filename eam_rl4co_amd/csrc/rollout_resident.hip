@@ -33,6 +33,14 @@ constexpr int RH = 8;        // heads
 constexpr int RD = 16;       // head dim
 constexpr int RNP = 128;     // node slots
 
+#ifdef EAMRL_STAMPS   // development build only (tools/stamps.sh): per-stage cycle sums of wavefront 0
+__device__ unsigned long long g_stamps[8];
+#define STAMP(i) do { if (wv == fw) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+                                     stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 template <int CP>
 struct ResLds {
     static constexpr int WROW = 4 * CP + 4;     // floats per head row of w (chunk-padded, +4 spreads banks)
@@ -52,8 +60,10 @@ struct ResLds {
 };
 
 // CP: chunk stride of a w row in LDS (multiple of 4, >= chunk length C); CR: V registers per chunk (C <= CR <= CP)
-template <int ENV, int CP, int CR>
-__global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
+// MS (multistart batches, R = S*B rows in "(s b)" order): workgroup (b, g) = blockIdx b + g*B keeps instance b's
+// operands in registers and rolls out its starts g, g+G, g+2G, ... one after the other.
+template <int ENV, int CP, int CR, bool MS>
+__global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, int G)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using L = ResLds<CP>;
@@ -64,8 +74,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ve = tid & 127, vg = tid >> 7;   // glimpse layout: column, chunk pair
     const int M = a.M;
-    const int64_t r = blockIdx.x;
-    const int64_t bi = r % a.B;
+    const int64_t bi = blockIdx.x % a.B;
     const int64_t ld = a.ld;
     const int C = (M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
     const int n0 = lane, n1 = lane + 64;
@@ -106,9 +115,13 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
         }
         for (int i = tid; i < RH * WROW; i += RB) l.w[i] = 0.0f;   // chunk padding stays 0 for the whole episode
     }
-    const int pos0 = in0 ? (n0 / C) * CP + (n0 - (n0 / C) * C) : 0;   // slots of the two nodes in a w row
-    const int pos1 = in1 ? (n1 / C) * CP + (n1 - (n1 / C) * C) : 0;
+    // slots of the two nodes in a w row; absent nodes (n >= M) point at the row's never-read spare slot 4*CP
+    const int pos0 = in0 ? (n0 / C) * CP + (n0 - (n0 / C) * C) : 4 * CP;
+    const int pos1 = in1 ? (n1 / C) * CP + (n1 - (n1 / C) * C) : 4 * CP;
     const float sqrtE = __builtin_sqrtf((float)RE);
+
+    for (int s = MS ? (int)(blockIdx.x / a.B) : 0; s < (MS ? S : 1); s += (MS ? G : 1)) {
+    const int64_t r = MS ? (int64_t)s * a.B + bi : (int64_t)blockIdx.x;
 
     // ---- state: mask / visited in LDS; the scalar row state lives in wavefront 0 -----------------------------------------
     if (tid < RNP) {
@@ -119,12 +132,14 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
     if (tid == 0) l.done = a.done[r] != 0;
     __syncthreads();
 
+    constexpr int fw = 0;      // the wavefront that runs the serial "finish" section of a step
+
     int64_t first = 0, cur = 0, istep = 1;
     float used = 0.0f, vcap = 0.0f;
     int count = 0;
     float gq[2] = {0.f, 0.f}, cv[2] = {0.f, 0.f}, p1f[2] = {0.f, 0.f}, mydem[2] = {0.f, 0.f};
     bool done = l.done != 0;
-    if (wv == 0) {
+    if (wv == fw) {
         cur = a.cur[r];
         if (ENV == EAMRL_ENV_TSP) { first = a.first[r]; istep = a.istep[r]; }
         else { used = a.used[r]; vcap = a.vcap[r]; }
@@ -150,11 +165,19 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
 
     int t = 0;
     uint32_t st_flags = 0;
-    while (!done && t < a.t_max) {
+#ifdef EAMRL_STAMPS
+    unsigned long long stamp_acc[5] = {0, 0, 0, 0, 0}, stamp_t = __builtin_readcyclecounter();
+#endif
+    for (;;) {
+        // the LDS reads that open a step are issued together: episode flag and this lane's two mask bytes
+        // (slots >= M hold 0 for the whole episode, so no range check is needed)
+        done = l.done != 0;
+        const bool f0 = l.msk[n0] != 0, f1 = l.msk[n1] != 0;
+        if (done || t >= a.t_max) break;
         // prefetch this step's per-row inputs (latency hidden behind the glimpse)
         float nz0 = 1.0f, nz1 = 1.0f;
         int64_t given = 0;
-        if (wv == 0) {
+        if (wv == fw) {
             if (a.mode == EAMRL_SAMPLE) {
                 const float* nzp = a.noise + (r * a.t_max + t) * (int64_t)M;
                 if (in0) nz0 = nzp[n0];
@@ -164,29 +187,40 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
         }
 
         // ---- S1: scores, per-head max and softmax weights of heads 2w, 2w+1 for both nodes (all inside the wave) ----
+        // Branch-free and written so that the two heads' chains, butterflies and exponentials interleave.
         if (!(a.dbg & 1)) {
-            const bool f0 = in0 && l.msk[n0] != 0, f1 = in1 && l.msk[n1] != 0;
+            float s0[2] = {0.0f, 0.0f}, s1[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int d = 0; d < RD; d += 4) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const float4 qq = *reinterpret_cast<const float4*>(l.q + (2 * wv + hh) * RD + d);
+                    s0[hh] = fma_(qq.x, kreg[0][hh * RD + d], s0[hh]);     s1[hh] = fma_(qq.x, kreg[1][hh * RD + d], s1[hh]);
+                    s0[hh] = fma_(qq.y, kreg[0][hh * RD + d + 1], s0[hh]); s1[hh] = fma_(qq.y, kreg[1][hh * RD + d + 1], s1[hh]);
+                    s0[hh] = fma_(qq.z, kreg[0][hh * RD + d + 2], s0[hh]); s1[hh] = fma_(qq.z, kreg[1][hh * RD + d + 2], s1[hh]);
+                    s0[hh] = fma_(qq.w, kreg[0][hh * RD + d + 3], s0[hh]); s1[hh] = fma_(qq.w, kreg[1][hh * RD + d + 3], s1[hh]);
+                }
+            }
+            f32x2 sc[2];
+            float m[2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const float* qp = l.q + (2 * wv + hh) * RD;
-                float s0 = 0.0f, s1 = 0.0f;
+                sc[hh].x = f0 ? s0[hh] * 0.25f : -INFINITY;              // 1/sqrt(16)
+                sc[hh].y = f1 ? s1[hh] * 0.25f : -INFINITY;
+                m[hh] = vmax_raw(sc[hh].x, sc[hh].y);
+            }
+            m[0] = wave_max(m[0]);
+            m[1] = wave_max(m[1]);
 #pragma unroll
-                for (int d = 0; d < RD; d += 4) {
-                    const float4 qq = *reinterpret_cast<const float4*>(qp + d);
-                    s0 = fma_(qq.x, kreg[0][hh * RD + d], s0);     s1 = fma_(qq.x, kreg[1][hh * RD + d], s1);
-                    s0 = fma_(qq.y, kreg[0][hh * RD + d + 1], s0); s1 = fma_(qq.y, kreg[1][hh * RD + d + 1], s1);
-                    s0 = fma_(qq.z, kreg[0][hh * RD + d + 2], s0); s1 = fma_(qq.z, kreg[1][hh * RD + d + 2], s1);
-                    s0 = fma_(qq.w, kreg[0][hh * RD + d + 3], s0); s1 = fma_(qq.w, kreg[1][hh * RD + d + 3], s1);
-                }
-                s0 = f0 ? s0 * 0.25f : -INFINITY;              // 1/sqrt(16)
-                s1 = f1 ? s1 * 0.25f : -INFINITY;
-                const float m = wave_max(__builtin_fmaxf(s0, s1));
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x2 e2 = d_expf2(sc[hh] - splat2(m[hh]));        // masked / absent nodes: value discarded below
                 float* wrow = l.w + (2 * wv + hh) * WROW;
-                if (in0) wrow[pos0] = f0 ? d_expf(s0 - m) : 0.0f;
-                if (in1) wrow[pos1] = f1 ? d_expf(s1 - m) : 0.0f;
+                wrow[pos0] = f0 ? e2.x : 0.0f;                           // absent nodes write 0 into the row's spare slot
+                wrow[pos1] = f1 ? e2.y : 0.0f;
             }
         }
         __syncthreads();
+        STAMP(0);
 
         // ---- S2: glimpse partials, column ve, chunks 2vg and 2vg+1 ----------------------------------------------------
         if (!(a.dbg & 2)) {
@@ -208,6 +242,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
             }
         }
         __syncthreads();
+        STAMP(1);
 
         // ---- S4: lanes 0-31 finish the 32 glimpse values of column chunk w; then the logit partials of both nodes ----
         if (!(a.dbg & 4)) {
@@ -233,16 +268,17 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
             l.cpart[n1 * 4 + wv] = c1;
         }
         __syncthreads();
+        STAMP(2);
 
-        // ---- S5: wavefront 0 finishes the step: clip, mask, log-softmax, selection, env transition, next query -------
-        if (wv == 0) {
+        // ---- S5: one wavefront finishes the step: clip, mask, log-softmax, selection, env transition, next query -----
+        if (wv == fw) {
             if (!(a.dbg & 32)) __builtin_amdgcn_s_setprio(3);   // the serial section of the step: let it win issue arbitration
             // both nodes of the lane go through the elementwise math side by side (packed fp32 instructions:
             // half the issue slots and two independent dependency chains for this single wavefront)
             float x[2], lpv[2];
             bool fe[2];
-            fe[0] = in0 && l.msk[n0] != 0;
-            fe[1] = in1 && l.msk[n1] != 0;
+            fe[0] = f0;                          // the mask changes only at the end of this section
+            fe[1] = f1;
             const float4 cpa = *reinterpret_cast<const float4*>(l.cpart + n0 * 4);
             const float4 cpb = *reinterpret_cast<const float4*>(l.cpart + n1 * 4);
             f32x2 u2 = (f32x2){cpa.x, cpb.x} + (f32x2){cpa.y, cpb.y};
@@ -253,28 +289,39 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
             f32x2 v2 = (a.clip > 0.0f) ? d_tanhf2(logit2) * splat2(a.clip) : logit2;
             v2.x = fe[0] ? v2.x : -INFINITY;
             v2.y = fe[1] ? v2.y : -INFINITY;
-            if (a.temp != 1.0f) v2 = v2 / splat2(a.temp);       // v / 1 == v exactly
+            if (a.temp != 1.0f) {                               // v / 1 == v exactly
+                asm volatile("" ::: "memory");                  // keep this a (uniform) branch: 2 IEEE divisions
+                v2 = v2 / splat2(a.temp);
+            }
             x[0] = v2.x; x[1] = v2.y;
-            const float mx = wave_max(__builtin_fmaxf(x[0], x[1]));
+            const float mx = wave_max(vmax_raw(x[0], x[1]));
             const f32x2 ex2 = d_expf2(v2 - splat2(mx));
             const float e0 = fe[0] ? ex2.x : 0.0f;
             const float e1 = fe[1] ? ex2.y : 0.0f;
-            float Zl = wave_tree_sum(e0);
-            if (M > 64) Zl = Zl + wave_tree_sum(e1);
+            // second 64-block of the lane tree: all zeros when M <= 64, and Z + 0 == Z
+            const float Zl = wave_tree_sum(e0) + wave_tree_sum(e1);
             const float lse = d_logf(Zl);
             const f32x2 lp2 = (v2 - splat2(mx)) - splat2(lse);
             lpv[0] = fe[0] ? lp2.x : -INFINITY;
             lpv[1] = fe[1] ? lp2.y : -INFINITY;
-            float key0 = lpv[0], key1 = lpv[1];
+            int sel;
             if (a.mode == EAMRL_SAMPLE) {
                 const f32x2 k2 = d_expf2((f32x2){lpv[0], lpv[1]}) / (f32x2){nz0, nz1};
-                key0 = k2.x; key1 = k2.y;
+                float best = in0 ? k2.x : -INFINITY;
+                int besti = in0 ? n0 : 0x7fffffff;
+                const bool take1 = in1 & (k2.y > best);
+                best = take1 ? k2.y : best;
+                besti = take1 ? n1 : besti;
+                wave_argmax(best, besti);
+                sel = besti;
+            } else {
+                // argmax of the log-probs, lowest index on ties: the maximum is known -- the lanes holding the
+                // largest logit have (mx - mx) - lse = 0 - lse, and rounding is monotonic -- so the winner is the
+                // first lane that equals it
+                const float top = 0.0f - lse;
+                const unsigned long long b0 = __ballot(in0 && lpv[0] == top), b1 = __ballot(in1 && lpv[1] == top);
+                sel = b0 ? __builtin_ctzll(b0) : 64 + (b1 ? __builtin_ctzll(b1) : 64);
             }
-            float best = in0 ? key0 : -INFINITY;
-            int besti = in0 ? n0 : 0x7fffffff;
-            if (in1 && key1 > best) { best = key1; besti = n1; }
-            wave_argmax(best, besti);
-            int sel = besti;
             if (a.dbg & 8) sel = t;
             if (a.mode == EAMRL_EVALUATE) sel = (int)given;
             sel = __builtin_amdgcn_readfirstlane(sel);
@@ -332,10 +379,17 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
             }
             __builtin_amdgcn_s_setprio(0);
         }
+        STAMP(3);
         __syncthreads();
-        done = l.done != 0;
+        STAMP(4);
         ++t;
     }
+#ifdef EAMRL_STAMPS
+    if (wv == fw && lane == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], stamp_acc[i]);
+        atomicAdd(&g_stamps[5], (unsigned long long)t);
+    }
+#endif
 
     // ---- write back the episode and the final state ---------------------------------------------------------------
     __syncthreads();
@@ -347,7 +401,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
         a.mask[r * M + tid] = l.msk[tid];
         if (ENV == EAMRL_ENV_CVRP) a.visited[r * M + tid] = l.vis[tid];
     }
-    if (tid == 0) {
+    if (wv == fw && lane == 0) {
         a.cur[r] = cur;
         a.done[r] = done ? 1 : 0;
         if (ENV == EAMRL_ENV_TSP) { a.first[r] = first; a.istep[r] = istep; }
@@ -355,6 +409,8 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a)
         atomicMax(a.steps_out, t);
         if (!done) st_flags |= EAMRL_ST_STEP_OVERRUN;
         if (st_flags) atomicOr(a.status, st_flags);
+    }
+    if (MS) __syncthreads();      // the next start re-initialises the row state in LDS
     }
 }
 
@@ -370,15 +426,33 @@ __global__ void k_rollout_pad_cvrp_res(DecArgs a)
     }
 }
 
-template <int ENV, int CP, int CR>
-int launch_cp(const DecArgs& a, hipStream_t st)
+template <int ENV, int CP, int CR, bool MS>
+int launch_ms(const DecArgs& a, int S, int G, hipStream_t st)
 {
     const size_t lds = ((sizeof(ResLds<CP>) + 15) & ~size_t(15)) + (size_t)a.M * RE * sizeof(float);
-    auto k = k_rollout_resident<ENV, CP, CR>;
+    auto k = k_rollout_resident<ENV, CP, CR, MS>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return EAMRL_E_LAUNCH;
-    hipLaunchKernelGGL(k, dim3((unsigned)a.R), dim3(RB), lds, st, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)(MS ? a.B * G : a.R)), dim3(RB), lds, st, a, S, G);
+    return 0;
+}
+
+template <int ENV, int CP, int CR>
+int launch_cp(const DecArgs& a, hipStream_t st)
+{
+    // multistart batch: enough workgroups per instance to fill the chip four times over, the rest of the starts
+    // are looped inside the workgroup on the register-resident operands
+    const int64_t S = a.R / a.B;
+    int rc;
+    if (S > 1 && a.R % a.B == 0 && !g_debug[6]) {
+        int64_t G = (4 * 512 + a.B - 1) / a.B;
+        G = G < 1 ? 1 : (G > S ? S : G);
+        rc = launch_ms<ENV, CP, CR, true>(a, (int)S, (int)G, st);
+    } else {
+        rc = launch_ms<ENV, CP, CR, false>(a, 1, 1, st);
+    }
+    if (rc) return rc;
     if (ENV == EAMRL_ENV_CVRP)
         hipLaunchKernelGGL(k_rollout_pad_cvrp_res, dim3((unsigned)((a.R + 255) / 256)), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
@@ -398,6 +472,18 @@ int launch_env(const DecArgs& a, hipStream_t st)
 }
 
 }  // namespace
+
+#ifdef EAMRL_STAMPS
+extern "C" __attribute__((visibility("default"))) int eamrl_debug_read_stamps(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 bool rollout_resident_supports(int env, const DecArgs& a)
 {

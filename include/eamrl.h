@@ -56,7 +56,8 @@ const char* eamrl_last_error(void);
  * key 0: 1 = run eamrl_linear on the VALU cross-check kernel instead of the MFMA kernel.
  * key 1: 1 = eamrl_am_rollout always uses the streaming kernel (never the register-resident one).
  * key 4: 1 = eamrl_linear uses 128-row tiles instead of 64-row tiles.
- * key 3: 1 = eamrl_mha_encoder uses the one-row-per-thread kernel even where the blocked one applies. */
+ * key 3: 1 = eamrl_mha_encoder uses the one-row-per-thread kernel even where the blocked one applies.
+ * key 6: 1 = eamrl_am_rollout does not use the start-sharing kernel for multistart batches (R = S*B rows). */
 int eamrl_debug_set(int key, int value);
 
 /* ---- environment state machines ---------------------------------------------------------------- */

@@ -93,6 +93,44 @@ def test_multistart_sampling_cvrp_and_select_best(oracle):
     assert torch.equal(best["reward"], r.max(1).values) and best["actions"].shape[0] == B
 
 
+@pytest.mark.parametrize("env_name,N,B,S", [("tsp", 20, 4, 2), ("tsp", 20, 3, 5), ("tsp", 50, 2, 7), ("tsp", 100, 2, 9),
+                                            ("cvrp", 20, 3, 3), ("cvrp", 100, 2, 6), ("cvrp", 127, 1, 5)])
+@pytest.mark.parametrize("mode", ["greedy", "sampling"])
+def test_start_sharing_kernel_matches_oracle_and_single_row_kernel(oracle, env_name, N, B, S, mode):
+    """Multistart batches go through the start-sharing kernel (P starts of an instance per workgroup, ragged last
+    group when S % P != 0, CVRP rows finishing at different steps): bit-equal to the oracle and to the
+    one-row-per-workgroup kernel."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import _lib
+
+    cfg = "am_" + env_name
+    pol = make_policy(cfg)
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=N)
+    torch.manual_seed(7 + N)
+    td_cpu = env.reset(batch_size=[B])
+    locs = td_cpu["locs"].numpy()
+    demand = td_cpu["demand"].numpy() if env_name == "cvrp" else None
+    M = locs.shape[1]
+    kw, noise = dict(num_starts=S), None
+    if mode == "sampling":
+        noise = torch.empty(B * S, 2 * M + 1, M).exponential_(1, generator=torch.Generator().manual_seed(N + S))
+        kw["noise"] = noise.to(DEV)
+    outs = []
+    for single in (0, 1):
+        _lib.load().eamrl_debug_set(6, single)
+        try:
+            outs.append(pol(td_cpu.to(DEV), env, phase="test", decode_type="multistart_" + mode,
+                            return_sum_log_likelihood=False, **kw))
+        finally:
+            _lib.load().eamrl_debug_set(6, 0)
+    o = oracle.policy_rollout(golden_weights(cfg), env_name, locs, demand, decode_type="multistart_" + mode,
+                              num_starts=S, noise=None if noise is None else noise.numpy())
+    for out in outs:
+        assert_bits_equal(out["actions"], o["actions"], "tours")
+        assert_bits_equal(out["log_likelihood"], o["logp_steps"], "logp")
+        assert_bits_equal(out["reward"], o["reward"], "reward")
+
+
 # ---------------------------------------------------------------------------------------------------------
 # N2: evaluation harness
 # ---------------------------------------------------------------------------------------------------------
