@@ -240,4 +240,25 @@ __attribute__((visibility("default"))) int eamrl_check_solution(int env, const i
                     "eamrl_check_solution");
 }
 
+__attribute__((visibility("default"))) int eamrl_ea_tsp_run(const float* locs, int64_t* pop, float* fitness, int64_t B,
+                                                           int S, int N, int num_generations, double mutation_rate,
+                                                           double crossover_rate, double selection_rate,
+                                                           const double* cross_rand, const int32_t* cross_idx,
+                                                           const double* mut_rand, const int32_t* mut_idx, void* stream)
+{
+    REQUIRE(locs && pop && fitness, "eamrl_ea_tsp_run");
+    REQUIRE(B >= 0 && B <= 0x7fffffffLL && S >= 1 && S <= 128 && N >= 2 && N <= 128 && num_generations >= 0,
+            "eamrl_ea_tsp_run (population and tour length are limited to 128)");
+    REQUIRE(mutation_rate == mutation_rate && crossover_rate == crossover_rate && selection_rate >= 0.0,
+            "eamrl_ea_tsp_run");
+    int ne = S;
+    if (S > 2) { ne = (int)(selection_rate * (double)S); if (ne <= 0 || ne > S) ne = S; }
+    if (num_generations > 0 && ne / 2 > 0)      // an elite set of one produces no offspring and reads no draws
+        REQUIRE(cross_rand && cross_idx && mut_rand && mut_idx, "eamrl_ea_tsp_run (draws)");
+    if (B == 0) return 0;
+    return launched(launch_ea_tsp(locs, pop, fitness, B, S, N, num_generations, mutation_rate, crossover_rate,
+                                  selection_rate, cross_rand, cross_idx, mut_rand, mut_idx, (hipStream_t)stream),
+                    "eamrl_ea_tsp_run");
+}
+
 }  // extern "C"

@@ -35,5 +35,8 @@ int launch_decode_step(int env, const DecArgs& a, hipStream_t st);
 int launch_rollout_stream(int env, const DecArgs& a, hipStream_t st);
 int launch_rollout_resident(int env, const DecArgs& a, hipStream_t st);
 bool rollout_resident_supports(int env, const DecArgs& a);
+int launch_ea_tsp(const float* locs, int64_t* pop, float* fitness, int64_t B, int S, int N, int G, double mutation_rate,
+                  double crossover_rate, double selection_rate, const double* cross_rand, const int32_t* cross_idx,
+                  const double* mut_rand, const int32_t* mut_idx, hipStream_t st);
 
 }  // namespace eamrl

@@ -262,6 +262,40 @@ def check_solution(env_name, actions, demand=None, vcap=None, num_loc=None):
 # ------------------------------------------------------------------------------------------------------
 # decode
 # ------------------------------------------------------------------------------------------------------
+def ea_num_pairs(selection_rate: float, pop_size: int) -> int:
+    """Crossover pairs per generation of EA.run (elites // 2; int(rate*S) elites, 0 -> all, S <= 2 -> all)."""
+    if pop_size <= 2:
+        ne = pop_size
+    else:
+        ne = int(selection_rate * pop_size)
+        ne = pop_size if ne <= 0 else min(ne, pop_size)
+    return ne // 2
+
+
+def ea_tsp_run_(locs, pop, num_generations, mutation_rate, crossover_rate, selection_rate, cross_rand, cross_idx,
+                mut_rand, mut_idx):
+    """In place on pop [B, S, N] (int64); returns fitness [B, S].  Draw tensors: see include/eamrl.h."""
+    lib = _lib.load()
+    _chk(locs, "locs", torch.float32)
+    _chk(pop, "pop", torch.int64)
+    B, S, N = pop.shape
+    if locs.shape != (B, N, 2):
+        raise ValueError(f"ea_tsp_run: locs {tuple(locs.shape)} does not match pop {tuple(pop.shape)}")
+    P = ea_num_pairs(selection_rate, S)
+    G = int(num_generations)
+    if G > 0 and P > 0:
+        _chk(cross_rand, "cross_rand", torch.float64, (G, B, P))
+        _chk(cross_idx, "cross_idx", torch.int32, (G, B, P, 2))
+        _chk(mut_rand, "mut_rand", torch.float64, (G, B, 2 * P))
+        _chk(mut_idx, "mut_idx", torch.int32, (G, B, 2 * P, 2))
+    fitness = torch.empty(B, S, device=pop.device, dtype=torch.float32)
+    nul = lambda t: _ptr(t) if (G > 0 and P > 0) else None
+    _lib.check(lib.eamrl_ea_tsp_run(_ptr(locs), _ptr(pop), _ptr(fitness), B, S, N, G, float(mutation_rate),
+                                    float(crossover_rate), float(selection_rate), nul(cross_rand), nul(cross_idx),
+                                    nul(mut_rand), nul(mut_idx), _stream(pop)), "eamrl_ea_tsp_run")
+    return fitness
+
+
 class DecodeCache:
     """Device-resident decoder cache (struct eamrl_cache).
 

@@ -178,6 +178,26 @@ int eamrl_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, 
 int eamrl_check_solution(int env, const int64_t* actions, const float* demand, const float* vcap, int64_t R,
                          int64_t B, int N, int T, int32_t* bad, void* stream);
 
+/* ---- evolutionary improvement (the fork's EA) ---------------------------------------------------------------- */
+
+/* EA.run for TSP populations  [rl4co/models/zoo/earl/evolution.py:252-354; operators :356-362 (fitness),
+ * :1103-1108 (elitism_selection), :392-488 (order_crossover_tsp), :490-517 (inverse_mutate_tsp)].
+ * One population per instance, all generations in one launch; replaces the per-instance CPU thread pool of
+ * evolution_worker (:28-123).
+ *   locs [B][N][2] f32;  pop [B][S][N] i64, in: initial tours, out: evolved tours;  fitness [B][S] f32 out
+ *   (= f32(1.5*N) - tour length).  S, N <= 128.
+ * Elites: ne = S if S <= 2 else int(selection_rate*S) (0 -> S); pairs P = ne/2; offspring O = 2P per generation.
+ * Replacement: if the first nodes of the initial population are pairwise distinct, position s keeps the best of
+ * itself and the offspring starting at its first node; otherwise the S fittest of population ++ offspring.
+ * The reference draws inside the operators with numba's per-thread np.random; here the draws are inputs:
+ *   cross_rand [G][B][P] f64 uniforms (pair 0 always crosses, the others with the adjusted rate),
+ *   cross_idx  [G][B][P][2] i32 cut points in [1, N)   (read only where the pair crosses),
+ *   mut_rand   [G][B][O] f64 uniforms,  mut_idx [G][B][O][2] i32 in [1, N)  (read only where mut_rand < rate).
+ * crossover_rate: pass the float32-rounded value the reference's signature implies. */
+int eamrl_ea_tsp_run(const float* locs, int64_t* pop, float* fitness, int64_t B, int S, int N, int num_generations,
+                     double mutation_rate, double crossover_rate, double selection_rate, const double* cross_rand,
+                     const int32_t* cross_idx, const double* mut_rand, const int32_t* mut_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

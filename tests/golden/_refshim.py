@@ -203,3 +203,62 @@ def install():
         m = types.ModuleType(pkg)
         m.__path__ = [base + "/" + "/".join(pkg.split(".")[1:])]
         sys.modules[pkg] = m
+
+
+# ---------------------------------------------------------------------------------------------------------
+# numba stand-in for the fork's evolution operators (rl4co/models/zoo/earl/evolution.py)
+# ---------------------------------------------------------------------------------------------------------
+class _NbType:
+    """nb.int64 / nb.float32 / nb.boolean ...: usable as a numpy dtype (`.dtype`), as a cast (`nb.int64(50)`)
+    and inside signatures (`nb.int64[:, :]`, `nb.float32[:](...)`)."""
+
+    def __init__(self, np_type):
+        import numpy as np
+
+        self._t = np_type
+        self.dtype = np.dtype(np_type)
+
+    def __getitem__(self, _):
+        return self
+
+    def __call__(self, *a, **k):
+        if len(a) == 1 and not k and not isinstance(a[0], _NbType):
+            return self._t(a[0])
+        return self            # a signature such as nb.float32[:](nb.float32[:], nb.int64)
+
+
+def install_numba():
+    """`numba` is absent (no network).  Its decorators carry no arithmetic: with `njit` as the identity and
+    `prange` as `range`, the reference's evolution operators run as the plain Python/numpy they are written in
+    (sequentially, so the order of np.random draws is the program order)."""
+    if "numba" in sys.modules:
+        return
+    import numpy as np
+
+    nb = types.ModuleType("numba")
+
+    def njit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not isinstance(a[0], _NbType) and not k:
+            return a[0]
+        return lambda f: f
+
+    nb.njit = njit
+    nb.jit = njit
+    nb.prange = range
+    nb.set_num_threads = lambda n: None
+    for name in ("int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float32", "float64"):
+        setattr(nb, name, _NbType(getattr(np, name)))
+    nb.boolean = _NbType(np.bool_)
+    nb.void = _NbType(np.float64)
+    nb_types = types.ModuleType("numba.types")
+    nb_types.Tuple = lambda members: (lambda *a, **k: None)
+    nb.types = nb_types
+    core = types.ModuleType("numba.core")
+    config = types.ModuleType("numba.core.config")
+    config.NUMBA_NUM_THREADS = 1
+    core.config = config
+    nb.core = core
+    sys.modules["numba"] = nb
+    sys.modules["numba.types"] = nb_types
+    sys.modules["numba.core"] = core
+    sys.modules["numba.core.config"] = config

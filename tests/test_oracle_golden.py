@@ -154,3 +154,46 @@ def test_defined_math_accuracy(oracle):
     assert np.max(np.abs(l - np.log(xl.astype(np.float64)))) < 6e-7
     assert oracle.math_probe(np.array([1.0], np.float32))[1][0] == 0.0
     assert oracle.math_probe(np.array([-np.inf, 0.0], np.float32))[0].tolist() == [0.0, 1.0]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# evolutionary operators (the fork's EA): oracle/ea_oracle.py against outputs of the reference's own functions
+# ---------------------------------------------------------------------------------------------------------
+def test_ea_operators_match_reference():
+    from oracle import ea_oracle as ea
+
+    g = golden("ea_tsp_operators")
+    off = ea.order_crossover_tsp(g["parents"], float(g["crossover_rate"]), g["cross_rand"], g["cross_idx"])
+    np.testing.assert_array_equal(off, g["offspring"])
+    mut = ea.inverse_mutate_tsp(g["offspring"], float(g["mutation_rate"]), g["mut_rand"], g["mut_idx"])
+    np.testing.assert_array_equal(mut, g["mutated"])
+    sel = ea.elitism_selection(g["parents"], g["fitness"], float(g["selection_rate"]))
+    np.testing.assert_array_equal(sel, g["selected"])
+    for row in off:      # offspring are permutations that keep their parent's first node
+        assert sorted(row.tolist()) == list(range(off.shape[1]))
+    np.testing.assert_array_equal(off[:, 0], g["parents"][: off.shape[0], 0])
+
+
+@pytest.mark.parametrize("name", ["ea_tsp20_default", "ea_tsp20_busy", "ea_tsp50_busy"])
+def test_ea_run_matches_reference(name):
+    """EA.run of the reference (its operators executed with recorded draws) vs the restatement: identical
+    populations; fitness within 1e-5 relative (the reference's cost is torch's tour length, ours the canonical one)."""
+    from oracle import ea_oracle as ea
+
+    g = golden(name)
+    for b in range(g["locs"].shape[0]):
+        pop, fit = ea.ea_run_tsp(g["locs"][b], g["init_pop"][b], int(g["num_generations"]), float(g["mutation_rate"]),
+                                 float(g["crossover_rate"]), float(g["selection_rate"]), g["cross_rand"][:, b],
+                                 g["cross_idx"][:, b], g["mut_rand"][:, b], g["mut_idx"][:, b])
+        np.testing.assert_array_equal(pop, g["pop"][b])
+        np.testing.assert_allclose(fit, g["fitness"][b], rtol=1e-5, atol=1e-5)
+        assert (fit >= ea.tsp_fitness(ea.tsp_cost(g["locs"][b], g["init_pop"][b]), pop.shape[1]) - 1e-6).all()
+
+
+def test_ea_population_from_single_tour():
+    from oracle import ea_oracle as ea
+
+    route = np.array([3, 0, 4, 1, 2], dtype=np.int64)
+    pop = ea.generate_population_tsp(route, 7)
+    assert pop[0].tolist() == route.tolist() and pop[1].tolist() == [0, 4, 1, 2, 3] and pop[5].tolist() == pop[1].tolist()
+    assert pop[6].tolist() == [0, 4, 1, 2, 3]     # i % N == 1

@@ -81,6 +81,22 @@ def bench_decode(iters, dbg, t_max=None):
     print(f"decode resident dbg={dbg:2d} t_max={t_max or M}: {sorted(times[2:])[len(times[2:]) // 2]:8.1f} us (median, events around ops.rollout)")
 
 
+def bench_ea(iters):
+    """eamrl_ea_tsp_run at the POMO training shape: 1024 instances x 100 starts x 100 nodes, 3 generations."""
+    import eam_rl4co_amd as ea
+
+    B, S, N, G = 1024, 100, 100, 3
+    env = ea.get_env("tsp", generator_params=dict(num_loc=N))
+    td = env.reset(batch_size=[B]).to("cuda")
+    init = torch.stack([torch.stack([torch.cat([torch.tensor([s]), torch.tensor([x for x in torch.randperm(N).tolist() if x != s])])
+                                     for s in range(S)]) for _ in range(4)]).repeat(B // 4, 1, 1).cuda()
+    for rates in ((0.1, 0.6, 0.2), (0.5, 0.9, 1.0)):
+        runner = ea.EA(env, dict(num_generations=G, mutation_rate=rates[0], crossover_rate=rates[1], selection_rate=rates[2]))
+        d = ea.EADraws.sample(G, B, S, N, rates[2], "cuda")
+        us = timeit(lambda: runner.run(init, td, draws=d), iters)
+        print(f"ea_tsp_run B={B} S={S} N={N} G={G} rates={rates}: {us:8.1f} us  ({B * S * G / us:.1f} M individuals-generations/s)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
@@ -95,6 +111,8 @@ def main():
         bench_gemm(a.iters)
     if a.what in ("mha", "all"):
         bench_mha(a.iters)
+    if a.what in ("ea", "all"):
+        bench_ea(a.iters)
     if a.what in ("decode",):
         for d, tm in ((0, None), (0, 1), (0, 11), (0, 51), (15, 1), (15, 51), (15, None)):
             bench_decode(a.iters, d, tm)
