@@ -78,6 +78,37 @@ __device__ __forceinline__ f32x2 d_expf2(f32x2 x)
     return res;
 }
 
+// d_expf2 for arguments that are never positive (softmax: x - max): the upper clamp is a no-op there and the lower
+// one becomes a single max; every in-range value goes through the same operations as d_expf, so the bits agree.
+__device__ __forceinline__ float vmax_raw(float a, float b);
+__device__ __forceinline__ f32x2 d_expf2_nonpos(f32x2 x)
+{
+    f32x2 xc;
+    xc.x = vmax_raw(x.x, -88.0f);                   // -inf / NaN -> -88; the result of that lane is replaced by 0 below
+    xc.y = vmax_raw(x.y, -88.0f);
+    const f32x2 t = xc * splat2(1.44269504088896341f);
+    f32x2 n;
+    n.x = __builtin_rintf(t.x);
+    n.y = __builtin_rintf(t.y);
+    f32x2 r = pk_fma(n, splat2(-0.693359375f), xc);
+    r = pk_fma(n, splat2(2.12194440e-4f), r);
+    f32x2 p = splat2(1.9875691500e-4f);
+    p = pk_fma(p, r, splat2(1.3981999507e-3f));
+    p = pk_fma(p, r, splat2(8.3334519073e-3f));
+    p = pk_fma(p, r, splat2(4.1665795894e-2f));
+    p = pk_fma(p, r, splat2(1.6666665459e-1f));
+    p = pk_fma(p, r, splat2(5.0000001201e-1f));
+    const f32x2 r2 = r * r;
+    const f32x2 y = pk_fma(p, r2, r) + splat2(1.0f);
+    f32x2 sc;
+    sc.x = __uint_as_float((uint32_t)((int)n.x + 127) << 23);
+    sc.y = __uint_as_float((uint32_t)((int)n.y + 127) << 23);
+    f32x2 res = y * sc;
+    res.x = (x.x >= -87.0f) ? res.x : 0.0f;
+    res.y = (x.y >= -87.0f) ? res.y : 0.0f;
+    return res;
+}
+
 // log(x), x a normal positive number.
 __device__ __forceinline__ float d_logf(float x)
 {
@@ -186,6 +217,12 @@ __device__ __forceinline__ float vmax_raw(float a, float b)
 {
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3_raw(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 // one butterfly level of a max: max(v, v of the DPP partner lane); s_nop 1 = the 2 wait states a DPP read needs

@@ -467,13 +467,13 @@ __global__ __launch_bounds__(256) void k_mha_encoder_x2(const float* __restrict_
         for (int d = 0; d < D; d += 4) {
             const float4 a = *reinterpret_cast<const float4*>(p0 + d);
             const float4 c = *reinterpret_cast<const float4*>(p1 + d);
-            q2[d] = (f32x2){a.x, c.x}; q2[d + 1] = (f32x2){a.y, c.y};
-            q2[d + 2] = (f32x2){a.z, c.z}; q2[d + 3] = (f32x2){a.w, c.w};
+            // 1/sqrt(16) folded into q: a power of two, so chain(0.25 q, k) == 0.25 chain(q, k) bit for bit
+            q2[d] = (f32x2){a.x, c.x} * 0.25f; q2[d + 1] = (f32x2){a.y, c.y} * 0.25f;
+            q2[d + 2] = (f32x2){a.z, c.z} * 0.25f; q2[d + 3] = (f32x2){a.w, c.w} * 0.25f;
         }
     }
     const float* kh = ks + hh * D;
     const float* vh = vs + hh * D;
-    const f32x2 quarter = splat2(0.25f);
     f32x2 m2 = splat2(-INFINITY);
     for (int j = 0; j < N; ++j) {
         f32x2 a2 = splat2(0.0f);
@@ -485,7 +485,6 @@ __global__ __launch_bounds__(256) void k_mha_encoder_x2(const float* __restrict_
             a2 = pk_fma(q2[d + 2], splat2(kk.z), a2);
             a2 = pk_fma(q2[d + 3], splat2(kk.w), a2);
         }
-        a2 = a2 * quarter;
         m2.x = __builtin_fmaxf(m2.x, a2.x);
         m2.y = __builtin_fmaxf(m2.y, a2.y);
     }
@@ -502,7 +501,7 @@ __global__ __launch_bounds__(256) void k_mha_encoder_x2(const float* __restrict_
             a2 = pk_fma(q2[d + 2], splat2(kk.z), a2);
             a2 = pk_fma(q2[d + 3], splat2(kk.w), a2);
         }
-        const f32x2 w2 = d_expf2(a2 * quarter - m2);
+        const f32x2 w2 = d_expf2_nonpos(a2 - m2);
         Z2 = Z2 + w2;
 #pragma unroll
         for (int d = 0; d < D; d += 4) {
@@ -535,6 +534,8 @@ int launch_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, in
     const size_t lds = (size_t)2 * N * D * sizeof(float);
     if (D * H != E || lds > 160 * 1024 || B * H > 0x7fffffffLL) return EAMRL_E_ARG;
     dim3 grid((unsigned)(B * H)), block(128);
+    if (g_debug[7] && mha_mfma_supports(B, N, E, H, qkv, out))      // matrix-core attention: measured slower, opt-in
+        return launch_mha_mfma(qkv, out, B, N, E, H, st);
     // blocked kernel: 4 heads per block, 2 query rows per thread (needs 4 * ceil(N/2) <= 256 threads, aligned rows)
     if (D == 16 && H % 4 == 0 && 2 * (N + 1) <= 256 && !g_debug[3] && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0) {
         const size_t lds2 = (size_t)2 * N * 64 * sizeof(float);

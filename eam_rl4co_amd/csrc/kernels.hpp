@@ -19,6 +19,8 @@ extern int g_debug[8];   // eamrl_debug_set knobs
 
 int launch_linear(const GemmArgs& g, hipStream_t st);
 int launch_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H, hipStream_t st);
+int launch_mha_mfma(const float* qkv, float* out, int64_t B, int N, int E, int H, hipStream_t st);
+bool mha_mfma_supports(int64_t B, int N, int E, int H, const float* qkv, const float* out);
 int launch_normalize(float* x, int64_t B, int N, int E, int kind, const float* gamma, const float* beta,
                      const float* mean, const float* var, float eps, hipStream_t st);
 int launch_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, hipStream_t st);

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             m[1] = wave_max(m[1]);
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const f32x2 e2 = d_expf2(sc[hh] - splat2(m[hh]));        // masked / absent nodes: value discarded below
+                const f32x2 e2 = d_expf2_nonpos(sc[hh] - splat2(m[hh]));        // masked / absent nodes: value discarded below
                 float* wrow = l.w + (2 * wv + hh) * WROW;
                 wrow[pos0] = f0 ? e2.x : 0.0f;                           // absent nodes write 0 into the row's spare slot
                 wrow[pos1] = f1 ? e2.y : 0.0f;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             }
             x[0] = v2.x; x[1] = v2.y;
             const float mx = wave_max(vmax_raw(x[0], x[1]));
-            const f32x2 ex2 = d_expf2(v2 - splat2(mx));
+            const f32x2 ex2 = d_expf2_nonpos(v2 - splat2(mx));
             const float e0 = fe[0] ? ex2.x : 0.0f;
             const float e1 = fe[1] ? ex2.y : 0.0f;
             // second 64-block of the lane tree: all zeros when M <= 64, and Z + 0 == Z
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             lpv[1] = fe[1] ? lp2.y : -INFINITY;
             int sel;
             if (a.mode == EAMRL_SAMPLE) {
-                const f32x2 k2 = d_expf2((f32x2){lpv[0], lpv[1]}) / (f32x2){nz0, nz1};
+                const f32x2 k2 = d_expf2_nonpos((f32x2){lpv[0], lpv[1]}) / (f32x2){nz0, nz1};
                 float best = in0 ? k2.x : -INFINITY;
                 int besti = in0 ? n0 : 0x7fffffff;
                 const bool take1 = in1 & (k2.y > best);

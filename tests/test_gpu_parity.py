@@ -122,6 +122,24 @@ def test_matmul_right(oracle):
     assert_bits_equal(ops.matmul_right(t(x), t(Wt)), oracle.matmul_right(x, Wt), "matmul_right")
 
 
+@pytest.mark.parametrize("N", [1, 2, 5, 31, 32, 33, 63, 64, 65, 96, 97, 99, 100, 128])
+def test_matrix_core_attention_is_bit_exact(oracle, N):
+    """The MFMA attention kernel (scores and weighted values on v_mfma_f32_32x32x2_f32, every key-tile count and
+    ragged last tiles) against the oracle's ordered fma chains, with large-magnitude scores too."""
+    from eam_rl4co_amd import ops
+
+    rng = np.random.default_rng(1000 + N)
+    E, H, B = 128, 8, 3
+    from eam_rl4co_amd import _lib
+
+    qkv = (rng.standard_normal((B, N, 3 * E)) * rng.choice([0.3, 1.0, 3.0])).astype(np.float32)
+    _lib.load().eamrl_debug_set(7, 1)
+    try:
+        assert_bits_equal(ops.mha_encoder(t(qkv), H), oracle.mha_encoder(qkv, H), "mha_encoder (matrix cores)")
+    finally:
+        _lib.load().eamrl_debug_set(7, 0)
+
+
 @pytest.mark.parametrize("B,N", [(3, 20), (2, 100), (2, 101), (1, 127), (1, 301)])
 def test_encoder_attention_norms_mean(oracle, B, N):
     from eam_rl4co_amd import ops
@@ -131,12 +149,13 @@ def test_encoder_attention_norms_mean(oracle, B, N):
     from eam_rl4co_amd import _lib
     qkv = rng.standard_normal((B, N, 3 * E)).astype(np.float32)
     ref = oracle.mha_encoder(qkv, H)
-    for variant in (0, 1):     # blocked (2 rows / thread) and plain kernels
-        _lib.load().eamrl_debug_set(3, variant)
+    assert_bits_equal(ops.mha_encoder(t(qkv), H), ref, "mha_encoder default dispatch")
+    for key, variant in ((7, 1), (3, 1)):     # matrix-core kernel (N <= 128), then the plain VALU kernel
+        _lib.load().eamrl_debug_set(key, variant)
         try:
-            assert_bits_equal(ops.mha_encoder(t(qkv), H), ref, f"mha_encoder variant {variant}")
+            assert_bits_equal(ops.mha_encoder(t(qkv), H), ref, f"mha_encoder debug key {key}")
         finally:
-            _lib.load().eamrl_debug_set(3, 0)
+            _lib.load().eamrl_debug_set(key, 0)
     x = rng.standard_normal((B, N, E)).astype(np.float32)
     g, bt = rng.standard_normal(E).astype(np.float32), rng.standard_normal(E).astype(np.float32)
     mu, var = rng.standard_normal(E).astype(np.float32), (rng.random(E) + 0.5).astype(np.float32)
