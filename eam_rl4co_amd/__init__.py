@@ -3,7 +3,7 @@ RL4CO interfaces of Tarseus/eam-rl4co.  See DESIGN.md."""
 from .envs import CVRPEnv, CVRPGenerator, RL4COEnvBase, TSPEnv, TSPGenerator, get_env  # noqa: F401
 from .policy import (AttentionModelDecoder, AttentionModelEncoder, AttentionModelPolicy, GraphedRollout,  # noqa: F401
                      load_reference_checkpoint, random_policy, rollout)
-from .evolution import EA, EADraws, evolution_worker, generate_batch_population  # noqa: F401
+from .evolution import EA, EACvrpDraws, EADraws, evolution_worker, generate_batch_population  # noqa: F401
 from .tensordict_lite import TensorDict  # noqa: F401
 from .utils import batchify, gather_by_index, unbatchify  # noqa: F401
 

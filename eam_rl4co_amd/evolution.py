@@ -12,7 +12,8 @@ or supplied by the caller -- the form in which the operators are tested against 
 (tests/golden/ea_*.npz).
 
 Built: TSP (order crossover, inversion mutation, elitism, per-start-node / top-k replacement, single-start
-rotation population).  CVRP / PCTSP / OP / FFSP operators are not built and raise NotImplementedError.
+rotation population) and CVRP (route-prefix crossover with capacity repair, in-route inversion, initial
+mutation pass).  PCTSP / OP / FFSP operators are not built and raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -49,6 +50,28 @@ class EADraws:
         return EADraws(*(t.to(device).contiguous() for t in (self.cross_rand, self.cross_idx, self.mut_rand, self.mut_idx)))
 
 
+@dataclass
+class EACvrpDraws:
+    """Random inputs of one CVRP EA.run over a batch (eamrl_ea_cvrp_run): uniforms in [0, 1) everywhere; integer
+    choices are lo + floor(u * (hi - lo)) inside the kernel because their ranges depend on the evolving tours."""
+    init_mut_rand: torch.Tensor  # [B, S]
+    init_mut_u: torch.Tensor     # [B, S, 3]
+    cross_rand: torch.Tensor     # [G, B, P]
+    cross_u: torch.Tensor        # [G, B, P]
+    mut_rand: torch.Tensor       # [G, B, O]
+    mut_u: torch.Tensor          # [G, B, O, 3]
+
+    @staticmethod
+    def sample(G, B, S, selection_rate, device, generator=None):
+        P = ops.ea_num_pairs(selection_rate, S)
+        r = lambda *shape: torch.rand(*shape, dtype=torch.float64, device=device, generator=generator)
+        return EACvrpDraws(r(B, S), r(B, S, 3), r(G, B, P), r(G, B, P), r(G, B, 2 * P), r(G, B, 2 * P, 3))
+
+    def to(self, device):
+        return EACvrpDraws(*(t.to(device).contiguous() for t in (self.init_mut_rand, self.init_mut_u, self.cross_rand,
+                                                                 self.cross_u, self.mut_rand, self.mut_u)))
+
+
 def generate_batch_population(routes: torch.Tensor, env_code: int = 1, pop_size: int = SINGLE_START_POP_SIZE):
     """[B, N] single tours -> [B, pop_size, N] (evolution.py:1574-1626): TSP (env_code 1) rotations of the tour --
     member 0 is the tour, member i starts at position i % N (position 1 where that is 0); other codes: copies."""
@@ -72,9 +95,9 @@ class EA:
         self.selection_rate = kwargs.get("selection_rate")
         self.method = kwargs.get("method", None)
         self.env_name = env.name
-        if self.env_name != "tsp":
-            if self.env_name in ("cvrp", "pctsp", "op", "ffsp"):
-                raise NotImplementedError(f"EA operators for {self.env_name} are not built (TSP only)")
+        if self.env_name not in ("tsp", "cvrp"):
+            if self.env_name in ("pctsp", "op", "ffsp"):
+                raise NotImplementedError(f"EA operators for {self.env_name} are not built (TSP and CVRP only)")
             raise ValueError(f"Unsupported env for EA operators: {self.env_name}")
         assert self.num_generations is not None, "Number of generations must be specified"
         assert self.mutation_rate is not None, "Mutation rate must be specified"
@@ -88,11 +111,12 @@ class EA:
             pop = pop[None]
         B, S, N = pop.shape
         rows = pop.permute(1, 0, 2).reshape(S * B, N).contiguous()      # (s b) order: row r reads instance r % B
-        return -ops.tour_length_reward(td["locs"].contiguous(), rows, with_depot=False).view(S, B).t()
+        return -ops.tour_length_reward(td["locs"].contiguous(), rows, with_depot=self.env_name == "cvrp").view(S, B).t()
 
     def get_fitness(self, pop, td):
-        N = pop.shape[-1]
-        return torch.tensor(np.float32(1.5 * N), device=pop.device) - self.get_cost(pop, td)
+        size = pop.shape[-1]                                             # chromosome length, as the reference
+        worst = np.float32((1.5 if self.env_name == "tsp" else 2.5) * size)
+        return torch.tensor(worst, device=pop.device) - self.get_cost(pop, td)
 
     # -- the run ----------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -102,6 +126,15 @@ class EA:
         pop = (init_pop[None] if squeeze else init_pop).to(torch.int64).contiguous().clone()
         B, S, N = pop.shape
         G = int(self.num_generations)
+        if self.env_name == "cvrp":
+            draws = (EACvrpDraws.sample(G, B, S, self.selection_rate, pop.device, generator) if draws is None
+                     else draws.to(pop.device))
+            fit = ops.ea_cvrp_run_(td["locs"].contiguous(), td["demand"].contiguous(),
+                                   td["vehicle_capacity"].reshape(B).to(torch.float32).contiguous(), pop, G,
+                                   float(self.mutation_rate), float(self.crossover_rate), float(self.selection_rate),
+                                   self.method == "am", draws.init_mut_rand, draws.init_mut_u, draws.cross_rand,
+                                   draws.cross_u, draws.mut_rand, draws.mut_u)
+            return (pop[0], fit[0]) if squeeze else (pop, fit)
         if draws is None:
             draws = EADraws.sample(G, B, S, N, self.selection_rate, pop.device, generator)
         else:
@@ -126,9 +159,7 @@ def evolution_worker(actions, _td, ea: EA, env, return_population: bool = False,
     if n_start > 1:
         pop = unbatchify(actions, n_start).contiguous()                     # [B, S, T]
     else:
-        if ea.env_name != "tsp":
-            raise NotImplementedError("single-start evolution is built for TSP only")
-        pop = generate_batch_population(actions, env_code=1)
+        pop = generate_batch_population(actions, env_code=1 if ea.env_name == "tsp" else 2)
     new_pop, _ = ea.run(pop, _td, draws=draws, generator=generator)
     if n_start > 1:
         new_actions = new_pop.permute(1, 0, 2).reshape(-1, new_pop.shape[-1])[:, 1:].contiguous()

@@ -296,6 +296,34 @@ def ea_tsp_run_(locs, pop, num_generations, mutation_rate, crossover_rate, selec
     return fitness
 
 
+def ea_cvrp_run_(locs, demand, vcap, pop, num_generations, mutation_rate, crossover_rate, selection_rate, top_k,
+                 init_mut_rand, init_mut_u, cross_rand, cross_u, mut_rand, mut_u):
+    """In place on pop [B, S, L] (int64 action rows, 0 = depot); returns fitness [B, S].  See include/eamrl.h."""
+    lib = _lib.load()
+    _chk(pop, "pop", torch.int64)
+    B, S, L = pop.shape
+    N = demand.shape[-1]
+    _chk(locs, "locs", torch.float32, (B, N + 1, 2))
+    _chk(demand, "demand", torch.float32, (B, N))
+    _chk(vcap, "vcap", torch.float32, (B,))
+    P = ea_num_pairs(selection_rate, S)
+    G = int(num_generations)
+    _chk(init_mut_rand, "init_mut_rand", torch.float64, (B, S))
+    _chk(init_mut_u, "init_mut_u", torch.float64, (B, S, 3))
+    if G > 0 and P > 0:
+        _chk(cross_rand, "cross_rand", torch.float64, (G, B, P))
+        _chk(cross_u, "cross_u", torch.float64, (G, B, P))
+        _chk(mut_rand, "mut_rand", torch.float64, (G, B, 2 * P))
+        _chk(mut_u, "mut_u", torch.float64, (G, B, 2 * P, 3))
+    fitness = torch.empty(B, S, device=pop.device, dtype=torch.float32)
+    nul = lambda t: _ptr(t) if (G > 0 and P > 0) else None
+    _lib.check(lib.eamrl_ea_cvrp_run(_ptr(locs), _ptr(demand), _ptr(vcap), _ptr(pop), _ptr(fitness), B, S, N, L, G,
+                                     float(mutation_rate), float(crossover_rate), float(selection_rate), int(bool(top_k)),
+                                     _ptr(init_mut_rand), _ptr(init_mut_u), nul(cross_rand), nul(cross_u),
+                                     nul(mut_rand), nul(mut_u), _stream(pop)), "eamrl_ea_cvrp_run")
+    return fitness
+
+
 class DecodeCache:
     """Device-resident decoder cache (struct eamrl_cache).
 

@@ -199,6 +199,23 @@ int eamrl_ea_tsp_run(const float* locs, int64_t* pop, float* fitness, int64_t B,
                      double mutation_rate, double crossover_rate, double selection_rate, const double* cross_rand,
                      const int32_t* cross_idx, const double* mut_rand, const int32_t* mut_idx, void* stream);
 
+/* EA.run for CVRP populations  [evolution.py:252-354; :364-370 (fitness = f32(2.5*L) - cost), :585-788
+ * (order_crossover_cvrp: the parent's first `end` routes, then the missing customers in index order, split by a
+ * float64 load against the capacity), :519-553 (inverse_mutate_cvrp: reverse a segment inside one route)].
+ *   locs [B][N+1][2] f32, depot first;  demand [B][N] f32 (normalised);  vcap [B] f32;
+ *   pop [B][S][L] i64 chromosomes = action rows, 0 = depot, zero-padded; in/out;  fitness [B][S] f32 out.
+ *   S <= 128, N <= 127, L <= 256, S*L <= 24000.  top_k != 0: the `method == "am"` replacement (S fittest of
+ *   population ++ offspring) even when the start nodes are distinct.
+ * An initial mutation pass precedes the generations (EA.run :273-274).  Draws are uniforms u in [0, 1);
+ * randint(lo, hi) = lo + min(floor(u*(hi-lo)), hi-lo-1):
+ *   init_mut_rand [B][S], init_mut_u [B][S][3] (route, segment start, segment end);
+ *   cross_rand [G][B][P], cross_u [G][B][P] (number of routes kept);  mut_rand [G][B][O], mut_u [G][B][O][3]. */
+int eamrl_ea_cvrp_run(const float* locs, const float* demand, const float* vcap, int64_t* pop, float* fitness, int64_t B,
+                      int S, int N, int L, int num_generations, double mutation_rate, double crossover_rate,
+                      double selection_rate, int top_k, const double* init_mut_rand, const double* init_mut_u,
+                      const double* cross_rand, const double* cross_u, const double* mut_rand, const double* mut_u,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

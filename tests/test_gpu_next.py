@@ -343,3 +343,80 @@ def test_evolution_worker_layouts():
     p0 = ea.generate_batch_population(greedy["actions"])
     for b in range(B):
         np.testing.assert_array_equal(p0[b].cpu().numpy(), eo.generate_population_tsp(greedy["actions"][b].cpu().numpy(), 50))
+
+
+def _cvrp_oracle_run(locs, demand, vcap, init, G, mr, cr, sr, d, top_k):
+    from oracle import ea_oracle as eo
+
+    dd = {k: getattr(d, k).cpu().numpy() for k in ("init_mut_rand", "init_mut_u", "cross_rand", "cross_u", "mut_rand", "mut_u")}
+    pops, fits = [], []
+    for b in range(locs.shape[0]):
+        u = {}
+        for i in range(dd["init_mut_u"].shape[1]):
+            for k in range(3):
+                u[(("init",), i, k)] = dd["init_mut_u"][b, i, k]
+        for g in range(G):
+            for p in range(dd["cross_u"].shape[2]):
+                u[(("cross", g), p, 0)] = dd["cross_u"][g, b, p]
+            for i in range(dd["mut_u"].shape[2]):
+                for k in range(3):
+                    u[(("mut", g), i, k)] = dd["mut_u"][g, b, i, k]
+        p, f = eo.ea_run_cvrp(locs[b], demand[b], vcap, init[b], G, mr, cr, sr, dd["init_mut_rand"][b],
+                              dd["cross_rand"][:, b], dd["mut_rand"][:, b], eo.StructuredDraws(u), top_k=top_k)
+        pops.append(p); fits.append(f)
+    return np.stack(pops), np.stack(fits)
+
+
+@pytest.mark.parametrize("name", ["ea_cvrp20_default", "ea_cvrp20_busy", "ea_cvrp50_am"])
+def test_ea_cvrp_kernel_reproduces_reference_run(name):
+    import eam_rl4co_amd as ea
+
+    g = golden(name)
+    B, M = g["locs"].shape[:2]
+    env = ea.get_env("cvrp", generator_params=dict(num_loc=M - 1))
+    td = ea.TensorDict({"locs": t(g["locs"]), "demand": t(g["demand"]),
+                        "vehicle_capacity": torch.full((B, 1), float(g["vehicle_capacity"]), device=DEV)}, batch_size=[B])
+    runner = ea.EA(env, dict(num_generations=int(g["num_generations"]), mutation_rate=float(g["mutation_rate"]),
+                             crossover_rate=float(g["crossover_rate"]), selection_rate=float(g["selection_rate"]),
+                             method="am" if int(g["top_k"]) else None))
+    d = ea.EACvrpDraws(t(g["init_mut_rand"]), t(g["init_mut_u"]), t(g["cross_rand"]), t(g["cross_u"]), t(g["mut_rand"]),
+                       t(g["mut_u"]))
+    pop, fit = runner.run(t(g["init_pop"]), td, draws=d)
+    np.testing.assert_array_equal(pop.cpu().numpy(), g["pop"])                  # the reference's evolved tours
+    np.testing.assert_allclose(fit.cpu().numpy(), g["fitness"], rtol=1e-5, atol=1e-5)
+    _, ofit = _cvrp_oracle_run(g["locs"], g["demand"], float(g["vehicle_capacity"]), g["init_pop"], int(g["num_generations"]),
+                               float(g["mutation_rate"]), float(g["crossover_rate"]), float(g["selection_rate"]), d,
+                               bool(g["top_k"]))
+    assert_bits_equal(fit, ofit, "fitness")
+    assert_bits_equal(runner.get_fitness(pop, td), ofit, "get_fitness")
+
+
+@pytest.mark.parametrize("N,S,B,G,top_k", [(5, 1, 2, 2, False), (8, 2, 3, 2, False), (20, 20, 4, 3, False), (20, 13, 3, 3, True),
+                                           (50, 40, 2, 2, False), (100, 100, 2, 2, False), (127, 60, 1, 2, True)])
+@pytest.mark.parametrize("rates", [(0.1, 0.6, 0.2), (0.9, 1.0, 1.0)])
+def test_ea_cvrp_kernel_matches_oracle_on_rollout_populations(N, S, B, G, top_k, rates):
+    """Populations = multistart sampled rollouts of the policy (real action rows with padding), evolved on the GPU
+    and by the oracle with the same uniforms: identical tours, bit-equal fitness, feasible results."""
+    import eam_rl4co_amd as ea
+
+    mr, cr, sr = rates
+    env = ea.get_env("cvrp", generator_params=dict(num_loc=N), seed=N)
+    torch.manual_seed(N + S)
+    td = env.reset(batch_size=[B]).to(DEV)
+    pol = make_policy("am_cvrp")
+    S_eff = min(S, N)
+    out = pol(td.clone(), env, phase="train", decode_type="multistart_sampling" if S_eff > 1 else "sampling",
+              **(dict(num_starts=S_eff) if S_eff > 1 else {}))
+    init = ea.unbatchify(out["actions"], S_eff).contiguous() if S_eff > 1 else out["actions"][:, None, :].contiguous()
+    runner = ea.EA(env, dict(num_generations=G, mutation_rate=mr, crossover_rate=cr, selection_rate=sr,
+                             method="am" if top_k else None))
+    gen = torch.Generator(device=DEV).manual_seed(N * 7 + S)
+    d = ea.EACvrpDraws.sample(G, B, S_eff, sr, DEV, gen)
+    pop, fit = runner.run(init, td, draws=d)
+    locs = td["locs"].cpu().numpy(); demand = td["demand"].cpu().numpy()
+    opop, ofit = _cvrp_oracle_run(locs, demand, 1.0, init.cpu().numpy(), G, mr, cr, sr, d, top_k)
+    np.testing.assert_array_equal(pop.cpu().numpy(), opop)
+    assert_bits_equal(fit, ofit, "fitness")
+    rows = pop.permute(1, 0, 2).reshape(-1, pop.shape[-1])
+    env.check_solution_validity(ea.batchify(td, S_eff) if S_eff > 1 else td, rows)      # feasible CVRP tours
+    # (no monotonicity claim: the reference mutates the whole initial population before the first selection)

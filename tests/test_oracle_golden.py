@@ -197,3 +197,43 @@ def test_ea_population_from_single_tour():
     pop = ea.generate_population_tsp(route, 7)
     assert pop[0].tolist() == route.tolist() and pop[1].tolist() == [0, 4, 1, 2, 3] and pop[5].tolist() == pop[1].tolist()
     assert pop[6].tolist() == [0, 4, 1, 2, 3]     # i % N == 1
+
+
+def _cvrp_rint(g, b):
+    from oracle import ea_oracle as ea
+
+    u = {}
+    S, P, O, G = g["init_mut_u"].shape[1], g["cross_u"].shape[2], g["mut_u"].shape[2], g["cross_u"].shape[0]
+    for i in range(S):
+        for k in range(3):
+            u[(("init",), i, k)] = g["init_mut_u"][b, i, k]
+    for gg in range(G):
+        for p in range(P):
+            u[(("cross", gg), p, 0)] = g["cross_u"][gg, b, p]
+        for i in range(O):
+            for k in range(3):
+                u[(("mut", gg), i, k)] = g["mut_u"][gg, b, i, k]
+    return ea.StructuredDraws(u)
+
+
+@pytest.mark.parametrize("name", ["ea_cvrp20_default", "ea_cvrp20_busy", "ea_cvrp50_am"])
+def test_ea_cvrp_run_matches_reference(name):
+    """EA.run of the reference on CVRP (its operators with recorded draws, numba's float64 load accumulator emulated,
+    see make_golden_ea.py) vs the restatement driven by per-slot uniforms: identical populations."""
+    from oracle import ea_oracle as ea
+
+    g = golden(name)
+    for b in range(g["locs"].shape[0]):
+        pop, fit = ea.ea_run_cvrp(g["locs"][b], g["demand"][b], float(g["vehicle_capacity"]), g["init_pop"][b],
+                                  int(g["num_generations"]), float(g["mutation_rate"]), float(g["crossover_rate"]),
+                                  float(g["selection_rate"]), g["init_mut_rand"][b], g["cross_rand"][:, b],
+                                  g["mut_rand"][:, b], _cvrp_rint(g, b), top_k=bool(g["top_k"]))
+        np.testing.assert_array_equal(pop, g["pop"][b])
+        np.testing.assert_allclose(fit, g["fitness"][b], rtol=1e-5, atol=1e-5)
+        N = g["demand"].shape[1]
+        for row in pop:      # every customer exactly once, every route within the capacity
+            assert sorted(x for x in row.tolist() if x) == list(range(1, N + 1))
+            load = 0.0
+            for x in row:
+                load = 0.0 if x == 0 else load + float(g["demand"][b, x - 1])
+                assert load <= float(g["vehicle_capacity"]) + 1e-5
