@@ -191,3 +191,45 @@ def reinforce_loss(policy, env, td, baseline: str = "shared", num_starts: int = 
         loss = -(reward * ll).mean()
     return {"loss": loss, "reward": reward, "log_likelihood": ll, "actions": actions, "logp_steps": logp,
             "native_log_likelihood": out["log_likelihood"]}
+
+
+def eam_loss(policy, env, td, ea, num_starts: int, improve: bool = True, draws=None, generator=None):
+    """One EAM training step of the fork with the POMO (shared) baseline (rl4co/models/zoo/earl/model.py:129-247):
+
+    1. sampled multistart rollout on the native path (no grad);
+    2. the sampled tours are improved by the evolutionary operators on the GPU (`evolution_worker`; the reference
+       ships them to CPU threads, model.py:166-171) and get their start column back (`_align_improved_actions`);
+    3. both sets of tours are re-evaluated with autograd (`evaluate_log_likelihood`, the reference's
+       `policy(..., actions=improved)`, model.py:189-195);
+    4. REINFORCE with the per-instance mean over starts as baseline, over the concatenation [original; improved]
+       treated as 2B instances (model.py:226-244, reinforce.py:103-106).
+
+    Returns dict(loss, reward, improved_reward, log_likelihood, improved_log_likelihood, actions, improved_actions)."""
+    from .evolution import evolution_worker
+    from .utils import batchify
+
+    S = int(num_starts)
+    assert S > 1, "the EAM step uses the multistart (shared) baseline"
+    was_training = policy.training
+    policy.eval()
+    with torch.no_grad():
+        out = policy(td, env, phase="train", decode_type="multistart_sampling", num_starts=S)
+    policy.train(was_training)
+    actions, reward = out["actions"], out["reward"]
+    ll = evaluate_log_likelihood(policy, td, env, actions, num_starts=S).sum(1)
+    rs, lls = [unbatchify(reward, S)], [unbatchify(ll, S)]
+    res = {"reward": reward, "log_likelihood": ll, "actions": actions}
+    if improve:
+        with torch.no_grad():
+            improved, _ = evolution_worker(actions, td, ea, env, draws=draws, generator=generator)
+            if improved.shape[-1] + 1 == actions.shape[-1]:          # _align_improved_actions
+                improved = torch.cat([actions[:, :1], improved], dim=-1)
+            r_imp = env.get_reward(batchify(td, S), improved)
+        ll_imp = evaluate_log_likelihood(policy, td, env, improved, num_starts=S).sum(1)
+        rs.append(unbatchify(r_imp, S))
+        lls.append(unbatchify(ll_imp, S))
+        res.update(improved_actions=improved, improved_reward=r_imp, improved_log_likelihood=ll_imp)
+    r_all, ll_all = torch.cat(rs, 0), torch.cat(lls, 0)              # [B or 2B, S]
+    adv = r_all - r_all.mean(1, keepdim=True)
+    res["loss"] = -(adv * ll_all).mean()
+    return res

@@ -420,3 +420,33 @@ def test_ea_cvrp_kernel_matches_oracle_on_rollout_populations(N, S, B, G, top_k,
     rows = pop.permute(1, 0, 2).reshape(-1, pop.shape[-1])
     env.check_solution_validity(ea.batchify(td, S_eff) if S_eff > 1 else td, rows)      # feasible CVRP tours
     # (no monotonicity claim: the reference mutates the whole initial population before the first selection)
+
+
+@pytest.mark.parametrize("env_name,cfg,N", [("tsp", "pomo_tsp", 20), ("cvrp", "am_cvrp", 20)])
+def test_eam_training_step(env_name, cfg, N):
+    """The fork's training step end to end on the GPU: sampled rollout -> evolution -> re-evaluation -> loss.
+    The autograd log-likelihood of the improved tours equals the native teacher-forced evaluation (1e-4)."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import train
+
+    B, S = 6, 10
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=3)
+    torch.manual_seed(3)
+    td = env.reset(batch_size=[B]).to(DEV)
+    pol = make_policy(cfg)
+    runner = ea.EA(env, dict(num_generations=3, mutation_rate=0.3, crossover_rate=0.8, selection_rate=0.6))
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    res = train.eam_loss(pol, env, td.clone(), runner, num_starts=S, generator=gen)
+    assert torch.isfinite(res["loss"])
+    res["loss"].backward()
+    g = pol.encoder.init_embedding.init_embed.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+    imp = res["improved_actions"]
+    assert imp.shape == res["actions"].shape and torch.equal(imp[:, 0], res["actions"][:, 0])
+    env.check_solution_validity(ea.batchify(td, S), imp)
+    if env_name == "tsp":
+        assert (res["improved_reward"] >= res["reward"] - 1e-6).all() and (res["improved_reward"] > res["reward"] + 1e-6).any()
+    native = pol(td.clone(), env, phase="train", num_starts=S, actions=imp)      # policy(..., actions=improved)
+    assert torch.equal(native["reward"], res["improved_reward"])
+    np.testing.assert_allclose(native["log_likelihood"].cpu().numpy(), res["improved_log_likelihood"].detach().cpu().numpy(),
+                               rtol=1e-4, atol=1e-4)
