@@ -43,6 +43,12 @@ WORKLOADS = {
 }
 POMO_KW = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+F32_PEAK_TFLOPS = 157.3  # dense fp32 (vector = f32 MFMA) peak, same guide
+
+
+def algorithmic_flops_per_query_step(M, E=128):
+    """6*M*E (QK^T, AV, logits) + 2*(2E)*E (context projection) + 2*E*E (output projection)."""
+    return 6 * M * E + 4 * E * E + 2 * E * E
 
 
 def algorithmic_bytes_per_decode_step(env, M, E=128, S=1):
@@ -211,6 +217,21 @@ def main():
         T = float(np.mean(decode_steps))
         alg_bytes = algorithmic_bytes_per_decode_step(env_name, M, S=S) * batch * T
         achieved = alg_bytes / (kern * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, batch),
+                    "kernel": "decode loop (eamrl_am_rollout)", "kernel_ms": round(kern, 4),
+                    "algorithmic_bytes_per_launch": int(alg_bytes)}
+        if S > 1:
+            # S queries share one K/V/L tile: 63 flop/B, beyond the fp32 ridge -> priced against the fp32 peak
+            # (SURVEY.md 8d); the HBM view is kept next to it
+            flops = algorithmic_flops_per_query_step(M) * batch * S * T
+            tf = flops / (kern * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "kernel": "decode loop (eamrl_am_rollout), fp32 VALU: one workgroup per row, starts of an "
+                                  "instance looped on register-resident K/V/L",
+                        "kernel_ms": round(kern, 4), "algorithmic_flops_per_launch": int(flops),
+                        "hbm_view": {"achieved_GBs": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4)}}
         line = {
             "metric": "env-steps/sec (batch x num_loc / s), AttentionModel construction rollout",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -221,10 +242,7 @@ def main():
                                    f"(encoder + cache + decode loop + reward)",
                        "decode_steps": T, "reward_mean": round(float(out["reward"].mean()), 4),
                        "launch": "eager" if args.no_graph else "hipGraph replay"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, batch),
-                         "kernel": "decode loop (eamrl_am_rollout)", "kernel_ms": round(kern, 4),
-                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(env_name, num_loc, decode_type, num_starts=S if S > 1 else 0, pomo=pomo)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs on the MI355X box (through gpurun): the GPU test suite, the bench lines of every workload, a rocprofv3
+# kernel-stats pass and the two PMC passes (FETCH_SIZE, WRITE_SIZE; separately, as MI355X_MICROARCH.md prescribes)
+# of the headline workload.  Everything lands in gpurun_out/<tag>/; copy what is cited into profiles/.
+#   usage: bash tools/collect_profiles.sh r01h
+set -o pipefail
+TAG=${1:-run}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "exit=$?" >> $OUT/pytest_gpu.log
+tail -3 $OUT/pytest_gpu.log
+grep -q "exit=0" $OUT/pytest_gpu.log || exit 1
+timeout -k 10 400 python bench.py --steps 20 --warmup 3 > $OUT/bench_tsp100.json 2> $OUT/bench_tsp100.err || exit 1
+for w in tsp20 cvrp100 cvrp500 pomo100; do
+  timeout -k 10 400 python bench.py --workload $w --steps 10 --warmup 2 > $OUT/bench_$w.json 2> $OUT/bench_$w.err || echo "bench $w failed"
+done
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-graph > $OUT/stats.log 2>&1 || echo "stats pass failed"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $OUT/pmc_$c.log 2>&1 || echo "pmc $c failed"
+done
+find $OUT -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
+cut -c1-250 $OUT/bench_*.json
