@@ -528,6 +528,117 @@ __global__ __launch_bounds__(256) void k_mha_encoder_x2(const float* __restrict_
     }
 }
 
+// Large graphs (N > 127): the blocked kernel with the keys tiled through LDS.  One block = (instance, group of 4
+// heads, block of 128 query rows); a thread owns the query rows (i0, i0 + 64) of one head.  Pass 1 walks all key tiles
+// for the row maxima, pass 2 walks them again in ascending order for exp / Z / PV, so every sum keeps the canonical
+// ascending-key order of k_mha_encoder (accumulators simply carry across tiles).
+constexpr int MHA_TK = 128;     // keys per LDS tile
+__global__ __launch_bounds__(256) void k_mha_encoder_tiled(const float* __restrict__ qkv, float* __restrict__ out, int N, int E,
+                                                           int H)
+{
+    constexpr int D = 16, HG = 4, W = HG * D;
+    __shared__ __attribute__((aligned(16))) float ks[MHA_TK * W];
+    __shared__ __attribute__((aligned(16))) float vs[MHA_TK * W];
+    const int groups = H / HG;
+    const int qblocks = (N + 127) / 128;
+    const int qb = blockIdx.x % qblocks;
+    const int64_t bg = blockIdx.x / qblocks;
+    const int64_t b = bg / groups;
+    const int h0 = (int)(bg - b * groups) * HG;
+    const float* base = qkv + b * (int64_t)N * 3 * E;
+    const int hh = threadIdx.x >> 6, pr = threadIdx.x & 63;
+    const int i0 = qb * 128 + pr, i1 = i0 + 64;
+    const bool has0 = i0 < N, has1 = i1 < N;
+    const int i0c = has0 ? i0 : N - 1, i1c = has1 ? i1 : N - 1;
+    f32x2 q2[D];
+    {
+        const float* p0 = base + (int64_t)i0c * 3 * E + (h0 + hh) * D;
+        const float* p1 = base + (int64_t)i1c * 3 * E + (h0 + hh) * D;
+#pragma unroll
+        for (int d = 0; d < D; d += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(p0 + d);
+            const float4 c = *reinterpret_cast<const float4*>(p1 + d);
+            q2[d] = (f32x2){a.x, c.x} * 0.25f; q2[d + 1] = (f32x2){a.y, c.y} * 0.25f;
+            q2[d + 2] = (f32x2){a.z, c.z} * 0.25f; q2[d + 3] = (f32x2){a.w, c.w} * 0.25f;
+        }
+    }
+    const float* kh = ks + hh * D;
+    const float* vh = vs + hh * D;
+    f32x2 m2 = splat2(-INFINITY);
+    for (int j0 = 0; j0 < N; j0 += MHA_TK) {
+        const int nj = N - j0 < MHA_TK ? N - j0 : MHA_TK;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nj * (W / 4); i += 256) {
+            const int n = i / (W / 4), c4 = i - n * (W / 4);
+            *reinterpret_cast<float4*>(ks + n * W + 4 * c4) =
+                *reinterpret_cast<const float4*>(base + (int64_t)(j0 + n) * 3 * E + E + h0 * D + 4 * c4);
+        }
+        __syncthreads();
+        for (int j = 0; j < nj; ++j) {
+            f32x2 a2 = splat2(0.0f);
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const float4 kk = *reinterpret_cast<const float4*>(kh + j * W + d);
+                a2 = pk_fma(q2[d], splat2(kk.x), a2);
+                a2 = pk_fma(q2[d + 1], splat2(kk.y), a2);
+                a2 = pk_fma(q2[d + 2], splat2(kk.z), a2);
+                a2 = pk_fma(q2[d + 3], splat2(kk.w), a2);
+            }
+            m2.x = __builtin_fmaxf(m2.x, a2.x);
+            m2.y = __builtin_fmaxf(m2.y, a2.y);
+        }
+    }
+    f32x2 Z2 = splat2(0.0f), o2[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) o2[d] = splat2(0.0f);
+    for (int j0 = 0; j0 < N; j0 += MHA_TK) {
+        const int nj = N - j0 < MHA_TK ? N - j0 : MHA_TK;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nj * (W / 4); i += 256) {
+            const int n = i / (W / 4), c4 = i - n * (W / 4);
+            const float* src = base + (int64_t)(j0 + n) * 3 * E + E + h0 * D + 4 * c4;
+            *reinterpret_cast<float4*>(ks + n * W + 4 * c4) = *reinterpret_cast<const float4*>(src);
+            *reinterpret_cast<float4*>(vs + n * W + 4 * c4) = *reinterpret_cast<const float4*>(src + E);
+        }
+        __syncthreads();
+        for (int j = 0; j < nj; ++j) {
+            f32x2 a2 = splat2(0.0f);
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const float4 kk = *reinterpret_cast<const float4*>(kh + j * W + d);
+                a2 = pk_fma(q2[d], splat2(kk.x), a2);
+                a2 = pk_fma(q2[d + 1], splat2(kk.y), a2);
+                a2 = pk_fma(q2[d + 2], splat2(kk.z), a2);
+                a2 = pk_fma(q2[d + 3], splat2(kk.w), a2);
+            }
+            const f32x2 w2 = d_expf2_nonpos(a2 - m2);
+            Z2 = Z2 + w2;
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const float4 vv = *reinterpret_cast<const float4*>(vh + j * W + d);
+                o2[d] = pk_fma(w2, splat2(vv.x), o2[d]);
+                o2[d + 1] = pk_fma(w2, splat2(vv.y), o2[d + 1]);
+                o2[d + 2] = pk_fma(w2, splat2(vv.z), o2[d + 2]);
+                o2[d + 3] = pk_fma(w2, splat2(vv.w), o2[d + 3]);
+            }
+        }
+    }
+    if (has0) {
+        float* op0 = out + (b * N + i0) * (int64_t)E + (h0 + hh) * D;
+#pragma unroll
+        for (int d = 0; d < D; d += 4)
+            *reinterpret_cast<float4*>(op0 + d) =
+                make_float4(o2[d].x / Z2.x, o2[d + 1].x / Z2.x, o2[d + 2].x / Z2.x, o2[d + 3].x / Z2.x);
+    }
+    if (has1) {
+        float* op1 = out + (b * N + i1) * (int64_t)E + (h0 + hh) * D;
+#pragma unroll
+        for (int d = 0; d < D; d += 4)
+            *reinterpret_cast<float4*>(op1 + d) =
+                make_float4(o2[d].y / Z2.y, o2[d + 1].y / Z2.y, o2[d + 2].y / Z2.y, o2[d + 3].y / Z2.y);
+    }
+}
+
 int launch_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H, hipStream_t st)
 {
     const int D = E / H;
@@ -540,6 +651,12 @@ int launch_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, in
     if (D == 16 && H % 4 == 0 && 2 * (N + 1) <= 256 && !g_debug[3] && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0) {
         const size_t lds2 = (size_t)2 * N * 64 * sizeof(float);
         hipLaunchKernelGGL(k_mha_encoder_x2, dim3((unsigned)(B * (H / 4))), dim3(256), lds2, st, qkv, out, N, E, H);
+        return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+    }
+    if (D == 16 && H % 4 == 0 && !g_debug[3] && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
+        B * (H / 4) * ((N + 127) / 128) <= 0x7fffffffLL) {              // large graphs: keys tiled through LDS
+        const unsigned nb = (unsigned)(B * (H / 4) * ((N + 127) / 128));
+        hipLaunchKernelGGL(k_mha_encoder_tiled, dim3(nb), dim3(256), 0, st, qkv, out, N, E, H);
         return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
     }
     if (D == 16) {

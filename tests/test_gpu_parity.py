@@ -140,7 +140,8 @@ def test_matrix_core_attention_is_bit_exact(oracle, N):
         _lib.load().eamrl_debug_set(7, 0)
 
 
-@pytest.mark.parametrize("B,N", [(3, 20), (2, 100), (2, 101), (1, 127), (1, 301)])
+@pytest.mark.parametrize("B,N", [(3, 20), (2, 100), (2, 101), (1, 127), (2, 128), (1, 129), (1, 256), (1, 257), (1, 301),
+                                 (1, 501)])
 def test_encoder_attention_norms_mean(oracle, B, N):
     from eam_rl4co_amd import ops
 
