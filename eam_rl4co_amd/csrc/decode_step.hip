@@ -17,6 +17,8 @@
 namespace eamrl {
 
 constexpr int BLOCK = 256;
+constexpr int DU2 = 8;    // score stage: (node, head) pairs whose key loads are in flight together
+constexpr int DU4 = 16;   // glimpse stage: value loads in flight per thread
 constexpr int NWAVE = BLOCK / EAMRL_WAVE;
 
 struct RowState {
@@ -68,6 +70,42 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
 
     // ---- D2 scores s[h][n] = chain_d(q, K) / sqrt(D) ------------------------------------------------
     const float qk_scale = 1.0f / __builtin_sqrtf((float)D);
+    if (D == 16) {
+    // DU2 (node, head) pairs per thread and trip: all 16 key loads of a trip are in flight before the first is used
+    // (this kernel lives on HBM / L2 latency; a load-use loop would expose it once per pair)
+    for (int p0 = tid; p0 < M * H; p0 += DU2 * BLOCK) {
+        float4 kk[DU2][4];
+        bool on[DU2];
+#pragma unroll
+        for (int u = 0; u < DU2; ++u) {
+            const int p = p0 + u * BLOCK;
+            const int pc = p < M * H ? p : M * H - 1;
+            const int n = pc / H, h = pc - n * H;
+            on[u] = p < M * H && l.msk[n] != 0;
+            const float* kp = K + (int64_t)n * ld + h * D;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4)
+                kk[u][d4] = on[u] ? *reinterpret_cast<const float4*>(kp + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < DU2; ++u) {
+            const int p = p0 + u * BLOCK;
+            if (p >= M * H) break;
+            const int n = p / H, h = p - n * H;
+            const float* qp = l.q + h * D;
+            float acc = 0.0f;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) {
+                acc = fma_(qp[4 * d4], kk[u][d4].x, acc);
+                acc = fma_(qp[4 * d4 + 1], kk[u][d4].y, acc);
+                acc = fma_(qp[4 * d4 + 2], kk[u][d4].z, acc);
+                acc = fma_(qp[4 * d4 + 3], kk[u][d4].w, acc);
+            }
+            l.w[h * M + n] = on[u] ? acc * qk_scale : -INFINITY;
+        }
+    }
+        __syncthreads();
+    } else {
     for (int p = tid; p < M * H; p += BLOCK) {
         const int n = p / H, h = p - n * H;
         float sc = -INFINITY;
@@ -86,7 +124,8 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         }
         l.w[h * M + n] = sc;
     }
-    __syncthreads();
+        __syncthreads();
+    }
 
     // ---- D3 per-head max, w = exp(s - max) -------------------------------------------------------------
     for (int h = wv; h < H; h += NWAVE) {
@@ -105,11 +144,21 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         const float* wh = l.w + h * M;
         const int n0 = g * C, n1 = min(M, n0 + C);
         float zg = 0.0f, ag = 0.0f;
-        for (int n = n0; n < n1; ++n) {
-            if (l.msk[n]) {
-                float wn = wh[n];
-                zg = zg + wn;
-                ag = fma_(wn, V[(int64_t)n * ld + e], ag);
+        // DU4 value loads in flight per thread; a masked node has w == +0 exactly, so adding its terms unconditionally
+        // (with v = 0 in place of the skipped load) leaves both sums bit-identical
+        for (int nb = n0; nb < n1; nb += DU4) {
+            float vv[DU4], ww[DU4];
+#pragma unroll
+            for (int u = 0; u < DU4; ++u) {
+                const int n = nb + u;
+                const bool onv = n < n1 && l.msk[n] != 0;
+                vv[u] = onv ? V[(int64_t)n * ld + e] : 0.0f;
+                ww[u] = onv ? wh[n] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < DU4; ++u) {
+                zg = zg + ww[u];
+                ag = fma_(ww[u], vv[u], ag);
             }
         }
         l.partA[g * E + e] = ag;
@@ -127,21 +176,56 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
 
     // ---- D5 logit partials over NCHUNK column chunks ---------------------------------------------------------
     const int EC = E / EAMRL_NCHUNK;
-    for (int p = tid; p < M * EAMRL_NCHUNK; p += BLOCK) {
-        const int n = p / EAMRL_NCHUNK, c = p - n * EAMRL_NCHUNK;
-        float cg = 0.0f;
-        if (l.msk[n]) {
-            const float* lp = Lp + (int64_t)n * ld + c * EC;
-            const float* hp = l.heads + c * EC;
-            for (int e = 0; e < EC; e += 4) {
-                float4 v = *reinterpret_cast<const float4*>(lp + e);
-                cg = fma_(hp[e], v.x, cg);
-                cg = fma_(hp[e + 1], v.y, cg);
-                cg = fma_(hp[e + 2], v.z, cg);
-                cg = fma_(hp[e + 3], v.w, cg);
+    if (EC == 32) {
+        // two (node, column chunk) pairs per trip: 16 float4 loads in flight
+        for (int p0 = tid; p0 < M * EAMRL_NCHUNK; p0 += 2 * BLOCK) {
+            float4 lv[2][8];
+            bool on[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int p = p0 + u * BLOCK;
+                const int pc = p < M * EAMRL_NCHUNK ? p : M * EAMRL_NCHUNK - 1;
+                const int n = pc / EAMRL_NCHUNK, c = pc - n * EAMRL_NCHUNK;
+                on[u] = p < M * EAMRL_NCHUNK && l.msk[n] != 0;
+                const float* lp = Lp + (int64_t)n * ld + c * EC;
+#pragma unroll
+                for (int e4 = 0; e4 < 8; ++e4)
+                    lv[u][e4] = on[u] ? *reinterpret_cast<const float4*>(lp + 4 * e4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int p = p0 + u * BLOCK;
+                if (p >= M * EAMRL_NCHUNK) break;
+                const int c = p % EAMRL_NCHUNK;
+                const float* hp = l.heads + c * EC;
+                float cg = 0.0f;
+#pragma unroll
+                for (int e4 = 0; e4 < 8; ++e4) {
+                    cg = fma_(hp[4 * e4], lv[u][e4].x, cg);
+                    cg = fma_(hp[4 * e4 + 1], lv[u][e4].y, cg);
+                    cg = fma_(hp[4 * e4 + 2], lv[u][e4].z, cg);
+                    cg = fma_(hp[4 * e4 + 3], lv[u][e4].w, cg);
+                }
+                l.partL[p] = cg;       // masked node: all-zero operands -> chain of exact zeros, as before
             }
         }
-        l.partL[p] = cg;
+    } else {
+        for (int p = tid; p < M * EAMRL_NCHUNK; p += BLOCK) {
+            const int n = p / EAMRL_NCHUNK, c = p - n * EAMRL_NCHUNK;
+            float cg = 0.0f;
+            if (l.msk[n]) {
+                const float* lp = Lp + (int64_t)n * ld + c * EC;
+                const float* hp = l.heads + c * EC;
+                for (int e = 0; e < EC; e += 4) {
+                    float4 v = *reinterpret_cast<const float4*>(lp + e);
+                    cg = fma_(hp[e], v.x, cg);
+                    cg = fma_(hp[e + 1], v.y, cg);
+                    cg = fma_(hp[e + 2], v.z, cg);
+                    cg = fma_(hp[e + 3], v.w, cg);
+                }
+            }
+            l.partL[p] = cg;
+        }
     }
     __syncthreads();
 
