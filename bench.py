@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the workload's batch is the GLOBAL batch, split over the ranks (default: weak, "
+                         "the batch is per GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,6 +160,10 @@ def main():
 
     env_name, num_loc, batch, decode_type = WORKLOADS[args.workload]
     batch = args.batch or batch
+    if args.strong:
+        if batch % world:
+            raise SystemExit(f"--strong: global batch {batch} is not divisible by {world} ranks")
+        batch //= world
     env = ea.get_env(env_name, generator_params=dict(num_loc=num_loc), seed=1234 + rank)
     torch.manual_seed(1234 + rank)
     td0 = env.reset(batch_size=[batch]).to(device)         # synthetic uniform-[0,1]^2 instances, resident in HBM
@@ -236,7 +243,7 @@ def main():
             "metric": "env-steps/sec (batch x num_loc / s), AttentionModel construction rollout",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{env_name.upper()} num_loc={num_loc} batch={batch}/GPU "
                                    + (f"x {S} starts POMO" if pomo else "AM") + f" {decode_type} rollout "
                                    f"(encoder + cache + decode loop + reward)",

@@ -108,10 +108,24 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             }
         }
         const float* Pc = (ENV == EAMRL_ENV_TSP ? a.Pb : a.Pa) + bi * M * ld;
-        for (int i = tid; i < M * (RE / 4); i += RB) {
-            const int row = i / (RE / 4), c4 = i - row * (RE / 4);
-            *reinterpret_cast<float4*>(Plds + row * RE + 4 * c4) =
-                *reinterpret_cast<const float4*>(Pc + (int64_t)row * ld + 4 * c4);
+        // context rows -> LDS, eight loads in flight per thread (a load-store loop would pay the latency 13 times)
+        for (int i0 = tid; i0 < M * (RE / 4); i0 += 8 * RB) {
+            float4 st[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * RB;
+                const int ic = i < M * (RE / 4) ? i : M * (RE / 4) - 1;
+                const int row = ic / (RE / 4), c4 = ic - row * (RE / 4);
+                st[u] = *reinterpret_cast<const float4*>(Pc + (int64_t)row * ld + 4 * c4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * RB;
+                if (i < M * (RE / 4)) {
+                    const int row = i / (RE / 4), c4 = i - row * (RE / 4);
+                    *reinterpret_cast<float4*>(Plds + row * RE + 4 * c4) = st[u];
+                }
+            }
         }
         for (int i = tid; i < RH * WROW; i += RB) l.w[i] = 0.0f;   // chunk padding stays 0 for the whole episode
     }
