@@ -108,14 +108,14 @@ def np_(t):
 
 def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_starts=None,
              keep_steps=None, keep_embeds=False, data_seed=1234, sample_seed=4321, actions=None,
-             td_init=None):
+             td_init=None, decode_kw=None):
     Env = TSPEnv if env_name == "tsp" else CVRPEnv
     env = Env(generator_params=dict(num_loc=num_loc), seed=data_seed)
     if td_init is None:
         torch.manual_seed(data_seed)
         td_init = env.reset(batch_size=[batch])
     policy = make_policy(env_name, **(policy_kw or {}))
-    kw = dict(decode_type=decode_type)
+    kw = dict(decode_type=decode_type, **(decode_kw or {}))
     if num_starts is not None:
         kw["num_starts"] = num_starts
     torch.manual_seed(sample_seed)
@@ -150,6 +150,8 @@ def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_st
     if policy_kw:
         for k, v in policy_kw.items():
             fx["policy_kw_" + k] = np.array(v)
+    for k, v in (decode_kw or {}).items():
+        fx["decode_kw_" + k] = np.array(v)
     if keep_embeds:
         cache = out["hidden"]  # PrecomputedCache after the decoder's pre_decoder_hook
         fx["init_embeds"] = np_(out["init_embeds"])
@@ -241,5 +243,25 @@ def main():
     run_env_case("env_cvrp100_random", "cvrp", 100, 4)
 
 
+def extra():
+    """Second batch of fixtures (python make_golden.py extra): graphs above 128 nodes (the streaming decode kernel and
+    the key-tiled attention), mid sizes, the POMO policy on CVRP, and non-default temperature / tanh clipping."""
+    first4 = [0, 1, 2, 3]
+    pomo = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False)
+    run_case("tsp50_greedy", "tsp", 50, 8, "greedy", keep_steps=first4, data_seed=50)
+    run_case("cvrp50_sampling", "cvrp", 50, 8, "sampling", keep_steps=first4, data_seed=51)
+    run_case("tsp200_greedy", "tsp", 200, 2, "greedy", keep_steps=first4 + [100, 199], data_seed=200)
+    run_case("cvrp200_greedy", "cvrp", 200, 2, "greedy", keep_steps=first4 + [100], data_seed=201)
+    run_case("pomo_cvrp20_multistart_greedy", "cvrp", 20, 4, "multistart_greedy", policy_kw=pomo, num_starts=20,
+             keep_steps=first4, data_seed=21)
+    run_case("cvrp20_sampling_temp", "cvrp", 20, 4, "sampling", keep_steps=first4, data_seed=22,
+             decode_kw=dict(temperature=1.5, tanh_clipping=8.0))
+    run_case("tsp20_greedy_noclip", "tsp", 20, 4, "greedy", keep_steps=first4, data_seed=23,
+             decode_kw=dict(temperature=0.5, tanh_clipping=0.0))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        extra()
+    else:
+        main()

@@ -264,7 +264,9 @@ def test_decode_step_api_bit_exact_every_step(oracle, name):
 
 POLICY_CASES = ["tsp20_greedy", "tsp20_sampling", "tsp20_evaluate", "tsp20_multistart_greedy", "tsp100_greedy",
                 "tsp100_sampling", "cvrp20_greedy", "cvrp20_sampling", "cvrp20_evaluate", "cvrp20_multistart_greedy",
-                "cvrp100_greedy", "cvrp100_sampling", "pomo_tsp20_multistart_sampling"]
+                "cvrp100_greedy", "cvrp100_sampling", "pomo_tsp20_multistart_sampling",
+                "tsp50_greedy", "cvrp50_sampling", "tsp200_greedy", "cvrp200_greedy", "pomo_cvrp20_multistart_greedy",
+                "cvrp20_sampling_temp", "tsp20_greedy_noclip"]
 
 
 @pytest.mark.parametrize("stream_kernel", [0, 1])
@@ -291,6 +293,9 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
             decode_type = "multistart_" + decode_type
     if "noise" in fx:
         kw["noise"] = t(fx["noise"])
+    for k in ("temperature", "tanh_clipping"):
+        if "decode_kw_" + k in fx:
+            kw[k] = float(fx["decode_kw_" + k])
     lib = _lib.load()
     lib.eamrl_debug_set(1, stream_kernel)
     try:
@@ -303,7 +308,8 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
     o = oracle.policy_rollout(golden_weights(cfg), env_name, fx["locs"], fx.get("demand"),
                               decode_type=decode_type if "actions" not in kw else "evaluate", num_starts=ns,
                               noise=fx.get("noise"), given=fx["actions"] if "actions" in kw else None,
-                              use_graph_context=pol.decoder.use_graph_context)
+                              use_graph_context=pol.decoder.use_graph_context,
+                              clip=kw.get("tanh_clipping", 10.0), temp=kw.get("temperature", 1.0))
     assert_bits_equal(out["log_likelihood"], o["logp_steps"], "per-step logp vs oracle")
     assert_bits_equal(out["reward"], o["reward"], "reward vs oracle")
 

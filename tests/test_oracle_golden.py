@@ -17,6 +17,9 @@ POLICY_CASES = [
     "tsp20_greedy", "tsp20_sampling", "tsp20_evaluate", "tsp20_multistart_greedy", "tsp100_greedy", "tsp100_sampling",
     "cvrp20_greedy", "cvrp20_sampling", "cvrp20_evaluate", "cvrp20_multistart_greedy", "cvrp100_greedy",
     "cvrp100_sampling", "pomo_tsp20_multistart_sampling",
+    # second batch: mid sizes, graphs above 128 nodes, POMO policy on CVRP, non-default temperature / clipping
+    "tsp50_greedy", "cvrp50_sampling", "tsp200_greedy", "cvrp200_greedy", "pomo_cvrp20_multistart_greedy",
+    "cvrp20_sampling_temp", "tsp20_greedy_noclip",
 ]
 
 
@@ -29,7 +32,8 @@ def _run(orc, fx):
         decode_type = "multistart_" + decode_type
     return orc.policy_rollout(
         sd, str(fx["env_name"]), fx["locs"], fx.get("demand"), decode_type=decode_type, num_starts=ns,
-        noise=fx.get("noise"), given=given, use_graph_context=bool(fx.get("policy_kw_use_graph_context", True)))
+        noise=fx.get("noise"), given=given, use_graph_context=bool(fx.get("policy_kw_use_graph_context", True)),
+        clip=float(fx.get("decode_kw_tanh_clipping", 10.0)), temp=float(fx.get("decode_kw_temperature", 1.0)))
 
 
 @pytest.mark.parametrize("name", POLICY_CASES)
