@@ -9,7 +9,7 @@
 
 using namespace eamrl;
 
-namespace eamrl { int g_debug[8] = {0}; }
+namespace eamrl { int g_debug[16] = {0}; }
 
 static thread_local char g_err[256] = "";
 
@@ -40,7 +40,7 @@ __attribute__((visibility("default"))) int eamrl_version(void) { return EAMRL_VE
 __attribute__((visibility("default"))) const char* eamrl_last_error(void) { return g_err; }
 __attribute__((visibility("default"))) int eamrl_debug_set(int key, int value)
 {
-    if (key < 0 || key >= 8) return fail(EAMRL_E_ARG, "eamrl_debug_set: unknown key %d", key);
+    if (key < 0 || key >= 16) return fail(EAMRL_E_ARG, "eamrl_debug_set: unknown key %d", key);
     g_debug[key] = value;
     return 0;
 }

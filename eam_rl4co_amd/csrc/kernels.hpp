@@ -15,7 +15,7 @@ struct GemmArgs {
     int dbg;   // profiling experiments only (eamrl_debug_set key 2)
 };
 
-extern int g_debug[8];   // eamrl_debug_set knobs
+extern int g_debug[16];   // eamrl_debug_set knobs
 
 int launch_linear(const GemmArgs& g, hipStream_t st);
 int launch_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H, hipStream_t st);

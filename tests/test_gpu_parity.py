@@ -81,7 +81,7 @@ def test_library_loads_and_shares_torch_stream():
 
 
 @pytest.mark.parametrize("rows,k,n", [(1, 256, 128), (77, 128, 384), (300, 512, 128), (513, 128, 640), (2500, 128, 128), (50, 6, 7),
-                                       (64, 129, 33), (9, 3, 128)])
+                                       (64, 129, 33), (9, 3, 128), (4100, 128, 384), (2049, 128, 512), (6000, 128, 128)])
 @pytest.mark.parametrize("variant", ["mfma64", "mfma128", "valu"])
 def test_linear_is_a_k_ordered_fma_chain(oracle, rows, k, n, variant):
     """MFMA (v_mfma_f32_32x32x2_f32, 64- and 128-row tiles) and VALU kernels all equal the oracle's fmaf chain."""
@@ -101,6 +101,8 @@ def test_linear_is_a_k_ordered_fma_chain(oracle, rows, k, n, variant):
         assert_bits_equal(y, oracle.linear(x, W, b), "linear")
         y = ops.linear(t(x), t(W), None, relu=True, residual=t(res))
         assert_bits_equal(y, res + oracle.linear(x, W, None, relu=True), "linear relu+res")
+        assert_bits_equal(ops.linear(t(x), t(W), t(b), relu=True), oracle.linear(x, W, b, relu=True), "linear relu")
+        assert_bits_equal(ops.linear(t(x), t(W), t(b), residual=t(res)), res + oracle.linear(x, W, b), "linear res")
         if k == n:
             assert_bits_equal(ops.matmul_right(t(x), t(W)), oracle.matmul_right(x, W), "matmul_right")
         g, bt = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
