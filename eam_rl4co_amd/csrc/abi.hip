@@ -88,7 +88,7 @@ __attribute__((visibility("default"))) int eamrl_linear(const float* x, int64_t 
     REQUIRE(rows >= 0 && in_dim > 0 && out_dim > 0, "eamrl_linear");
     REQUIRE(ldx >= in_dim && ldw >= in_dim && ldy >= out_dim && (!res || ldres >= out_dim), "eamrl_linear");
     REQUIRE((rows + 127) / 128 <= 0x7fffffffLL, "eamrl_linear");
-    GemmArgs g{x, ldx, W, ldw, 0, bias, res, ldres, y, ldy, rows, in_dim, out_dim, relu, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+    GemmArgs g{x, ldx, W, ldw, 0, bias, res, ldres, y, ldy, rows, in_dim, out_dim, relu, nullptr, nullptr, nullptr, nullptr, 0.f};
     return launched(launch_linear(g, (hipStream_t)stream), "eamrl_linear");
 }
 
@@ -102,7 +102,7 @@ __attribute__((visibility("default"))) int eamrl_linear_bn(const float* x, int64
     REQUIRE(rows >= 0 && in_dim > 0 && out_dim > 0, "eamrl_linear_bn");
     REQUIRE(ldx >= in_dim && ldw >= in_dim && ldy >= out_dim && (!res || ldres >= out_dim), "eamrl_linear_bn");
     REQUIRE((rows + 127) / 128 <= 0x7fffffffLL, "eamrl_linear_bn");
-    GemmArgs g{x, ldx, W, ldw, 0, bias, res, ldres, y, ldy, rows, in_dim, out_dim, 0, gamma, beta, mean, var, eps, 0};
+    GemmArgs g{x, ldx, W, ldw, 0, bias, res, ldres, y, ldy, rows, in_dim, out_dim, 0, gamma, beta, mean, var, eps};
     return launched(launch_linear(g, (hipStream_t)stream), "eamrl_linear_bn");
 }
 
@@ -112,7 +112,7 @@ __attribute__((visibility("default"))) int eamrl_matmul_right(const float* x, in
 {
     REQUIRE(x && Wt && y, "eamrl_matmul_right");
     REQUIRE(rows >= 0 && in_dim > 0 && out_dim > 0 && ldx >= in_dim && ldy >= out_dim, "eamrl_matmul_right");
-    GemmArgs g{x, ldx, Wt, out_dim, 1, nullptr, nullptr, 0, y, ldy, rows, in_dim, out_dim, 0, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+    GemmArgs g{x, ldx, Wt, out_dim, 1, nullptr, nullptr, 0, y, ldy, rows, in_dim, out_dim, 0, nullptr, nullptr, nullptr, nullptr, 0.f};
     return launched(launch_linear(g, (hipStream_t)stream), "eamrl_matmul_right");
 }
 
@@ -204,7 +204,7 @@ __attribute__((visibility("default"))) int eamrl_am_rollout(int env, const eamrl
     REQUIRE(actions && logps && steps_out && a.done && t_max > 0, "eamrl_am_rollout");
     if (env == EAMRL_ENV_CVRP) REQUIRE(a.visited && a.demand, "eamrl_am_rollout");
     if (mode == EAMRL_EVALUATE) REQUIRE(t_given > 0, "eamrl_am_rollout");
-    a.fuse_env = 1; a.t_max = t_max; a.t_given = t_given; a.dbg = g_debug[5];
+    a.fuse_env = 1; a.t_max = t_max; a.t_given = t_given;
     a.action = actions; a.logp = logps; a.steps_out = steps_out;
     if (!g_debug[1] && rollout_resident_supports(env, a))
         return launched(launch_rollout_resident(env, a, (hipStream_t)stream), "eamrl_am_rollout");

@@ -19,7 +19,6 @@ struct DecArgs {
     float clip, temp; int fuse_env; int t_max;
     int64_t* action; float* logp; float* logprobs_all; float* logits_raw;
     int32_t* steps_out; uint32_t* status;
-    int dbg;   // profiling experiments only (eamrl_debug_set key 5): phases of the resident kernel to skip
 };
 
 // LDS carve for one row handled by one workgroup.

@@ -356,7 +356,6 @@ __global__ void k_small_linear(GemmArgs g)
 int launch_linear(const GemmArgs& g0, hipStream_t st)
 {
     GemmArgs g = g0;
-    g.dbg = g_debug[2];
     const bool force_valu = g_debug[0] != 0;
     if (g.rows <= 0) return 0;
     if (g.in_dim <= 4) {

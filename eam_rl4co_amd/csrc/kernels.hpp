@@ -12,7 +12,6 @@ struct GemmArgs {
     int64_t rows; int in_dim, out_dim, relu;
     // optional fused BatchNorm1d(eval) on the output columns (applied after residual): all null or all set
     const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_var; float bn_eps;
-    int dbg;   // profiling experiments only (eamrl_debug_set key 2)
 };
 
 extern int g_debug[16];   // eamrl_debug_set knobs

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
 
         // ---- S1: scores, per-head max and softmax weights of heads 2w, 2w+1 for both nodes (all inside the wave) ----
         // Branch-free and written so that the two heads' chains, butterflies and exponentials interleave.
-        if (!(a.dbg & 1)) {
+        {
             float s0[2] = {0.0f, 0.0f}, s1[2] = {0.0f, 0.0f};
 #pragma unroll
             for (int d = 0; d < RD; d += 4) {
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         STAMP(0);
 
         // ---- S2: glimpse partials, column ve, chunks 2vg and 2vg+1 ----------------------------------------------------
-        if (!(a.dbg & 2)) {
+        {
             const int h = ve >> 4;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         STAMP(1);
 
         // ---- S4: lanes 0-31 finish the 32 glimpse values of column chunk w; then the logit partials of both nodes ----
-        if (!(a.dbg & 4)) {
+        {
             float* hw = l.headsw + wv * 32;
             if (lane < 32) {
                 const int e = wv * 32 + lane, h = e >> 4;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
 
         // ---- S5: one wavefront finishes the step: clip, mask, log-softmax, selection, env transition, next query -----
         if (wv == fw) {
-            if (!(a.dbg & 32)) __builtin_amdgcn_s_setprio(3);   // the serial section of the step: let it win issue arbitration
+            __builtin_amdgcn_s_setprio(3);   // the serial section of the step: let it win issue arbitration
             // both nodes of the lane go through the elementwise math side by side (packed fp32 instructions:
             // half the issue slots and two independent dependency chains for this single wavefront)
             float x[2], lpv[2];
@@ -336,7 +336,6 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                 const unsigned long long b0 = __ballot(in0 && lpv[0] == top), b1 = __ballot(in1 && lpv[1] == top);
                 sel = b0 ? __builtin_ctzll(b0) : 64 + (b1 ? __builtin_ctzll(b1) : 64);
             }
-            if (a.dbg & 8) sel = t;
             if (a.mode == EAMRL_EVALUATE) sel = (int)given;
             sel = __builtin_amdgcn_readfirstlane(sel);
             if (__ballot(nan_seen) != 0ull) st_flags |= EAMRL_ST_NAN_LOGITS;

@@ -52,7 +52,7 @@ def bench_mha(iters):
     print(f"mha_encoder B=1024 N=100: {us:8.1f} us")
 
 
-def bench_decode(iters, dbg, t_max=None):
+def bench_decode(iters, t_max=None):
     """Resident rollout kernel alone at TSP-100 B=1024 with random cache contents (timing only)."""
     import eam_rl4co_amd as ea
     from eam_rl4co_amd import _lib
@@ -65,7 +65,6 @@ def bench_decode(iters, dbg, t_max=None):
     buf = torch.randn(B, M, 6 * E, device=dev) * 0.3
     emb = torch.randn(B, M, E, device=dev)
     cache = ops.DecodeCache("tsp", buf, torch.randn(E, device=dev), torch.randn(B, E, device=dev), emb, 8)
-    _lib.load().eamrl_debug_set(5, dbg)
 
     states = [state_from_td("tsp", td0.clone(), 0) for _ in range(iters + 2)]
     torch.cuda.synchronize()
@@ -78,7 +77,7 @@ def bench_decode(iters, dbg, t_max=None):
         e1.record()
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1) * 1e3)
-    print(f"decode resident dbg={dbg:2d} t_max={t_max or M}: {sorted(times[2:])[len(times[2:]) // 2]:8.1f} us (median, events around ops.rollout)")
+    print(f"decode resident t_max={t_max or M}: {sorted(times[2:])[len(times[2:]) // 2]:8.1f} us (median, events around ops.rollout)")
 
 
 def bench_ea(iters):
@@ -101,11 +100,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--dbg", type=int, default=0)
     ap.add_argument("--bm128", type=int, default=0)
     a = ap.parse_args()
     from eam_rl4co_amd import _lib
-    _lib.load().eamrl_debug_set(2, a.dbg)
     _lib.load().eamrl_debug_set(4, a.bm128)
     if a.what in ("gemm", "all"):
         bench_gemm(a.iters)
@@ -114,8 +111,8 @@ def main():
     if a.what in ("ea", "all"):
         bench_ea(a.iters)
     if a.what in ("decode",):
-        for d, tm in ((0, None), (0, 1), (0, 11), (0, 51), (15, 1), (15, 51), (15, None)):
-            bench_decode(a.iters, d, tm)
+        for tm in (None, 1, 11, 51):
+            bench_decode(a.iters, tm)
 
 
 if __name__ == "__main__":
