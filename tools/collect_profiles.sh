@@ -21,5 +21,8 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $OUT/pmc_$c.log 2>&1 || echo "pmc $c failed"
 done
+# LDS and issue counters of the same launches (separate passes: a few counters per pass)
+timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_lds -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $OUT/pmc_lds.log 2>&1 || echo "pmc lds failed"
+timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_valu -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $OUT/pmc_valu.log 2>&1 || echo "pmc valu failed"
 find $OUT -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
 cut -c1-250 $OUT/bench_*.json
