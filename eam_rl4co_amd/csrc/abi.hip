@@ -240,6 +240,18 @@ __attribute__((visibility("default"))) int eamrl_check_solution(int env, const i
                     "eamrl_check_solution");
 }
 
+__attribute__((visibility("default"))) int eamrl_beam_topk(const float* logprobs, const float* parent, int64_t B, int beam_width,
+                                                          int M, int64_t* node, int32_t* beam, float* cum, float* step_logp,
+                                                          void* stream)
+{
+    REQUIRE(logprobs && parent && node && beam && cum && step_logp, "eamrl_beam_topk");
+    REQUIRE(B >= 0 && B <= 0x7fffffffLL && beam_width >= 1 && M >= 1 && (int64_t)beam_width * M <= 36000,
+            "eamrl_beam_topk (beam_width * M <= 36000)");
+    if (B == 0) return 0;
+    return launched(launch_beam_topk(logprobs, parent, B, beam_width, M, node, beam, cum, step_logp, (hipStream_t)stream),
+                    "eamrl_beam_topk");
+}
+
 __attribute__((visibility("default"))) int eamrl_ea_tsp_run(const float* locs, int64_t* pop, float* fitness, int64_t B,
                                                            int S, int N, int num_generations, double mutation_rate,
                                                            double crossover_rate, double selection_rate,

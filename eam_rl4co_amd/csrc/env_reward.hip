@@ -146,6 +146,54 @@ __global__ __launch_bounds__(256) void k_sum_logp(const float* logp, int64_t ld,
     if (tid < 64 && r0 + tid < R) out[r0 + tid] = s;
 }
 
+// BeamSearch._make_beam_step (rl4co/utils/decoding.py:573-608): per instance, the beam_width best of the
+// beam_width * M candidates  logprobs[w*B + b][n] + parent[w*B + b]  (rows in "(w b)" order), descending; ties go to
+// the lower flat index w*M + n.  One workgroup per instance: candidates in LDS, beam_width rounds of a block argmax.
+// Output row k*B + b: node, parent beam, cumulative log-prob and the step log-prob of the chosen (beam, node).
+__global__ __launch_bounds__(256) void k_beam_topk(const float* logprobs, const float* parent, int64_t B, int BW, int M,
+                                                   int64_t* node, int32_t* beam, float* cum, float* step_lp)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* val = reinterpret_cast<float*>(smem);                 // [BW * M]
+    float* redv = val + BW * M;                                   // [4]
+    int* redi = reinterpret_cast<int*>(redv + 4);                 // [4]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t b = blockIdx.x;
+    const int C = BW * M;
+    for (int c = tid; c < C; c += 256) {
+        const int w = c / M, n = c - w * M;
+        const int64_t r = (int64_t)w * B + b;
+        val[c] = logprobs[r * M + n] + parent[r];
+    }
+    __syncthreads();
+    for (int k = 0; k < BW; ++k) {
+        float best = -INFINITY;
+        int besti = 0x7fffffff;
+        for (int c = tid; c < C; c += 256) {                      // ascending c per thread: the first maximum is kept
+            const float v = val[c];
+            if (v == v && (besti == 0x7fffffff || v > best)) { best = v; besti = c; }      // NaN marks "taken"
+        }
+        wave_argmax(best, besti);
+        if (lane == 0) { redv[wv] = best; redi[wv] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            float bv = redv[0];
+            int bi = redi[0];
+            for (int i = 1; i < 4; ++i)
+                if (redi[i] != 0x7fffffff && (bi == 0x7fffffff || redv[i] > bv || (redv[i] == bv && redi[i] < bi))) { bv = redv[i]; bi = redi[i]; }
+            if (bi == 0x7fffffff) bi = 0;                          // unreachable for BW <= BW * M
+            const int w = bi / M, n = bi - w * M;
+            const int64_t r = (int64_t)k * B + b;
+            node[r] = n;
+            beam[r] = w;
+            cum[r] = bv;
+            step_lp[r] = logprobs[((int64_t)w * B + b) * M + n];
+            val[bi] = __builtin_nanf("");                          // taken
+        }
+        __syncthreads();
+    }
+}
+
 // One wavefront per row; "seen" bitmap in LDS (M <= 4096).
 __global__ __launch_bounds__(EB) void k_check_solution(int env, const int64_t* actions, const float* demand,
                                                        const float* vcap, int64_t R, int64_t B, int N, int T,
@@ -223,6 +271,18 @@ int launch_tour_length(const float* locs, const int64_t* actions, float* reward,
 int launch_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, hipStream_t st)
 {
     hipLaunchKernelGGL(k_sum_logp, dim3((unsigned)((R + 63) / 64)), dim3(256), 0, st, logp, ld, out, R, T);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_beam_topk(const float* logprobs, const float* parent, int64_t B, int BW, int M, int64_t* node, int32_t* beam,
+                     float* cum, float* step_lp, hipStream_t st)
+{
+    const size_t lds = ((size_t)BW * M + 8) * sizeof(float);
+    if (lds > 150 * 1024) return EAMRL_E_ARG;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_beam_topk),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return EAMRL_E_LAUNCH;
+    hipLaunchKernelGGL(k_beam_topk, dim3((unsigned)B), dim3(256), lds, st, logprobs, parent, B, BW, M, node, beam, cum, step_lp);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 

@@ -36,6 +36,8 @@ int launch_tour_length(const float* locs, const int64_t* actions, float* reward,
 int launch_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, hipStream_t st);
 int launch_check_solution(int env, const int64_t* actions, const float* demand, const float* vcap, int64_t R, int64_t B,
                           int N, int T, int32_t* bad, hipStream_t st);
+int launch_beam_topk(const float* logprobs, const float* parent, int64_t B, int BW, int M, int64_t* node, int32_t* beam,
+                     float* cum, float* step_lp, hipStream_t st);
 int launch_decode_step(int env, const DecArgs& a, hipStream_t st);
 int launch_rollout_stream(int env, const DecArgs& a, hipStream_t st);
 int launch_rollout_resident(int env, const DecArgs& a, hipStream_t st);

@@ -262,6 +262,25 @@ def check_solution(env_name, actions, demand=None, vcap=None, num_loc=None):
 # ------------------------------------------------------------------------------------------------------
 # decode
 # ------------------------------------------------------------------------------------------------------
+def beam_topk(logprobs, parent, B: int, beam_width: int):
+    """Per instance the beam_width best (beam, node) candidates of a beam-search step.
+    -> node [R] i64, beam [R] i32, cum [R] f32, step_logp [R] f32 with R = beam_width * B (rows "(w b)")."""
+    lib = _lib.load()
+    R, M = logprobs.shape
+    if R != beam_width * B:
+        raise ValueError("beam_topk: rows must be beam_width * B")
+    _chk(logprobs, "logprobs", torch.float32)
+    _chk(parent, "parent", torch.float32, (R,))
+    dev = logprobs.device
+    node = torch.empty(R, dtype=torch.int64, device=dev)
+    beam = torch.empty(R, dtype=torch.int32, device=dev)
+    cum = torch.empty(R, dtype=torch.float32, device=dev)
+    slp = torch.empty(R, dtype=torch.float32, device=dev)
+    _lib.check(lib.eamrl_beam_topk(_ptr(logprobs), _ptr(parent), B, beam_width, M, _ptr(node), _ptr(beam), _ptr(cum),
+                                   _ptr(slp), _stream(logprobs)), "eamrl_beam_topk")
+    return node, beam, cum, slp
+
+
 def ea_num_pairs(selection_rate: float, pop_size: int) -> int:
     """Crossover pairs per generation of EA.run (elites // 2; int(rate*S) elites, 0 -> all, S <= 2 -> all)."""
     if pop_size <= 2:
@@ -399,6 +418,14 @@ class RolloutState:
             self.used = torch.zeros(R, dtype=torch.float32, device=device)
             self.vcap = torch.ones(R, dtype=torch.float32, device=device)
             self.visited = torch.zeros(R, M, dtype=torch.uint8, device=device)
+
+    def reorder_(self, idx):
+        """Rows taken from rows `idx` (beam search: every beam continues the state of its parent beam).  vcap is
+        per instance and the row order keeps r % B, so it needs no reordering, nor does demand."""
+        for name in ("first", "cur", "istep", "done", "mask", "used", "visited"):
+            v = getattr(self, name)
+            if v is not None:
+                setattr(self, name, v.index_select(0, idx).contiguous())
 
     def struct(self):
         s = _lib.State()

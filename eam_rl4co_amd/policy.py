@@ -374,9 +374,9 @@ class AttentionModelPolicy(nn.Module):
         whole decode loop on the device, compute reward and log-likelihood.  Gradients are not produced here.
         Two halves: `_enqueue` launches every kernel without touching the host (it can be captured into a HIP
         graph, see GraphedRollout), `_finish` performs the rollout's single device->host sync and slices."""
-        return self._finish(self._enqueue(td, env, phase, calc_reward, return_actions, return_entropy, return_hidden,
-                                          return_init_embeds, return_sum_log_likelihood, actions, max_steps,
-                                          **decoding_kwargs))
+        p = self._enqueue(td, env, phase, calc_reward, return_actions, return_entropy, return_hidden,
+                          return_init_embeds, return_sum_log_likelihood, actions, max_steps, **decoding_kwargs)
+        return p["out"] if "out" in p else self._finish(p)     # beam search is host-driven and arrives finished
 
     def _enqueue(self, td, env, phase, calc_reward, return_actions, return_entropy, return_hidden, return_init_embeds,
                  return_sum_log_likelihood, actions, max_steps, **decoding_kwargs) -> dict:
@@ -392,9 +392,10 @@ class AttentionModelPolicy(nn.Module):
             given_type, decode_type = decode_type, "evaluate"
         elif decode_type is None:
             decode_type = getattr(self, f"{phase}_decode_type")
+        if decode_type == "beam_search":
+            return {"out": self._beam_search(td, env, decoding_kwargs, calc_reward, return_actions,
+                                             return_sum_log_likelihood, return_hidden, return_init_embeds, max_steps)}
         if decode_type not in DECODE_TYPES:
-            if decode_type == "beam_search":
-                raise NotImplementedError("beam_search is outside the MI355X rollout path")
             log.warning("Unknown decode type '%s'. Defaulting to sampling.", decode_type)
             decode_type = "sampling"
         temperature = decoding_kwargs.pop("temperature", self.temperature)
@@ -564,6 +565,93 @@ class AttentionModelPolicy(nn.Module):
         self._last_td = td_out   # final env state of the last rollout (the reference keeps it in a local)
         return out
 
+    def _beam_search(self, td, env, kw, calc_reward, return_actions, return_sum_log_likelihood, return_hidden,
+                     return_init_embeds, max_steps):
+        """decode_type="beam_search" (BeamSearch, rl4co/utils/decoding.py:468-608): the beams start from the
+        multistart nodes; every step keeps, per instance, the beam_width best (beam, node) continuations by cumulative
+        log-prob (`eamrl_beam_topk`), and each new beam inherits the state of its parent.  Host-driven step loop on
+        the step API, as the reference's; afterwards the tours are backtracked through the parent pointers."""
+        beam_width = kw.pop("beam_width", None)
+        select_best = kw.pop("select_best", True)
+        temperature = kw.pop("temperature", self.temperature)
+        tanh_clipping = kw.pop("tanh_clipping", self.tanh_clipping)
+        select_start_nodes_fn = kw.pop("select_start_nodes_fn", None)
+        for k in ("store_all_logp", "num_starts", "multistart"):
+            kw.pop(k, None)
+        if kw:
+            log.warning("ignored decoding kwargs: %s", list(kw))
+        BW = env.get_num_starts(td) if beam_width is None else int(beam_width)
+        assert BW > 1, "beam width must be larger than 1"
+        hidden, init_embeds = self.encoder(td)
+        cache = self.decoder._precompute_cache(hidden, num_starts=BW)
+        B = td.batch_size[0]
+        st = state_from_td(self.env_name, td, BW)
+        start = (select_start_nodes_fn(td, env, BW) if select_start_nodes_fn is not None
+                 else env.select_start_nodes(td, num_starts=BW)).to(torch.int64).contiguous()
+        if self.env_name == "tsp":
+            ops.tsp_step_(st.mask, st.first, st.cur, st.istep, start, st.done)
+        else:
+            ops.cvrp_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, start, st.mask, st.done)
+        dev = start.device
+        R, M = st.R, st.M
+        inst = torch.arange(B, device=dev).repeat(BW)
+        actions, step_lps = [start], [torch.zeros(R, dtype=torch.float32, device=dev)]
+        parents = [torch.zeros(R, dtype=torch.int64, device=dev)]
+        parent_lp = torch.zeros(R, dtype=torch.float32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        t_max = (M - 1) if self.env_name == "tsp" else 2 * M + 1
+        t_max = int(max(1, min(t_max, max_steps)))
+        t = 0
+        while t < t_max and not bool(st.done.all()):
+            _, _, all_lp, _, _ = ops.decode_step(st, cache, "greedy", clip=tanh_clipping, temp=temperature,
+                                                 fuse_env_step=False, want_logprobs=True, status=status)
+            node, beam, parent_lp, slp = ops.beam_topk(all_lp, parent_lp, B, BW)
+            beam = beam.to(torch.int64)
+            st.reorder_(inst + beam * B)
+            if self.env_name == "tsp":
+                ops.tsp_step_(st.mask, st.first, st.cur, st.istep, node, st.done)
+            else:
+                ops.cvrp_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, node, st.mask, st.done)
+            actions.append(node)
+            step_lps.append(slp)
+            parents.append(beam)
+            t += 1
+        ops.raise_on_status(int(status.item()))
+        if t == t_max and not bool(st.done.all()):
+            log.error("Exceeded maximum number of steps (%d) during decoding", t_max)
+        # backtrack (BeamSearch._backtrack): walk the parent pointers from the last step to the first
+        acts = torch.stack(actions, 1)
+        lps = torch.stack(step_lps, 1)
+        T = acts.shape[1]
+        cur_parent = parents[-1]
+        seq, seq_lp = [acts[:, -1]], [lps[:, -1]]
+        for k in range(T - 2, -1, -1):
+            idx = inst + cur_parent * B
+            seq.append(acts[idx, k])
+            seq_lp.append(lps[idx, k])
+            cur_parent = parents[k][idx]
+        actions_out = torch.stack(seq[::-1], 1).contiguous()
+        logprobs = torch.stack(seq_lp[::-1], 1).contiguous()
+        td_out = state_to_td(self.env_name, st, td)
+        if select_best:     # BeamSearch._select_best_beam
+            rewards = env.get_reward(td_out, actions_out)
+            best = unbatchify(rewards, BW).max(dim=-1).indices
+            flat = torch.arange(B, device=dev) + best * B
+            actions_out, logprobs = actions_out[flat].contiguous(), logprobs[flat].contiguous()
+            td_out = TensorDict({k: v[flat] for k, v in td_out.items()}, batch_size=[B])
+        if calc_reward:
+            td_out.set("reward", env.get_reward(td_out, actions_out))
+        out = {"reward": td_out["reward"],
+               "log_likelihood": ops.sum_logp(logprobs) if return_sum_log_likelihood else logprobs}
+        if return_actions:
+            out["actions"] = actions_out
+        if return_hidden:
+            out["hidden"] = cache
+        if return_init_embeds:
+            out["init_embeds"] = init_embeds
+        self._last_td = td_out
+        return out
+
     def _rollout_stepwise(self, st, cache, mode, noise, given, clip, temp, t_max):
         """Step-API loop (one fused decode+env launch per step) used when every step's full log-prob row
         is wanted (store_all_logp / return_entropy).  The loop condition is checked on the host each step,
@@ -645,8 +733,9 @@ class GraphedRollout:
 
     def __init__(self, policy: AttentionModelPolicy, env: RL4COEnvBase, td_example, warmup: int = 2, phase="test",
                  **forward_kwargs):
-        if forward_kwargs.get("return_entropy") or forward_kwargs.get("store_all_logp") or forward_kwargs.get("select_best"):
-            raise NotImplementedError("GraphedRollout: step-wise / select_best rollouts are not capturable")
+        if (forward_kwargs.get("return_entropy") or forward_kwargs.get("store_all_logp") or forward_kwargs.get("select_best")
+                or forward_kwargs.get("decode_type") == "beam_search"):
+            raise NotImplementedError("GraphedRollout: step-wise / select_best / beam-search rollouts are not capturable")
         self.policy, self.env = policy, env
         self.kw = dict(phase=phase, calc_reward=True, return_actions=True, return_entropy=False, return_hidden=False,
                        return_init_embeds=False, return_sum_log_likelihood=True, actions=None, max_steps=1_000_000)

@@ -179,6 +179,16 @@ int eamrl_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, 
 int eamrl_check_solution(int env, const int64_t* actions, const float* demand, const float* vcap, int64_t R,
                          int64_t B, int N, int T, int32_t* bad, void* stream);
 
+/* ---- beam search ------------------------------------------------------------------------------------------ */
+
+/* BeamSearch._make_beam_step  [rl4co/utils/decoding.py:573-608].  Rows in "(w b)" order, R = beam_width * B.
+ * logprobs [R][M] f32 (the step's log-probs of every row, -inf where masked), parent [R] f32 (cumulative log-prob of
+ * each beam).  For every instance the beam_width largest logprobs[w*B+b][n] + parent[w*B+b], descending, ties to
+ * the lower w*M + n; output row k*B + b: node [R] i64, beam [R] i32 (parent beam w), cum [R] f32 (new cumulative
+ * log-prob), step_logp [R] f32 (= logprobs of the chosen (beam, node)).  beam_width * M <= 36000. */
+int eamrl_beam_topk(const float* logprobs, const float* parent, int64_t B, int beam_width, int M, int64_t* node,
+                    int32_t* beam, float* cum, float* step_logp, void* stream);
+
 /* ---- evolutionary improvement (the fork's EA) ---------------------------------------------------------------- */
 
 /* EA.run for TSP populations  [rl4co/models/zoo/earl/evolution.py:252-354; operators :356-362 (fitness),

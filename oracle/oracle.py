@@ -370,3 +370,58 @@ def policy_rollout(sd, env_name, locs, demand=None, decode_type="greedy", num_st
     reward = tour_length_reward(locs, actions, with_depot=(env_name != "tsp"))
     return {"actions": actions, "logp_steps": logp, "log_likelihood": sum_logp(logp), "reward": reward,
             "steps": acts.shape[1], "embeddings": emb, "cache": cache}
+
+
+def policy_beam_search(sd, env_name, locs, demand=None, beam_width=None, select_best=True, use_graph_context=True,
+                       clip=10.0, temp=1.0, num_heads=8):
+    """decode_type="beam_search" restated (BeamSearch, rl4co/utils/decoding.py:468-608): beams start at the multistart
+    nodes; each step keeps per instance the beam_width best (beam, node) continuations by cumulative log-prob
+    (descending, ties to the lower beam*M + node), every new beam continues its parent's state; tours are recovered by
+    backtracking the parent pointers.  Returns dict(actions, logp_steps, log_likelihood, reward)."""
+    _, emb = encode(sd, env_name, locs, demand, num_heads)
+    cache = precompute(sd, env_name, emb, use_graph_context)
+    B, M = locs.shape[:2]
+    nloc = M if env_name == "tsp" else M - 1
+    BW = nloc if beam_width is None else int(beam_width)
+    st = State(env_name, locs, demand, num_starts=BW)
+    R = st.R
+    start = (np.repeat(np.arange(BW), B) % nloc + (0 if env_name == "tsp" else 1)).astype(np.int64)
+    st.step(start)
+    inst = np.tile(np.arange(B), BW)
+    actions, step_lps, parents = [start], [np.zeros(R, np.float32)], [np.zeros(R, np.int64)]
+    parent_lp = np.zeros(R, np.float32)
+    while not st.done.all():
+        _, _, _, logprobs = decode_step(st, cache, "greedy", clip=clip, temp=temp, num_heads=num_heads, want_all=True)
+        cand = (logprobs + parent_lp[:, None]).astype(np.float32)                     # [R, M]
+        flat = cand.reshape(BW, B, M).transpose(1, 0, 2).reshape(B, BW * M)          # [B, BW*M], index w*M + n
+        node = np.empty(R, np.int64); beam = np.empty(R, np.int64); new_parent = np.empty(R, np.float32)
+        for b in range(B):
+            order = np.lexsort((np.arange(BW * M), -flat[b].astype(np.float64)))[:BW]    # value desc, index asc
+            for k, c in enumerate(order):
+                node[k * B + b], beam[k * B + b], new_parent[k * B + b] = c % M, c // M, flat[b, c]
+        idx = inst + beam * B
+        slp = logprobs[idx, node]
+        for name in ("first", "cur", "istep", "done", "mask", "used", "visited"):
+            v = getattr(st, name)
+            if v is not None:
+                setattr(st, name, np.ascontiguousarray(v[idx]))
+        st.step(node)
+        actions.append(node); step_lps.append(slp.astype(np.float32)); parents.append(beam)
+        parent_lp = new_parent
+    acts = np.stack(actions, 1); lps = np.stack(step_lps, 1)
+    T = acts.shape[1]
+    cur_parent = parents[-1]
+    seq, seq_lp = [acts[:, -1]], [lps[:, -1]]
+    for k in range(T - 2, -1, -1):
+        idx = inst + cur_parent * B
+        seq.append(acts[idx, k]); seq_lp.append(lps[idx, k])
+        cur_parent = parents[k][idx]
+    actions_out = np.ascontiguousarray(np.stack(seq[::-1], 1))
+    logp = np.ascontiguousarray(np.stack(seq_lp[::-1], 1))
+    reward = tour_length_reward(locs, actions_out, with_depot=(env_name != "tsp"))
+    if select_best:
+        best = reward.reshape(BW, B).argmax(0)           # first maximum, as torch.max
+        flat_idx = np.arange(B) + best * B
+        actions_out, logp, reward = actions_out[flat_idx], logp[flat_idx], reward[flat_idx]
+    return {"actions": np.ascontiguousarray(actions_out), "logp_steps": np.ascontiguousarray(logp),
+            "log_likelihood": sum_logp(np.ascontiguousarray(logp)), "reward": reward}

@@ -260,8 +260,21 @@ def extra():
              decode_kw=dict(temperature=0.5, tanh_clipping=0.0))
 
 
+def beam():
+    """Third batch (python make_golden.py beam): decode_type="beam_search" of the reference."""
+    first4 = [0, 1, 2, 3]
+    run_case("tsp20_beam", "tsp", 20, 4, "beam_search", keep_steps=first4, data_seed=31, decode_kw=dict(select_best=True))
+    run_case("tsp20_beam5_all", "tsp", 20, 3, "beam_search", keep_steps=first4, data_seed=32,
+             decode_kw=dict(beam_width=5, select_best=False))
+    run_case("cvrp20_beam", "cvrp", 20, 4, "beam_search", keep_steps=first4, data_seed=33, decode_kw=dict(select_best=True))
+    run_case("tsp50_beam12_all", "tsp", 50, 2, "beam_search", keep_steps=first4, data_seed=34,
+             decode_kw=dict(beam_width=12, select_best=False))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+    if len(sys.argv) > 1 and sys.argv[1] == "beam":
+        beam()
+    elif len(sys.argv) > 1 and sys.argv[1] == "extra":
         extra()
     else:
         main()

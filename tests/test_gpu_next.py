@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import golden, golden_weights
+from _util import cfg_for, golden, golden_weights
 from test_gpu_parity import DEV, assert_bits_equal, make_policy, make_td, t
 
 pytestmark = pytest.mark.gpu
@@ -450,3 +450,48 @@ def test_eam_training_step(env_name, cfg, N):
     assert torch.equal(native["reward"], res["improved_reward"])
     np.testing.assert_allclose(native["log_likelihood"].cpu().numpy(), res["improved_log_likelihood"].detach().cpu().numpy(),
                                rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# beam search (decode_type="beam_search"): step API + eamrl_beam_topk
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,BW,M", [(1, 2, 3), (5, 20, 20), (3, 7, 101), (2, 128, 128), (4, 100, 101)])
+def test_beam_topk_kernel(B, BW, M):
+    from eam_rl4co_amd import ops
+
+    rng = np.random.default_rng(B * 100 + BW)
+    lp = rng.standard_normal((BW * B, M)).astype(np.float32)
+    lp[rng.random(lp.shape) < 0.4] = -np.inf                      # masked actions
+    lp[:, 0] = np.round(lp[:, 0])                                  # exact ties between beams
+    lp[:, 0][~np.isfinite(lp[:, 0])] = -3.0
+    parent = np.round(rng.standard_normal(BW * B)).astype(np.float32)
+    node, beam, cum, slp = ops.beam_topk(t(lp), t(parent), B, BW)
+    flat = (lp + parent[:, None]).reshape(BW, B, M).transpose(1, 0, 2).reshape(B, BW * M)
+    for b in range(B):
+        order = np.lexsort((np.arange(BW * M), -flat[b].astype(np.float64)))[:BW]
+        got = (beam.cpu().numpy()[b::B].astype(np.int64) * M + node.cpu().numpy()[b::B])
+        np.testing.assert_array_equal(got, order)
+        np.testing.assert_array_equal(cum.cpu().numpy()[b::B], flat[b, order])
+        np.testing.assert_array_equal(slp.cpu().numpy()[b::B], lp.reshape(BW, B, M)[order // M, b, order % M])
+
+
+@pytest.mark.parametrize("name", ["tsp20_beam", "tsp20_beam5_all", "cvrp20_beam", "tsp50_beam12_all"])
+def test_beam_search_reproduces_reference_tours(oracle, name):
+    fx = golden(name)
+    cfg = cfg_for(fx)
+    env_name = str(fx["env_name"])
+    pol = make_policy(cfg)
+    env, td = make_td(env_name, fx["locs"], fx.get("demand"))
+    kw = dict(select_best=bool(fx["decode_kw_select_best"]))
+    if "decode_kw_beam_width" in fx:
+        kw["beam_width"] = int(fx["decode_kw_beam_width"])
+    out = pol(td, env, phase="test", decode_type="beam_search", return_sum_log_likelihood=False, **kw)
+    assert_bits_equal(out["actions"], fx["actions"], "beam-search tours vs reference")
+    np.testing.assert_allclose(out["reward"].cpu().numpy(), fx["reward"], rtol=1e-6, atol=0)
+    o = oracle.policy_beam_search(golden_weights(cfg), env_name, fx["locs"], fx.get("demand"),
+                                  beam_width=kw.get("beam_width"), select_best=kw["select_best"])
+    assert_bits_equal(out["log_likelihood"], o["logp_steps"], "per-step logp vs oracle")
+    assert_bits_equal(out["reward"], o["reward"], "reward vs oracle")
+    # the reference's own shape test (tests/test_policy.py:61-76)
+    B = fx["locs"].shape[0]
+    assert out["reward"].shape == ((B,) if kw["select_best"] else (B * kw.get("beam_width", fx["locs"].shape[1]),))

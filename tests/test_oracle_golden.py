@@ -241,3 +241,15 @@ def test_ea_cvrp_run_matches_reference(name):
             for x in row:
                 load = 0.0 if x == 0 else load + float(g["demand"][b, x - 1])
                 assert load <= float(g["vehicle_capacity"]) + 1e-5
+
+
+@pytest.mark.parametrize("name", ["tsp20_beam", "tsp20_beam5_all", "cvrp20_beam", "tsp50_beam12_all"])
+def test_beam_search_matches_reference(oracle, name):
+    """decode_type="beam_search" of the reference (beam_width = num_loc or given, with and without select_best)."""
+    fx = golden(name)
+    bw = int(fx["decode_kw_beam_width"]) if "decode_kw_beam_width" in fx else None
+    out = oracle.policy_beam_search(golden_weights(cfg_for(fx)), str(fx["env_name"]), fx["locs"], fx.get("demand"),
+                                    beam_width=bw, select_best=bool(fx["decode_kw_select_best"]))
+    assert np.array_equal(out["actions"], fx["actions"]), "beam-search tours differ from the reference"
+    np.testing.assert_allclose(out["reward"], fx["reward"], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(out["logp_steps"], fx["logp_steps"], rtol=0, atol=1e-5)
