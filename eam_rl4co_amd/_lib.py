@@ -43,9 +43,9 @@ PROTOTYPES = {
     "eamrl_mha_encoder": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "eamrl_normalize": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp],
     "eamrl_mean_nodes": [_vp, _vp, _i64, _i32, _i32, _vp],
-    "eamrl_am_decode_step": [_i32, C.POINTER(Cache), C.POINTER(State), _i64, _i32, _vp, _vp, _f32, _f32, _i32,
+    "eamrl_am_decode_step": [_i32, C.POINTER(Cache), C.POINTER(State), _i64, _i32, _vp, _vp, _f32, _f32, _i32, _f32, _i32,
                              _vp, _vp, _vp, _vp, _vp, _vp],
-    "eamrl_am_rollout": [_i32, C.POINTER(Cache), C.POINTER(State), _i64, _i32, _vp, _vp, _i32, _f32, _f32, _i32,
+    "eamrl_am_rollout": [_i32, C.POINTER(Cache), C.POINTER(State), _i64, _i32, _vp, _vp, _i32, _f32, _f32, _i32, _f32, _i32,
                          _vp, _vp, _vp, _vp, _vp],
     "eamrl_tour_length": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
     "eamrl_sum_logp": [_vp, _i64, _vp, _i64, _i32, _vp],

@@ -143,7 +143,8 @@ __attribute__((visibility("default"))) int eamrl_mean_nodes(const float* emb, fl
 }
 
 static int fill_args(const char* what, int env, const eamrl_cache* c, const eamrl_state* s, int64_t R, int mode,
-                     const float* noise, const int64_t* given, float clip, float temp, uint32_t* status, DecArgs& a)
+                     const float* noise, const int64_t* given, float clip, float temp, int top_k, float top_p,
+                     uint32_t* status, DecArgs& a)
 {
     REQUIRE(c && s, what);
     REQUIRE(env == EAMRL_ENV_TSP || env == EAMRL_ENV_CVRP, what);
@@ -155,7 +156,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
     REQUIRE(((uintptr_t)c->K % 16 == 0) && ((uintptr_t)c->V % 16 == 0) && ((uintptr_t)c->Lp % 16 == 0), what);
     REQUIRE(R > 0 && R % c->B == 0 && R <= 0x7fffffffLL, what);
     REQUIRE(s->cur && s->mask && status, what);
-    REQUIRE(temp > 0.0f, what);
+    REQUIRE(temp > 0.0f && top_k >= 0 && top_p >= 0.0f && top_p <= 1.0f, what);
     if (env == EAMRL_ENV_TSP) REQUIRE(c->Pb && s->first && s->istep, what);
     if (env == EAMRL_ENV_CVRP) REQUIRE(s->used && s->vcap && c->M >= 2, what);
     if (mode == EAMRL_SAMPLE) REQUIRE(noise != nullptr, what);
@@ -165,20 +166,21 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
     a.ld = c->ld; a.B = c->B; a.M = c->M; a.E = c->E; a.H = c->H;
     a.first = s->first; a.cur = s->cur; a.istep = s->istep; a.used = s->used; a.vcap = s->vcap; a.demand = s->demand;
     a.mask = s->mask; a.visited = s->visited; a.done = s->done;
-    a.R = R; a.mode = mode; a.noise = noise; a.given = given; a.clip = clip; a.temp = temp; a.status = status;
+    a.R = R; a.mode = mode; a.noise = noise; a.given = given; a.clip = clip; a.temp = temp; a.top_k = top_k; a.top_p = top_p; a.status = status;
     return 0;
 }
 
 __attribute__((visibility("default"))) int eamrl_am_decode_step(int env, const eamrl_cache* cache_host,
                                                                const eamrl_state* state_host, int64_t R, int mode,
                                                                const float* noise, const int64_t* given, float tanh_clip,
-                                                               float temperature, int fuse_env_step, int64_t* action,
+                                                               float temperature, int top_k, float top_p,
+                                                               int fuse_env_step, int64_t* action,
                                                                float* logp, float* logprobs_all, float* logits_raw,
                                                                uint32_t* status, void* stream)
 {
     DecArgs a;
     int rc = fill_args("eamrl_am_decode_step", env, cache_host, state_host, R, mode, noise, given, tanh_clip, temperature,
-                       status, a);
+                       top_k, top_p, status, a);
     if (rc) return rc;
     REQUIRE(action && logp, "eamrl_am_decode_step");
     if (fuse_env_step) {
@@ -193,20 +195,21 @@ __attribute__((visibility("default"))) int eamrl_am_decode_step(int env, const e
 __attribute__((visibility("default"))) int eamrl_am_rollout(int env, const eamrl_cache* cache_host,
                                                            const eamrl_state* state_host, int64_t R, int mode,
                                                            const float* noise, const int64_t* given, int t_given,
-                                                           float tanh_clip, float temperature, int t_max,
-                                                           int64_t* actions, float* logps, int32_t* steps_out,
+                                                           float tanh_clip, float temperature, int top_k, float top_p,
+                                                           int t_max, int64_t* actions, float* logps, int32_t* steps_out,
                                                            uint32_t* status, void* stream)
 {
     DecArgs a;
     int rc = fill_args("eamrl_am_rollout", env, cache_host, state_host, R, mode, noise, given, tanh_clip, temperature,
-                       status, a);
+                       top_k, top_p, status, a);
     if (rc) return rc;
     REQUIRE(actions && logps && steps_out && a.done && t_max > 0, "eamrl_am_rollout");
     if (env == EAMRL_ENV_CVRP) REQUIRE(a.visited && a.demand, "eamrl_am_rollout");
     if (mode == EAMRL_EVALUATE) REQUIRE(t_given > 0, "eamrl_am_rollout");
     a.fuse_env = 1; a.t_max = t_max; a.t_given = t_given;
     a.action = actions; a.logp = logps; a.steps_out = steps_out;
-    if (!g_debug[1] && rollout_resident_supports(env, a))
+    const bool filtering = top_k > 0 || (top_p > 0.0f && top_p < 1.0f);        // only the streaming kernel filters
+    if (!g_debug[1] && !filtering && rollout_resident_supports(env, a))
         return launched(launch_rollout_resident(env, a, (hipStream_t)stream), "eamrl_am_rollout");
     return launched(launch_rollout_stream(env, a, (hipStream_t)stream), "eamrl_am_rollout");
 }

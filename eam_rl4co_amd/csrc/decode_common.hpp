@@ -17,6 +17,7 @@ struct DecArgs {
     // call
     int64_t R; int mode; const float* noise; const int64_t* given; int t_given;
     float clip, temp; int fuse_env; int t_max;
+    int top_k; float top_p;      // process_logits filtering (0 = off); handled by the step / streaming kernels
     int64_t* action; float* logp; float* logprobs_all; float* logits_raw;
     int32_t* steps_out; uint32_t* status;
 };

@@ -249,11 +249,66 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         tmax = __builtin_fmaxf(tmax, v);
     }
     if (nan_seen) atomicOr(a.status, EAMRL_ST_NAN_LOGITS);
-    const float mx = block_max(tmax, l.red);  // (syncs inside: partL reads above are complete)
+    float mx = block_max(tmax, l.red);  // (syncs inside: partL reads above are complete)
 
-    // ---- D7 log-softmax: lane-tree sum of exp(x - max) ------------------------------------------------------------------
+    // ---- D6b top-k / top-p filtering of the scaled logits (process_logits, rl4co/utils/decoding.py:110-136,170-176) -----
+    const bool use_topp = a.top_p > 0.0f && a.top_p < 1.0f;
+    if (a.top_k > 0 || use_topp) {
+        float* pp = l.partL;                      // [M] keep flags, then probabilities
+        float* srt = l.partL + M;                 // [M] probabilities in ascending (value, index) order -> remove flags
+        int* rk = reinterpret_cast<int*>(l.partL + 2 * M);
+        if (a.top_k > 0) {                        // keep n iff fewer than k entries are strictly larger (ties kept)
+            const int k = a.top_k < M ? a.top_k : M;
+            for (int n = tid; n < M; n += BLOCK) {
+                const float xn = l.x[n];
+                int cnt = 0;
+                for (int m = 0; m < M; ++m) cnt += (l.x[m] > xn);
+                pp[n] = (cnt < k) ? 1.0f : 0.0f;
+            }
+            __syncthreads();
+            for (int n = tid; n < M; n += BLOCK) if (pp[n] == 0.0f) l.x[n] = -INFINITY;
+            __syncthreads();
+        }
+        if (use_topp) {                           // nucleus: drop the lower tail whose running probability <= 1 - top_p
+            const float thr = (float)(1.0 - (double)a.top_p);
+            float t2 = -INFINITY;
+            for (int n = tid; n < M; n += BLOCK) t2 = __builtin_fmaxf(t2, l.x[n]);
+            const float m2 = block_max(t2, l.red);
+            for (int n = tid; n < M; n += BLOCK) pp[n] = (l.x[n] > -INFINITY) ? d_expf(l.x[n] - m2) : 0.0f;
+            __syncthreads();
+            const int nb2 = (M + 63) / 64;
+            for (int b = wv; b < nb2; b += NWAVE) {
+                const int n = b * 64 + lane;
+                const float v = wave_tree_sum(n < M ? pp[n] : 0.0f);
+                if (lane == 0) l.red[8 + b] = v;
+            }
+            __syncthreads();
+            float Z = l.red[8];
+            for (int b = 1; b < nb2; ++b) Z = Z + l.red[8 + b];
+            for (int n = tid; n < M; n += BLOCK) {
+                const float xn = l.x[n];
+                int r0 = 0;
+                for (int m = 0; m < M; ++m) { const float xm = l.x[m]; r0 += (xm < xn) | ((xm == xn) & (m < n)); }
+                rk[n] = r0;
+                srt[r0] = pp[n] / Z;
+            }
+            __syncthreads();
+            if (tid == 0) {                       // the running sum is sequential by definition
+                float cs = 0.0f;
+                for (int j = 0; j < M; ++j) { cs = cs + srt[j]; srt[j] = (cs <= thr) ? 1.0f : 0.0f; }
+            }
+            __syncthreads();
+            for (int n = tid; n < M; n += BLOCK) if (srt[rk[n]] != 0.0f) l.x[n] = -INFINITY;
+            __syncthreads();
+        }
+        float t3 = -INFINITY;
+        for (int n = tid; n < M; n += BLOCK) t3 = __builtin_fmaxf(t3, l.x[n]);
+        mx = block_max(t3, l.red);
+    }
+
+    // ---- D7 log-softmax: lane-tree sum of exp(x - max); an entry takes part iff it is still finite --------------------------
     float* ex = l.partL;  // reuse
-    for (int n = tid; n < M; n += BLOCK) ex[n] = l.msk[n] ? d_expf(l.x[n] - mx) : 0.0f;
+    for (int n = tid; n < M; n += BLOCK) ex[n] = (l.x[n] > -INFINITY) ? d_expf(l.x[n] - mx) : 0.0f;
     __syncthreads();
     const int nblk = (M + 63) / 64;
     for (int b = wv; b < nblk; b += NWAVE) {
@@ -271,7 +326,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
     float best = -INFINITY;
     int besti = 0x7fffffff;
     for (int n = tid; n < M; n += BLOCK) {
-        const bool feas = l.msk[n] != 0;
+        const bool feas = l.x[n] > -INFINITY;          // feasible and not filtered out
         float lpn = feas ? (l.x[n] - mx) - lse : -INFINITY;
         l.x[n] = lpn;
         if (logprobs_row) logprobs_row[n] = lpn;

@@ -77,12 +77,11 @@ class SamplingEval(EvalBase):
     def __init__(self, env, samples, softmax_temp=None, select_best=True, temperature=1.0, top_p=0.0, top_k=0, **kwargs):
         super().__init__(env, kwargs.get("progress", False))
         self.samples, self.temperature, self.select_best = samples, temperature, select_best
-        if top_p or top_k:
-            raise NotImplementedError("top-k / top-p filtering is outside the MI355X rollout path")
+        self.top_p, self.top_k = top_p, top_k
 
     def _inner(self, policy, td):
         out = policy(td.clone(), self.env, decode_type="sampling", num_samples=self.samples, multisample=True,
-                     temperature=self.temperature, select_best=self.select_best)
+                     temperature=self.temperature, top_p=self.top_p, top_k=self.top_k, select_best=self.select_best)
         return out["actions"], out["reward"]
 
 

@@ -453,7 +453,7 @@ def _validate_state(st: RolloutState, cache: DecodeCache):
 
 
 def decode_step(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0,
-                fuse_env_step=False, want_logprobs=False, want_logits=False, status=None):
+                fuse_env_step=False, want_logprobs=False, want_logits=False, status=None, top_k=0, top_p=0.0):
     """One decode step for all rows.  -> (action [R], logp [R], logprobs [R,M] | None, logits [R,M] | None)."""
     lib = _lib.load()
     _validate_state(st, cache)
@@ -470,14 +470,15 @@ def decode_step(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None,
         _chk(given, "given actions", torch.int64, (R,))
     cs, ss = cache.struct(), st.struct()
     _lib.check(lib.eamrl_am_decode_step(ENVS[st.env_name], C.byref(cs), C.byref(ss), R, MODES[mode], _ptr(noise),
-                                        _ptr(given), float(clip), float(temp), int(fuse_env_step), _ptr(action),
+                                        _ptr(given), float(clip), float(temp), int(top_k), float(top_p),
+                                        int(fuse_env_step), _ptr(action),
                                         _ptr(logp), _ptr(lps), _ptr(lgs), _ptr(status), _stream(st.mask)),
                "eamrl_am_decode_step")
     return action, logp, lps, lgs, status
 
 
 def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0,
-            t_max=None):
+            t_max=None, top_k=0, top_p=0.0):
     """Whole decode loop in one launch.  -> (actions [R,t_max], logps [R,t_max], info int32[2] = (steps, status))."""
     lib = _lib.load()
     _validate_state(st, cache)
@@ -507,7 +508,8 @@ def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, giv
     steps_ptr = C.c_void_p(info.data_ptr())
     status_ptr = C.c_void_p(info.data_ptr() + 4)
     _lib.check(lib.eamrl_am_rollout(ENVS[st.env_name], C.byref(cs), C.byref(ss), R, MODES[mode], _ptr(noise),
-                                    _ptr(given), t_given, float(clip), float(temp), int(t_max), _ptr(actions),
+                                    _ptr(given), t_given, float(clip), float(temp), int(top_k), float(top_p), int(t_max),
+                                    _ptr(actions),
                                     _ptr(logps), steps_ptr, status_ptr, _stream(st.mask)), "eamrl_am_rollout")
     return actions, logps, info
 

@@ -411,9 +411,9 @@ class AttentionModelPolicy(nn.Module):
         select_best = decoding_kwargs.pop("select_best", False)
         select_start_nodes_fn = decoding_kwargs.pop("select_start_nodes_fn", None)
         noise = decoding_kwargs.pop("noise", None)      # [R, T, M] Exp(1) draws replacing torch.multinomial's
-        for k in ("top_k", "top_p"):
-            if decoding_kwargs.pop(k, 0):
-                raise NotImplementedError(f"{k} filtering is outside the MI355X rollout path")
+        top_k = int(decoding_kwargs.pop("top_k", 0) or 0)          # process_logits filtering (decoding.py:170-176)
+        top_p = float(decoding_kwargs.pop("top_p", 0.0) or 0.0)
+        assert top_p <= 1.0, "top-p should be in (0, 1]."
         if decoding_kwargs:
             log.warning("ignored decoding kwargs: %s", list(decoding_kwargs))
         assert not (multistart and multisample), "Using both multistart and multisample is not supported"
@@ -471,11 +471,11 @@ class AttentionModelPolicy(nn.Module):
         dev = st.mask.device
         if store_all_logp:
             acts, lps, all_logp, T, status = self._rollout_stepwise(st, cache, mode, noise, given, tanh_clipping,
-                                                                    temperature, t_max)
+                                                                    temperature, t_max, top_k, top_p)
             info = None
         else:
             acts, lps, info = ops.rollout(st, cache, mode, noise=noise, given=given, clip=tanh_clipping,
-                                          temp=temperature, t_max=t_max)
+                                          temp=temperature, t_max=t_max, top_k=top_k, top_p=top_p)
         # Everything below is enqueued on the PADDED [R, t_max] arrays before the rollout's single host sync:
         # padding is depot visits with log-prob 0, which change neither the tour length (zero-length legs, and
         # x + 0 is exact in the lane tree), nor the log-likelihood sum, nor validity.
@@ -576,6 +576,7 @@ class AttentionModelPolicy(nn.Module):
         temperature = kw.pop("temperature", self.temperature)
         tanh_clipping = kw.pop("tanh_clipping", self.tanh_clipping)
         select_start_nodes_fn = kw.pop("select_start_nodes_fn", None)
+        top_k, top_p = int(kw.pop("top_k", 0) or 0), float(kw.pop("top_p", 0.0) or 0.0)
         for k in ("store_all_logp", "num_starts", "multistart"):
             kw.pop(k, None)
         if kw:
@@ -604,7 +605,8 @@ class AttentionModelPolicy(nn.Module):
         t = 0
         while t < t_max and not bool(st.done.all()):
             _, _, all_lp, _, _ = ops.decode_step(st, cache, "greedy", clip=tanh_clipping, temp=temperature,
-                                                 fuse_env_step=False, want_logprobs=True, status=status)
+                                                 fuse_env_step=False, want_logprobs=True, status=status,
+                                                 top_k=top_k, top_p=top_p)
             node, beam, parent_lp, slp = ops.beam_topk(all_lp, parent_lp, B, BW)
             beam = beam.to(torch.int64)
             st.reorder_(inst + beam * B)
@@ -652,7 +654,7 @@ class AttentionModelPolicy(nn.Module):
         self._last_td = td_out
         return out
 
-    def _rollout_stepwise(self, st, cache, mode, noise, given, clip, temp, t_max):
+    def _rollout_stepwise(self, st, cache, mode, noise, given, clip, temp, t_max, top_k=0, top_p=0.0):
         """Step-API loop (one fused decode+env launch per step) used when every step's full log-prob row
         is wanted (store_all_logp / return_entropy).  The loop condition is checked on the host each step,
         as the reference does."""
@@ -663,7 +665,7 @@ class AttentionModelPolicy(nn.Module):
             a, lp, all_lp, _, _ = ops.decode_step(
                 st, cache, mode, noise=None if noise is None else noise[:, t].contiguous(),
                 given=None if given is None else given[:, t].contiguous(), clip=clip, temp=temp,
-                fuse_env_step=True, want_logprobs=True, status=status)
+                fuse_env_step=True, want_logprobs=True, status=status, top_k=top_k, top_p=top_p)
             acts.append(a)
             lps.append(lp)
             alls.append(all_lp)

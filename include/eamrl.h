@@ -146,23 +146,27 @@ typedef struct eamrl_state {
 
 /* One decode step for R rows = AttentionModelDecoder.forward + DecodingStrategy.step
  * [zoo/am/decoder.py:161-198; nn/attention.py:282-328; utils/decoding.py:140-190,346-465]:
- * context query -> 8-head masked glimpse -> logits -> tanh clip -> mask -> /temperature -> log_softmax ->
- * greedy / sampling / evaluate.  Reads the state, does not modify it unless fuse_env_step != 0, in which
+ * context query -> 8-head masked glimpse -> logits -> tanh clip -> mask -> /temperature -> [top-k] -> [top-p] ->
+ * log_softmax -> greedy / sampling / evaluate.  top_k > 0: entries below the k-th largest scaled logit are dropped
+ * (ties kept); 0 < top_p < 1: the lower tail whose running softmax mass (ascending order) is <= 1 - top_p is dropped
+ * [utils/decoding.py:110-136,170-176]; 0 = off.  Reads the state, does not modify it unless fuse_env_step != 0, in which
  * case it also applies TSPEnv._step / CVRPEnv._step (+mask) with the selected action.
  * noise [R][M] (SAMPLE) / given [R] (EVALUATE) else NULL.  Outputs: action [R], logp [R];
  * optional logprobs_all [R][M] (store_all_logp) and logits_raw [R][M] (pre-clip decoder logits). */
 int eamrl_am_decode_step(int env, const eamrl_cache* cache_host, const eamrl_state* state_host, int64_t R,
                          int mode, const float* noise, const int64_t* given, float tanh_clip, float temperature,
-                         int fuse_env_step, int64_t* action, float* logp, float* logprobs_all, float* logits_raw,
-                         uint32_t* status, void* stream);
+                         int top_k, float top_p, int fuse_env_step, int64_t* action, float* logp, float* logprobs_all,
+                         float* logits_raw, uint32_t* status, void* stream);
 
 /* Whole decode loop in one launch (ConstructivePolicy.forward's while-loop, constructive/base.py:236-250):
  * repeats {decode step, env step} until every row is done or t_max steps were taken.  actions/logps are
  * [R][t_max] (right-padded: finished CVRP rows keep selecting the depot, logp 0).  noise [R][t_max][M],
- * given [R][t_given].  steps_out (device int32): number of steps executed = max over rows. */
+ * given [R][t_given].  steps_out (device int32): number of steps executed = max over rows.  With top_k / top_p
+ * filtering the streaming kernel is used (the register-resident one does not filter). */
 int eamrl_am_rollout(int env, const eamrl_cache* cache_host, const eamrl_state* state_host, int64_t R, int mode,
                      const float* noise, const int64_t* given, int t_given, float tanh_clip, float temperature,
-                     int t_max, int64_t* actions, float* logps, int32_t* steps_out, uint32_t* status, void* stream);
+                     int top_k, float top_p, int t_max, int64_t* actions, float* logps, int32_t* steps_out,
+                     uint32_t* status, void* stream);
 
 /* ---- reward ----------------------------------------------------------------------------------------- */
 

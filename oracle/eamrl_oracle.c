@@ -371,6 +371,8 @@ typedef struct {
     const float *cvec;            /* TSP: c0[E] (placeholder query); CVRP: wcap[E] */
     const float *gctx;            /* [Binst][E] or NULL */
     float clip, temp;
+    int top_k;          /* process_logits top-k filtering (0 = off)                      utils/decoding.py:110-115 */
+    float top_p;        /* process_logits nucleus filtering (0 or >= 1 = off)            utils/decoding.py:118-136 */
 } orc_dec_t;
 
 static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, int64_t istep, float remaining,
@@ -453,11 +455,46 @@ static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, in
         x[n] = v;
         if (v > mx) mx = v;
     }
-    /* D7 log-softmax */
-    for (int n = 0; n < M; ++n) ex[n] = mask[n] ? d_expf(x[n] - mx) : 0.0f;
+    /* D6b top-k / top-p filtering of the scaled logits (process_logits, decoding.py:170-176).
+     *   top-k: keep n iff fewer than k entries are strictly larger (== "logits < k-th largest" removed; ties kept).
+     *   top-p: p = softmax(x) (d_expf(x - max) / lane_tree sum); entries in ascending (value, index) order; running sum c
+     *          sequential in that order; remove while c <= (float)(1 - top_p). */
+    if (c->top_k > 0) {
+        const int k = c->top_k < M ? c->top_k : M;
+        for (int n = 0; n < M; ++n) {
+            int cnt = 0;
+            for (int m = 0; m < M; ++m) cnt += (x[m] > x[n]);
+            ex[n] = (cnt < k) ? 1.0f : 0.0f;
+        }
+        for (int n = 0; n < M; ++n) if (ex[n] == 0.0f) x[n] = -INFINITY;
+    }
+    if (c->top_p > 0.0f && c->top_p < 1.0f) {
+        const float thr = (float)(1.0 - (double)c->top_p);
+        float m2 = -INFINITY;
+        for (int n = 0; n < M; ++n) if (x[n] > m2) m2 = x[n];
+        for (int n = 0; n < M; ++n) ex[n] = (x[n] > -INFINITY) ? d_expf(x[n] - m2) : 0.0f;
+        const float Z = lane_tree(ex, M);
+        float* srt = w;                               /* the glimpse weights are no longer needed: H*M >= 2M floats */
+        int* rk = (int*)(w + M);
+        for (int n = 0; n < M; ++n) {
+            int r0 = 0;
+            for (int m = 0; m < M; ++m) r0 += (x[m] < x[n]) || (x[m] == x[n] && m < n);
+            rk[n] = r0;
+            srt[r0] = ex[n] / Z;
+        }
+        float cs = 0.0f;
+        for (int j = 0; j < M; ++j) { cs = cs + srt[j]; srt[j] = (cs <= thr) ? 1.0f : 0.0f; }
+        for (int n = 0; n < M; ++n) if (srt[rk[n]] != 0.0f) x[n] = -INFINITY;
+    }
+    if (c->top_k > 0 || (c->top_p > 0.0f && c->top_p < 1.0f)) {
+        mx = -INFINITY;
+        for (int n = 0; n < M; ++n) if (x[n] > mx) mx = x[n];
+    }
+    /* D7 log-softmax (an entry takes part iff it is still finite: masked and filtered entries are -inf) */
+    for (int n = 0; n < M; ++n) ex[n] = (x[n] > -INFINITY) ? d_expf(x[n] - mx) : 0.0f;
     float lse = d_logf(lane_tree(ex, M));
     for (int n = 0; n < M; ++n) {
-        x[n] = mask[n] ? (x[n] - mx) - lse : -INFINITY;
+        x[n] = (x[n] > -INFINITY) ? (x[n] - mx) - lse : -INFINITY;
         if (out_logprobs) out_logprobs[n] = x[n];
     }
     /* D8 selection (lowest index wins ties, as torch.argmax) */
@@ -489,9 +526,10 @@ ORC_API int orc_decode_step(int env, long R, long Binst, int M, int E, int H,
                             const int64_t* first, const int64_t* cur, const int64_t* istep,
                             const float* used, const float* vcap, const uint8_t* mask,
                             int mode, const float* noise, const int64_t* given, float clip, float temp,
+                            int top_k, float top_p,
                             int64_t* out_action, float* out_logp, float* out_logits, float* out_logprobs)
 {
-    orc_dec_t c = { env, R, Binst, M, E, H, K, V, Lp, Pa, Pb, cvec, gctx, clip, temp };
+    orc_dec_t c = { env, R, Binst, M, E, H, K, V, Lp, Pa, Pb, cvec, gctx, clip, temp, top_k, top_p };
     int status = 0;
 #pragma omp parallel
     {
@@ -623,7 +661,7 @@ ORC_API int orc_rollout(int env, long R, long Binst, int M, int E, int H,
                         float* used, const float* vcap, const float* demand,
                         uint8_t* mask, uint8_t* visited, uint8_t* done,
                         int mode, const float* noise, const int64_t* given, int Tgiven,
-                        float clip, float temp, int Tmax,
+                        float clip, float temp, int top_k, float top_p, int Tmax,
                         int64_t* actions, float* logps)
 {
     int64_t* a = (int64_t*)malloc(sizeof(int64_t) * R);
@@ -638,7 +676,7 @@ ORC_API int orc_rollout(int env, long R, long Binst, int M, int E, int H,
         if (noise) for (long r = 0; r < R; ++r) memcpy(nz + r * M, noise + (r * (long)Tmax + t) * M, sizeof(float) * M);
         if (given) for (long r = 0; r < R; ++r) gv[r] = (t < Tgiven) ? given[r * (long)Tgiven + t] : 0;
         status = orc_decode_step(env, R, Binst, M, E, H, K, V, Lp, Pa, Pb, cvec, gctx, first, cur, istep,
-                                 used, vcap, mask, mode, nz, gv, clip, temp, a, lp, NULL, NULL);
+                                 used, vcap, mask, mode, nz, gv, clip, temp, top_k, top_p, a, lp, NULL, NULL);
         if (status != 0) break;
         for (long r = 0; r < R; ++r) { actions[r * (long)Tmax + t] = a[r]; logps[r * (long)Tmax + t] = lp[r]; }
         if (env == ORC_ENV_TSP) orc_tsp_step(mask, first, cur, istep, a, done, R, M);

@@ -258,7 +258,7 @@ class State:
 
 
 def decode_step(st: State, cache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0, num_heads=8,
-                want_all=False):
+                want_all=False, top_k=0, top_p=0.0):
     R, M = st.R, st.M
     E = cache["K"].shape[-1]
     act = np.empty(R, np.int64)
@@ -271,7 +271,7 @@ def decode_step(st: State, cache, mode="greedy", noise=None, given=None, clip=10
         C.c_int(st.env), C.c_long(R), C.c_long(st.Binst), C.c_int(M), C.c_int(E), C.c_int(num_heads),
         _p(cache["K"]), _p(cache["V"]), _p(cache["Lp"]), _p(cache["Pa"]), _p(cache["Pb"]), _p(cache["cvec"]),
         _p(cache["gctx"]), _p(st.first), _p(st.cur), _p(st.istep), _p(st.used), _p(st.vcap), _p(st.mask),
-        C.c_int(MODES[mode]), _p(nz), _p(gv), C.c_float(clip), C.c_float(temp),
+        C.c_int(MODES[mode]), _p(nz), _p(gv), C.c_float(clip), C.c_float(temp), C.c_int(int(top_k)), C.c_float(top_p),
         _p(act), _p(lp), _p(logits), _p(logprobs))
     if rc == -1:
         raise AssertionError("Logits contain NaNs")
@@ -280,7 +280,8 @@ def decode_step(st: State, cache, mode="greedy", noise=None, given=None, clip=10
     return (act, lp, logits, logprobs) if want_all else (act, lp)
 
 
-def rollout(st: State, cache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0, num_heads=8, t_max=None):
+def rollout(st: State, cache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0, num_heads=8, t_max=None,
+            top_k=0, top_p=0.0):
     """Decode loop until every row is done.  -> (actions [R,T], logp [R,T])."""
     R, M = st.R, st.M
     E = cache["K"].shape[-1]
@@ -301,7 +302,7 @@ def rollout(st: State, cache, mode="greedy", noise=None, given=None, clip=10.0, 
         _p(cache["K"]), _p(cache["V"]), _p(cache["Lp"]), _p(cache["Pa"]), _p(cache["Pb"]), _p(cache["cvec"]),
         _p(cache["gctx"]), _p(st.first), _p(st.cur), _p(st.istep), _p(st.used), _p(st.vcap), _p(st.demand),
         _p(st.mask), _p(st.visited), _p(st.done), C.c_int(MODES[mode]), _p(noise), _p(given), C.c_int(tg),
-        C.c_float(clip), C.c_float(temp), C.c_int(t_max), _p(actions), _p(logps))
+        C.c_float(clip), C.c_float(temp), C.c_int(int(top_k)), C.c_float(top_p), C.c_int(t_max), _p(actions), _p(logps))
     if T == -1:
         raise AssertionError("Logits contain NaNs")
     if T == -2:
@@ -343,7 +344,7 @@ def check_cvrp(actions, demand, vcap):
 
 
 def policy_rollout(sd, env_name, locs, demand=None, decode_type="greedy", num_starts=0, noise=None, given=None,
-                   use_graph_context=True, clip=10.0, temp=1.0, num_heads=8):
+                   use_graph_context=True, clip=10.0, temp=1.0, num_heads=8, top_k=0, top_p=0.0):
     """ConstructivePolicy.forward restated on the oracle: encoder, cache, (multistart hook), loop, reward.
 
     locs for CVRP already include the depot at index 0 (post-reset layout).
@@ -364,7 +365,8 @@ def policy_rollout(sd, env_name, locs, demand=None, decode_type="greedy", num_st
             start, given = _i64(given[:, 0]), np.ascontiguousarray(given[:, 1:])
         st.step(start)
         pre_a, pre_lp = [start[:, None]], [np.zeros((st.R, 1), np.float32)]
-    acts, lps = rollout(st, cache, mode, noise=noise, given=given, clip=clip, temp=temp, num_heads=num_heads)
+    acts, lps = rollout(st, cache, mode, noise=noise, given=given, clip=clip, temp=temp, num_heads=num_heads,
+                        top_k=top_k, top_p=top_p)
     actions = np.concatenate(pre_a + [acts], 1)
     logp = np.concatenate(pre_lp + [lps], 1)
     reward = tour_length_reward(locs, actions, with_depot=(env_name != "tsp"))

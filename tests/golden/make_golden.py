@@ -271,8 +271,21 @@ def beam():
              decode_kw=dict(beam_width=12, select_best=False))
 
 
+def filtering():
+    """Fourth batch (python make_golden.py filtering): top-k / top-p (nucleus) filtering of process_logits."""
+    first4 = [0, 1, 2, 3]
+    run_case("tsp20_sampling_topk5", "tsp", 20, 4, "sampling", keep_steps=first4, data_seed=41, decode_kw=dict(top_k=5))
+    run_case("tsp20_sampling_topp", "tsp", 20, 4, "sampling", keep_steps=first4, data_seed=42,
+             decode_kw=dict(top_p=0.8, temperature=2.0))
+    run_case("cvrp20_sampling_topk_topp", "cvrp", 20, 4, "sampling", keep_steps=first4, data_seed=43,
+             decode_kw=dict(top_k=6, top_p=0.9, temperature=1.5))
+    run_case("tsp100_greedy_topk", "tsp", 100, 2, "greedy", keep_steps=first4, data_seed=44, decode_kw=dict(top_k=3))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "beam":
+    if len(sys.argv) > 1 and sys.argv[1] == "filtering":
+        filtering()
+    elif len(sys.argv) > 1 and sys.argv[1] == "beam":
         beam()
     elif len(sys.argv) > 1 and sys.argv[1] == "extra":
         extra()

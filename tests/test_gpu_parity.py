@@ -268,7 +268,8 @@ POLICY_CASES = ["tsp20_greedy", "tsp20_sampling", "tsp20_evaluate", "tsp20_multi
                 "tsp100_sampling", "cvrp20_greedy", "cvrp20_sampling", "cvrp20_evaluate", "cvrp20_multistart_greedy",
                 "cvrp100_greedy", "cvrp100_sampling", "pomo_tsp20_multistart_sampling",
                 "tsp50_greedy", "cvrp50_sampling", "tsp200_greedy", "cvrp200_greedy", "pomo_cvrp20_multistart_greedy",
-                "cvrp20_sampling_temp", "tsp20_greedy_noclip"]
+                "cvrp20_sampling_temp", "tsp20_greedy_noclip",
+                "tsp20_sampling_topk5", "tsp20_sampling_topp", "cvrp20_sampling_topk_topp", "tsp100_greedy_topk"]
 
 
 @pytest.mark.parametrize("stream_kernel", [0, 1])
@@ -295,9 +296,11 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
             decode_type = "multistart_" + decode_type
     if "noise" in fx:
         kw["noise"] = t(fx["noise"])
-    for k in ("temperature", "tanh_clipping"):
+    for k in ("temperature", "tanh_clipping", "top_p"):
         if "decode_kw_" + k in fx:
             kw[k] = float(fx["decode_kw_" + k])
+    if "decode_kw_top_k" in fx:
+        kw["top_k"] = int(fx["decode_kw_top_k"])
     lib = _lib.load()
     lib.eamrl_debug_set(1, stream_kernel)
     try:
@@ -311,7 +314,8 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
                               decode_type=decode_type if "actions" not in kw else "evaluate", num_starts=ns,
                               noise=fx.get("noise"), given=fx["actions"] if "actions" in kw else None,
                               use_graph_context=pol.decoder.use_graph_context,
-                              clip=kw.get("tanh_clipping", 10.0), temp=kw.get("temperature", 1.0))
+                              clip=kw.get("tanh_clipping", 10.0), temp=kw.get("temperature", 1.0),
+                              top_k=kw.get("top_k", 0), top_p=kw.get("top_p", 0.0))
     assert_bits_equal(out["log_likelihood"], o["logp_steps"], "per-step logp vs oracle")
     assert_bits_equal(out["reward"], o["reward"], "reward vs oracle")
 

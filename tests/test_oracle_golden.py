@@ -20,6 +20,8 @@ POLICY_CASES = [
     # second batch: mid sizes, graphs above 128 nodes, POMO policy on CVRP, non-default temperature / clipping
     "tsp50_greedy", "cvrp50_sampling", "tsp200_greedy", "cvrp200_greedy", "pomo_cvrp20_multistart_greedy",
     "cvrp20_sampling_temp", "tsp20_greedy_noclip",
+    # third batch: top-k / top-p filtering in process_logits
+    "tsp20_sampling_topk5", "tsp20_sampling_topp", "cvrp20_sampling_topk_topp", "tsp100_greedy_topk",
 ]
 
 
@@ -33,7 +35,8 @@ def _run(orc, fx):
     return orc.policy_rollout(
         sd, str(fx["env_name"]), fx["locs"], fx.get("demand"), decode_type=decode_type, num_starts=ns,
         noise=fx.get("noise"), given=given, use_graph_context=bool(fx.get("policy_kw_use_graph_context", True)),
-        clip=float(fx.get("decode_kw_tanh_clipping", 10.0)), temp=float(fx.get("decode_kw_temperature", 1.0)))
+        clip=float(fx.get("decode_kw_tanh_clipping", 10.0)), temp=float(fx.get("decode_kw_temperature", 1.0)),
+        top_k=int(fx.get("decode_kw_top_k", 0)), top_p=float(fx.get("decode_kw_top_p", 0.0)))
 
 
 @pytest.mark.parametrize("name", POLICY_CASES)
