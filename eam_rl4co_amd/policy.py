@@ -13,7 +13,6 @@ No CPU / PyTorch implementation of the rollout exists here: tensors must live on
 from __future__ import annotations
 
 import logging
-import math
 from typing import Optional
 
 import torch
