@@ -436,3 +436,47 @@ def test_status_flags_mirror_reference_asserts():
         pol.decoder.project_node_embeddings.weight[300, 0] = float("nan")
     with pytest.raises(AssertionError, match="Logits contain NaNs"):
         pol(td.clone(), env, phase="test", decode_type="greedy")
+
+
+def test_full_size_pomo_multistart_equals_oracle(oracle):
+    """BASELINE.json configs[3] shape per instance: POMO policy, TSP-100, 100 starts, multistart sampling (batch reduced
+    so the CPU oracle finishes in seconds): every tour, log-prob and reward bit-identical to the oracle."""
+    import eam_rl4co_amd as ea
+
+    N, B, S = 100, 12, 100
+    pol = make_policy("pomo_tsp")
+    env = ea.get_env("tsp", generator_params=dict(num_loc=N), seed=99)
+    td_cpu = env.reset(batch_size=[B])
+    noise = torch.empty(B * S, N - 1, N).exponential_(1, generator=torch.Generator().manual_seed(9))
+    out = pol(td_cpu.to(DEV), env, phase="train", decode_type="multistart_sampling", num_starts=S, noise=noise.to(DEV),
+              return_sum_log_likelihood=False)
+    o = oracle.policy_rollout(golden_weights("pomo_tsp"), "tsp", td_cpu["locs"].numpy(), None,
+                              decode_type="multistart_sampling", num_starts=S, noise=noise.numpy(), use_graph_context=False)
+    assert_bits_equal(out["actions"], o["actions"], "tours vs oracle")
+    assert_bits_equal(out["log_likelihood"], o["logp_steps"], "logp vs oracle")
+    assert_bits_equal(out["reward"], o["reward"], "reward vs oracle")
+    assert (np.sort(out["actions"].cpu().numpy(), 1) == np.arange(N)).all()
+    assert (out["actions"][:, 0].cpu().numpy() == np.repeat(np.arange(S), B)).all()      # start nodes in (s b) order
+
+
+def test_full_size_cvrp500_properties():
+    """BASELINE.json configs[4] at its full size (CVRP-500, batch 512, greedy, streaming decode kernel + tiled
+    attention): size-independent properties -- every customer exactly once, routes within capacity (the env's own
+    validity check), reward equal to the recomputed closed length, and a second run reproduces the first bit for bit."""
+    import eam_rl4co_amd as ea
+
+    N, B = 500, 512
+    pol = make_policy("am_cvrp")
+    env = ea.get_env("cvrp", generator_params=dict(num_loc=N), seed=1234)
+    td = env.reset(batch_size=[B]).to(DEV)
+    a = pol(td.clone(), env, phase="test", decode_type="greedy")
+    b = pol(td.clone(), env, phase="test", decode_type="greedy")
+    assert torch.equal(a["actions"], b["actions"]) and torch.equal(a["reward"], b["reward"])
+    acts = a["actions"]
+    srt = acts.sort(1).values
+    assert (srt[:, -N:] == torch.arange(1, N + 1, device=DEV)).all() and (srt[:, :-N] == 0).all()
+    env.check_solution_validity(td, acts)
+    locs = td["locs"].double()
+    pts = torch.cat([locs[:, :1], locs.gather(1, acts[..., None].expand(-1, -1, 2))], 1)
+    length = (pts.roll(-1, 1) - pts).norm(dim=-1).sum(1)
+    np.testing.assert_allclose(-a["reward"].cpu().numpy(), length.cpu().numpy(), rtol=2e-6)
