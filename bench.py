@@ -192,13 +192,35 @@ def main():
             return graphed(td0)                      # copy inputs into the captured buffers + one graph replay
         return policy(td0.clone(), env, phase="test", decode_type=decode_type, **dkw)
 
-    # duration of the decode-loop launch: HIP events around it on the launch stream, in eager passes before the timed region
+    # duration of the decode-loop launch, and of all nn.Linear launches (the encoder / cache GEMMs): HIP events around
+    # them on the launch stream, in eager passes before the timed region
+    gemm_ev, gemm_flops = [], []
+    orig_linear, orig_mmr = ops.linear, ops.matmul_right
+
+    def timed(fn, flops_of):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            gemm_ev.append((e0, e1))
+            gemm_flops.append(flops_of(a, r))
+            return r
+        return wrapper
+
     ops.rollout = timed_rollout
-    for _ in range(5):
+    ops.linear = timed(orig_linear, lambda a, r: 2.0 * a[0].numel() * r.shape[-1])
+    ops.matmul_right = timed(orig_mmr, lambda a, r: 2.0 * a[0].numel() * r.shape[-1])
+    n_pass = 5
+    for i in range(n_pass):
+        if i == 2:
+            gemm_ev.clear(); gemm_flops.clear()
         policy(td0.clone(), env, phase="test", decode_type=decode_type, **dkw)
     torch.cuda.synchronize()
-    ops.rollout = orig_rollout
+    ops.rollout, ops.linear, ops.matmul_right = orig_rollout, orig_linear, orig_mmr
     kernel_ms = kernel_ms[2:]
+    gemm_ms_per_rollout = sum(a.elapsed_time(b) for a, b in gemm_ev) / (n_pass - 2)
+    gemm_tflops = sum(gemm_flops) / (n_pass - 2) / (gemm_ms_per_rollout * 1e-3) / 1e12 if gemm_ev else 0.0
     for _ in range(args.warmup):
         out = one_step()
     if world > 1:
@@ -250,6 +272,10 @@ def main():
                        "decode_steps": T, "reward_mean": round(float(out["reward"].mean()), 4),
                        "launch": "eager" if args.no_graph else "hipGraph replay"},
             "roofline": roofline,
+            # the launches that take the largest share of the step time: the one-shot encoder / cache Linears on fp32 MFMA
+            "roofline_gemm": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(gemm_tflops / F32_PEAK_TFLOPS, 4), "kernel": "encoder + cache nn.Linear launches",
+                              "ms_per_step": round(gemm_ms_per_rollout, 4), "launches_per_step": len(gemm_ev) // (n_pass - 2)},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(env_name, num_loc, decode_type, num_starts=S if S > 1 else 0, pomo=pomo)
