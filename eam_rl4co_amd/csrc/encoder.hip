@@ -105,7 +105,10 @@ __device__ __forceinline__ void pair_swap(const float2 v, float& first, float& s
 
 // Tile = BM rows x 128 columns, 4 waves as 2 x 2, each wave (BM/2) x 64 = (BM/64) x 2 MFMA tiles of 32 x 32.
 // BM = 64 gives twice as many (half-size) tiles: better balance over the 256 CUs and more blocks per CU.
-template <bool WT, int BM>
+// EPI: -1 = epilogue configured at run time (any shape / alignment); 0..3 = compile-time epilogue for aligned, whole-tile
+// outputs (0 plain, 1 ReLU, 2 residual, 3 residual + BatchNorm): no option selects and one 64-bit address per tile --
+// on gfx950 every VALU instruction of a GEMM is paid out of its fp32-MFMA time.
+template <bool WT, int BM, int EPI>
 __global__ __launch_bounds__(256, 2) void k_linear_mfma(GemmArgs g)
 {
     constexpr int TA = BM / 64;                     // MFMA row tiles per wave; also A-tile float4 per thread / 2
@@ -204,10 +207,48 @@ __global__ __launch_bounds__(256, 2) void k_linear_mfma(GemmArgs g)
     const int er = lane >> 4, ec = (lane & 15) * 4;         // this lane's (row within 4, first column) when reading
     const int jbase = col0 + wc * 64 + ec;
     float sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bn_gamma) {
+    if (EPI == 3 || (EPI < 0 && g.bn_gamma)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (jbase + q < g.out_dim) bn_consts(g, jbase + q, sc4[q], sh4[q]);
+    }
+    if (EPI >= 0) {
+        // fast epilogue: whole column tiles, 16-byte aligned rows (checked by the launcher)
+        const int64_t rfirst = row0 + wr * (BM / 2) + er;
+#pragma unroll
+        for (int a = 0; a < TA; ++a) {
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    slab[((i & 3) + 8 * (i >> 2) + 4 * lk) * CS + b * 32 + li] = acc[a][b][i];
+            __syncthreads();
+            float* yp = g.y + (rfirst + a * 32) * g.ldy + jbase;
+            const float* rp = EPI >= 2 ? g.res + (rfirst + a * 32) * g.ldres + jbase : nullptr;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                if (rfirst + a * 32 + 4 * p < g.rows) {
+                    float4 v = *reinterpret_cast<const float4*>(slab + (er + 4 * p) * CS + ec);
+                    if (EPI == 1) {
+                        v.x = !(v.x > 0.0f) ? 0.0f : v.x; v.y = !(v.y > 0.0f) ? 0.0f : v.y;
+                        v.z = !(v.z > 0.0f) ? 0.0f : v.z; v.w = !(v.w > 0.0f) ? 0.0f : v.w;
+                    }
+                    if (EPI >= 2) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(rp);
+                        v.x = r4.x + v.x; v.y = r4.y + v.y; v.z = r4.z + v.z; v.w = r4.w + v.w;
+                    }
+                    if (EPI == 3) {
+                        v.x = fma_(v.x, sc4[0], sh4[0]); v.y = fma_(v.y, sc4[1], sh4[1]);
+                        v.z = fma_(v.z, sc4[2], sh4[2]); v.w = fma_(v.w, sc4[3], sh4[3]);
+                    }
+                    *reinterpret_cast<float4*>(yp) = v;
+                }
+                yp += 4 * g.ldy;
+                if (EPI >= 2) rp += 4 * g.ldres;
+            }
+        }
+        return;
     }
     const bool vec_ok = ((g.ldy & 3) == 0) && (((uintptr_t)g.y & 15) == 0) && (jbase + 3 < g.out_dim) &&
                         (!g.res || (((g.ldres & 3) == 0) && (((uintptr_t)g.res & 15) == 0)));
@@ -371,12 +412,29 @@ int launch_linear(const GemmArgs& g0, hipStream_t st)
     } else {
         const int bm = g_debug[4] ? 128 : 64;
         dim3 grid((unsigned)((g.rows + bm - 1) / bm), (unsigned)((g.out_dim + GT - 1) / GT));
-        if (bm == 64) {
-            if (g.wt) hipLaunchKernelGGL((k_linear_mfma<true, 64>), grid, dim3(256), 0, st, g);
-            else hipLaunchKernelGGL((k_linear_mfma<false, 64>), grid, dim3(256), 0, st, g);
+        // compile-time epilogue where the output is whole 128-column tiles of 16-byte aligned rows
+        const bool aligned = (g.out_dim % GT == 0) && ((g.ldy & 3) == 0) && (((uintptr_t)g.y & 15) == 0) &&
+                             (!g.res || (((g.ldres & 3) == 0) && (((uintptr_t)g.res & 15) == 0)));
+        int epi = -1;
+        if (aligned && !g_debug[10]) {
+            if (g.res && g.bn_gamma && !g.relu) epi = 3;
+            else if (g.res && !g.bn_gamma && !g.relu) epi = 2;
+            else if (!g.res && !g.bn_gamma) epi = g.relu ? 1 : 0;
+        }
+        if (bm == 64 && !g.wt) {
+            switch (epi) {
+            case 0: hipLaunchKernelGGL((k_linear_mfma<false, 64, 0>), grid, dim3(256), 0, st, g); break;
+            case 1: hipLaunchKernelGGL((k_linear_mfma<false, 64, 1>), grid, dim3(256), 0, st, g); break;
+            case 2: hipLaunchKernelGGL((k_linear_mfma<false, 64, 2>), grid, dim3(256), 0, st, g); break;
+            case 3: hipLaunchKernelGGL((k_linear_mfma<false, 64, 3>), grid, dim3(256), 0, st, g); break;
+            default: hipLaunchKernelGGL((k_linear_mfma<false, 64, -1>), grid, dim3(256), 0, st, g); break;
+            }
+        } else if (bm == 64) {
+            if (epi == 0) hipLaunchKernelGGL((k_linear_mfma<true, 64, 0>), grid, dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((k_linear_mfma<true, 64, -1>), grid, dim3(256), 0, st, g);
         } else {
-            if (g.wt) hipLaunchKernelGGL((k_linear_mfma<true, 128>), grid, dim3(256), 0, st, g);
-            else hipLaunchKernelGGL((k_linear_mfma<false, 128>), grid, dim3(256), 0, st, g);
+            if (g.wt) hipLaunchKernelGGL((k_linear_mfma<true, 128, -1>), grid, dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((k_linear_mfma<false, 128, -1>), grid, dim3(256), 0, st, g);
         }
     }
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;

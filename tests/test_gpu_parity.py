@@ -82,7 +82,7 @@ def test_library_loads_and_shares_torch_stream():
 
 @pytest.mark.parametrize("rows,k,n", [(1, 256, 128), (77, 128, 384), (300, 512, 128), (513, 128, 640), (2500, 128, 128), (50, 6, 7),
                                        (64, 129, 33), (9, 3, 128), (4100, 128, 384), (2049, 128, 512), (6000, 128, 128)])
-@pytest.mark.parametrize("variant", ["mfma64", "mfma128", "valu"])
+@pytest.mark.parametrize("variant", ["mfma64", "mfma64_generic_epilogue", "mfma128", "valu"])
 def test_linear_is_a_k_ordered_fma_chain(oracle, rows, k, n, variant):
     """MFMA (v_mfma_f32_32x32x2_f32, 64- and 128-row tiles) and VALU kernels all equal the oracle's fmaf chain."""
     valu = int(variant == "valu")
@@ -96,6 +96,7 @@ def test_linear_is_a_k_ordered_fma_chain(oracle, rows, k, n, variant):
     lib = _lib.load()
     lib.eamrl_debug_set(0, valu)
     lib.eamrl_debug_set(4, int(variant == "mfma128"))
+    lib.eamrl_debug_set(10, int(variant == "mfma64_generic_epilogue"))
     try:
         y = ops.linear(t(x), t(W), t(b))
         assert_bits_equal(y, oracle.linear(x, W, b), "linear")
@@ -113,6 +114,7 @@ def test_linear_is_a_k_ordered_fma_chain(oracle, rows, k, n, variant):
     finally:
         lib.eamrl_debug_set(0, 0)
         lib.eamrl_debug_set(4, 0)
+        lib.eamrl_debug_set(10, 0)
 
 
 def test_matmul_right(oracle):

@@ -100,9 +100,11 @@ def main():
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--bm128", type=int, default=0)
+    ap.add_argument("--generic-epilogue", type=int, default=0, help="1: run-time configured GEMM epilogue (A/B against the templates)")
     a = ap.parse_args()
     from eam_rl4co_amd import _lib
     _lib.load().eamrl_debug_set(4, a.bm128)
+    _lib.load().eamrl_debug_set(10, a.generic_epilogue)
     if a.what in ("gemm", "all"):
         bench_gemm(a.iters)
     if a.what in ("mha", "all"):
