@@ -49,7 +49,7 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
-enum { ORC_ENV_TSP = 0, ORC_ENV_CVRP = 1 };
+enum { ORC_ENV_TSP = 0, ORC_ENV_CVRP = 1, ORC_ENV_SDVRP = 2 };
 enum { ORC_GREEDY = 0, ORC_SAMPLE = 1, ORC_EVALUATE = 2 };
 #define ORC_NCHUNK 4 /* node chunks for the glimpse accumulation, column chunks for the logit dot */
 
@@ -358,6 +358,42 @@ ORC_API void orc_cvrp_step(uint8_t* visited, float* used, const float* vcap, con
     orc_cvrp_mask(visited, used, vcap, demand, cur, mask, R, Binst, N);
 }
 
+/* SDVRPEnv.get_action_mask  [rl4co/envs/routing/sdvrp/env.py:137-146].  rem [R][M] = demand_with_depot (remaining
+ * demand, depot slot 0), used / vcap [R], cur [R] -> mask [R][M] (1 = feasible). */
+ORC_API void orc_sdvrp_mask(const float* rem, const float* used, const float* vcap, const int64_t* cur,
+                            uint8_t* mask, long R, int M)
+{
+    for (long r = 0; r < R; ++r) {
+        const int full = used[r] >= vcap[r];
+        int any_free = 0;
+        for (int n = 1; n < M; ++n) {
+            int blocked = (rem[r * M + n] == 0.0f) | full;
+            mask[r * M + n] = !blocked;
+            any_free |= !blocked;
+        }
+        mask[r * M] = !((cur[r] == 0) && any_free);
+    }
+}
+
+/* SDVRPEnv._step (+ mask)  [sdvrp/env.py:58-92]: deliver min(remaining demand, free capacity) */
+ORC_API void orc_sdvrp_step(float* rem, float* used, const float* vcap, int64_t* cur, const int64_t* action,
+                            uint8_t* mask, uint8_t* done, long R, int M)
+{
+    for (long r = 0; r < R; ++r) {
+        const int64_t a = action[r];
+        const float sel = rem[r * M + a];
+        const float free_cap = vcap[r] - used[r];
+        const float delivered = sel < free_cap ? sel : free_cap;          /* torch.min */
+        used[r] = (used[r] + delivered) * (a != 0 ? 1.0f : 0.0f);
+        rem[r * M + a] = sel + (-delivered);                             /* scatter_add of -delivered */
+        cur[r] = a;
+        int any = 0;
+        for (int n = 0; n < M; ++n) any |= (rem[r * M + n] > 0.0f);
+        done[r] = !any;
+    }
+    orc_sdvrp_mask(rem, used, vcap, cur, mask, R, M);
+}
+
 /* ------------------------------------------------------------------------------------------
  * decode step (decoder + process_logits + selection); one row = one instance or one (start,instance)
  * ---------------------------------------------------------------------------------------- */
@@ -371,12 +407,14 @@ typedef struct {
     const float *cvec;            /* TSP: c0[E] (placeholder query); CVRP: wcap[E] */
     const float *gctx;            /* [Binst][E] or NULL */
     float clip, temp;
+    const float* dyn;   /* SDVRP dynamic embedding [3][E]: glimpse-key, glimpse-value and folded logit-key vectors that are
+                         * scaled by a node's remaining demand and added to its K / V / Lp rows   nn/env_embeddings/dynamic.py:60-78 */
     int top_k;          /* process_logits top-k filtering (0 = off)                      utils/decoding.py:110-115 */
     float top_p;        /* process_logits nucleus filtering (0 or >= 1 = off)            utils/decoding.py:118-136 */
 } orc_dec_t;
 
 static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, int64_t istep, float remaining,
-                      const uint8_t* mask, int mode, const float* noise, int64_t given,
+                      const float* rem, const uint8_t* mask, int mode, const float* noise, int64_t given,
                       int64_t* out_action, float* out_logp, float* out_logits, float* out_logprobs, float* scratch)
 {
     const int M = c->M, E = c->E, H = c->H, D = E / H;
@@ -397,11 +435,17 @@ static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, in
         if (c->env == ORC_ENV_TSP) {
             if (istep == 0) ctx = c->cvec[e];
             else ctx = c->Pa[(bi * M + first) * (long)E + e] + c->Pb[(bi * M + cur) * (long)E + e];
-        } else {
+        } else {   /* CVRP and SDVRP: VRPContext */
             ctx = fmaf(c->cvec[e], remaining, c->Pa[(bi * M + cur) * (long)E + e]);
         }
         q[e] = ctx + g;
     }
+    /* SDVRP: row n of K / V / Lp gets rem[n] * (its dynamic vector) added, element by element (product rounded, then
+     * the sum rounded), before it enters the chains below -- the reference's cached + dynamic embeddings */
+    const float* dk = (c->env == ORC_ENV_SDVRP) ? c->dyn : NULL;
+    const float* dv = dk ? c->dyn + E : NULL;
+    const float* dl = dk ? c->dyn + 2 * E : NULL;
+#define DYN(base_, vec_, n_, col_) ((vec_) ? (base_) + rem[n_] * (vec_)[col_] : (base_))
     /* D2-D4 glimpse */
     const int C = (M + ORC_NCHUNK - 1) / ORC_NCHUNK;
     const float qk_scale = 1.0f / sqrtf((float)D);
@@ -411,7 +455,7 @@ static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, in
         for (int n = 0; n < M; ++n) {
             if (!mask[n]) { wh[n] = -INFINITY; continue; }
             float acc = 0.0f;
-            for (int d = 0; d < D; ++d) acc = fmaf(q[h * D + d], K[(long)n * E + h * D + d], acc);
+            for (int d = 0; d < D; ++d) acc = fmaf(q[h * D + d], DYN(K[(long)n * E + h * D + d], dk, n, h * D + d), acc);
             acc = acc * qk_scale;                 /* 1/sqrt(D); D=16 -> exactly 0.25 */
             wh[n] = acc;
             if (acc > mx) mx = acc;
@@ -428,7 +472,7 @@ static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, in
             for (int g = 0; g < ORC_NCHUNK; ++g) {
                 float ag = 0.0f;
                 for (int n = g * C; n < M && n < (g + 1) * C; ++n)
-                    ag = fmaf(wh[n], V[(long)n * E + h * D + d], ag);
+                    ag = fmaf(wh[n], DYN(V[(long)n * E + h * D + d], dv, n, h * D + d), ag);
                 A = (g == 0) ? ag : A + ag;
             }
             heads[h * D + d] = A / Z;
@@ -443,7 +487,7 @@ static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, in
         float u = 0.0f;
         for (int g = 0; g < ORC_NCHUNK; ++g) {
             float cg = 0.0f;
-            for (int e = g * EC; e < (g + 1) * EC; ++e) cg = fmaf(heads[e], Lp[(long)n * E + e], cg);
+            for (int e = g * EC; e < (g + 1) * EC; ++e) cg = fmaf(heads[e], DYN(Lp[(long)n * E + e], dl, n, e), cg);
             u = (g == 0) ? cg : u + cg;
         }
         float logit = u / sqrtE;
@@ -525,20 +569,21 @@ ORC_API int orc_decode_step(int env, long R, long Binst, int M, int E, int H,
                             const float* Pa, const float* Pb, const float* cvec, const float* gctx,
                             const int64_t* first, const int64_t* cur, const int64_t* istep,
                             const float* used, const float* vcap, const uint8_t* mask,
+                            const float* rem, const float* dyn,
                             int mode, const float* noise, const int64_t* given, float clip, float temp,
                             int top_k, float top_p,
                             int64_t* out_action, float* out_logp, float* out_logits, float* out_logprobs)
 {
-    orc_dec_t c = { env, R, Binst, M, E, H, K, V, Lp, Pa, Pb, cvec, gctx, clip, temp, top_k, top_p };
+    orc_dec_t c = { env, R, Binst, M, E, H, K, V, Lp, Pa, Pb, cvec, gctx, clip, temp, dyn, top_k, top_p };
     int status = 0;
 #pragma omp parallel
     {
         float* scratch = (float*)malloc(sizeof(float) * (2 * (long)E + (long)H * M + 2 * (long)M));
 #pragma omp for schedule(static)
         for (long r = 0; r < R; ++r) {
-            float rem = (env == ORC_ENV_CVRP) ? (vcap[r] - used[r]) : 0.0f;
-            int st = decode_row(&c, r, first ? first[r] : 0, cur[r], istep ? istep[r] : 1, rem,
-                                mask + r * (long)M, mode, noise ? noise + r * (long)M : NULL,
+            float remaining = (env != ORC_ENV_TSP) ? (vcap[r] - used[r]) : 0.0f;
+            int st = decode_row(&c, r, first ? first[r] : 0, cur[r], istep ? istep[r] : 1, remaining,
+                                rem ? rem + r * (long)M : NULL, mask + r * (long)M, mode, noise ? noise + r * (long)M : NULL,
                                 given ? given[r] : 0, out_action + r, out_logp + r,
                                 out_logits ? out_logits + r * (long)M : NULL,
                                 out_logprobs ? out_logprobs + r * (long)M : NULL, scratch);
@@ -659,7 +704,7 @@ ORC_API int orc_rollout(int env, long R, long Binst, int M, int E, int H,
                         const float* Pa, const float* Pb, const float* cvec, const float* gctx,
                         int64_t* first, int64_t* cur, int64_t* istep,
                         float* used, const float* vcap, const float* demand,
-                        uint8_t* mask, uint8_t* visited, uint8_t* done,
+                        uint8_t* mask, uint8_t* visited, uint8_t* done, float* rem, const float* dyn,
                         int mode, const float* noise, const int64_t* given, int Tgiven,
                         float clip, float temp, int top_k, float top_p, int Tmax,
                         int64_t* actions, float* logps)
@@ -676,11 +721,12 @@ ORC_API int orc_rollout(int env, long R, long Binst, int M, int E, int H,
         if (noise) for (long r = 0; r < R; ++r) memcpy(nz + r * M, noise + (r * (long)Tmax + t) * M, sizeof(float) * M);
         if (given) for (long r = 0; r < R; ++r) gv[r] = (t < Tgiven) ? given[r * (long)Tgiven + t] : 0;
         status = orc_decode_step(env, R, Binst, M, E, H, K, V, Lp, Pa, Pb, cvec, gctx, first, cur, istep,
-                                 used, vcap, mask, mode, nz, gv, clip, temp, top_k, top_p, a, lp, NULL, NULL);
+                                 used, vcap, mask, rem, dyn, mode, nz, gv, clip, temp, top_k, top_p, a, lp, NULL, NULL);
         if (status != 0) break;
         for (long r = 0; r < R; ++r) { actions[r * (long)Tmax + t] = a[r]; logps[r * (long)Tmax + t] = lp[r]; }
         if (env == ORC_ENV_TSP) orc_tsp_step(mask, first, cur, istep, a, done, R, M);
-        else orc_cvrp_step(visited, used, vcap, demand, cur, a, mask, done, R, Binst, M - 1);
+        else if (env == ORC_ENV_CVRP) orc_cvrp_step(visited, used, vcap, demand, cur, a, mask, done, R, Binst, M - 1);
+        else orc_sdvrp_step(rem, used, vcap, cur, a, mask, done, R, M);
         ++t;
     }
     free(a); free(lp); free(nz); free(gv);

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ENV_TSP, ENV_CVRP = 0, 1
+ENV_TSP, ENV_CVRP, ENV_SDVRP = 0, 1, 2
 GREEDY, SAMPLE, EVALUATE = 0, 1, 2
 MODES = {"greedy": GREEDY, "sampling": SAMPLE, "evaluate": EVALUATE}
 
@@ -213,6 +213,10 @@ def precompute(sd, env_name, emb, use_graph_context=True):
         out["Pb"] = None
         out["cvec"] = np.ascontiguousarray(Wctx[:, E])
     out["gctx"] = linear(mean_nodes(emb), sd["decoder.project_fixed_context.weight"]) if use_graph_context else None
+    if env_name == "sdvrp":      # SDVRPDynamicEmbedding: Linear(1, 3E, bias=False); the logit part folded like Lp
+        w = _f32(sd["decoder.dynamic_embedding.projection.weight"]).reshape(3, E)
+        lw = matmul_right(np.ascontiguousarray(w[2:3]), sd["decoder.pointer.project_out.weight"])[0]
+        out["dyn"] = np.ascontiguousarray(np.stack([w[0], w[1], lw]).astype(np.float32))
     return out
 
 
@@ -224,7 +228,8 @@ class State:
 
     def __init__(self, env_name, locs, demand=None, vehicle_capacity=1.0, num_starts=0):
         self.env_name = env_name
-        self.env = ENV_TSP if env_name == "tsp" else ENV_CVRP
+        self.env = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP}[env_name]
+        self.rem = None
         self.locs = _f32(locs)
         self.Binst, self.M = self.locs.shape[:2]
         S = max(int(num_starts), 1)
@@ -239,6 +244,14 @@ class State:
             self.demand = None
             self.visited = None
             self.mask = np.ones((R, self.M), np.uint8)
+        elif env_name == "sdvrp":        # remaining demand per row, depot slot 0 (sdvrp/env.py:94-118)
+            self.demand = _f32(demand)
+            self.visited = None
+            d = np.concatenate([np.zeros((self.Binst, 1), np.float32), self.demand], 1)
+            self.rem = np.ascontiguousarray(np.tile(d, (S, 1)))
+            self.mask = np.empty((R, self.M), np.uint8)
+            lib().orc_sdvrp_mask(_p(self.rem), _p(self.used), _p(self.vcap), _p(self.cur), _p(self.mask), C.c_long(R),
+                                 C.c_int(self.M))
         else:
             self.demand = _f32(demand)
             self.visited = np.zeros((R, self.M), np.uint8)
@@ -251,6 +264,9 @@ class State:
         if self.env == ENV_TSP:
             lib().orc_tsp_step(_p(self.mask), _p(self.first), _p(self.cur), _p(self.istep), _p(a), _p(self.done),
                                C.c_long(self.R), C.c_int(self.M))
+        elif self.env == ENV_SDVRP:
+            lib().orc_sdvrp_step(_p(self.rem), _p(self.used), _p(self.vcap), _p(self.cur), _p(a), _p(self.mask),
+                                 _p(self.done), C.c_long(self.R), C.c_int(self.M))
         else:
             lib().orc_cvrp_step(_p(self.visited), _p(self.used), _p(self.vcap), _p(self.demand), _p(self.cur),
                                 _p(a), _p(self.mask), _p(self.done), C.c_long(self.R), C.c_long(self.Binst),
@@ -271,6 +287,7 @@ def decode_step(st: State, cache, mode="greedy", noise=None, given=None, clip=10
         C.c_int(st.env), C.c_long(R), C.c_long(st.Binst), C.c_int(M), C.c_int(E), C.c_int(num_heads),
         _p(cache["K"]), _p(cache["V"]), _p(cache["Lp"]), _p(cache["Pa"]), _p(cache["Pb"]), _p(cache["cvec"]),
         _p(cache["gctx"]), _p(st.first), _p(st.cur), _p(st.istep), _p(st.used), _p(st.vcap), _p(st.mask),
+        _p(st.rem), _p(cache.get("dyn")),
         C.c_int(MODES[mode]), _p(nz), _p(gv), C.c_float(clip), C.c_float(temp), C.c_int(int(top_k)), C.c_float(top_p),
         _p(act), _p(lp), _p(logits), _p(logprobs))
     if rc == -1:
@@ -286,7 +303,7 @@ def rollout(st: State, cache, mode="greedy", noise=None, given=None, clip=10.0, 
     R, M = st.R, st.M
     E = cache["K"].shape[-1]
     if t_max is None:
-        t_max = M if st.env == ENV_TSP else 2 * M + 1
+        t_max = M if st.env == ENV_TSP else (2 * M + 1 if st.env == ENV_CVRP else 3 * M + 1)
     if noise is not None:
         noise = _f32(noise)
         t_max = noise.shape[1]
@@ -301,7 +318,8 @@ def rollout(st: State, cache, mode="greedy", noise=None, given=None, clip=10.0, 
         C.c_int(st.env), C.c_long(R), C.c_long(st.Binst), C.c_int(M), C.c_int(E), C.c_int(num_heads),
         _p(cache["K"]), _p(cache["V"]), _p(cache["Lp"]), _p(cache["Pa"]), _p(cache["Pb"]), _p(cache["cvec"]),
         _p(cache["gctx"]), _p(st.first), _p(st.cur), _p(st.istep), _p(st.used), _p(st.vcap), _p(st.demand),
-        _p(st.mask), _p(st.visited), _p(st.done), C.c_int(MODES[mode]), _p(noise), _p(given), C.c_int(tg),
+        _p(st.mask), _p(st.visited), _p(st.done), _p(st.rem), _p(cache.get("dyn")), C.c_int(MODES[mode]), _p(noise),
+        _p(given), C.c_int(tg),
         C.c_float(clip), C.c_float(temp), C.c_int(int(top_k)), C.c_float(top_p), C.c_int(t_max), _p(actions), _p(logps))
     if T == -1:
         raise AssertionError("Logits contain NaNs")
@@ -359,7 +377,7 @@ def policy_rollout(sd, env_name, locs, demand=None, decode_type="greedy", num_st
     if multistart:
         # select_start_nodes: row j = s*B + b starts at node s (TSP) / s+1 (CVRP)   [utils/ops.py:133-169]
         B = st.Binst
-        nloc = st.M if env_name == "tsp" else st.M - 1
+        nloc = st.M if env_name == "tsp" else st.M - 1          # depot cannot be a start node (utils/ops.py:120-130)
         start = (np.repeat(np.arange(num_starts), B) % nloc + (0 if env_name == "tsp" else 1)).astype(np.int64)
         if given is not None:
             start, given = _i64(given[:, 0]), np.ascontiguousarray(given[:, 1:])

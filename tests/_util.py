@@ -10,6 +10,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 with open(os.path.join(GOLDEN, "state_dict_contract.json")) as _f:
     CONTRACT = json.load(_f)
+with open(os.path.join(GOLDEN, "state_dict_contract_sdvrp.json")) as _f:      # the split-delivery sibling env
+    CONTRACT.update(json.load(_f))
 
 
 def golden(name):
@@ -18,7 +20,7 @@ def golden(name):
 
 
 def golden_weights(cfg):
-    """{key: float32 ndarray} for a contract config: am_tsp, am_cvrp, pomo_tsp, pomo_cvrp."""
+    """{key: float32 ndarray} for a contract config: am_tsp, am_cvrp, am_sdvrp, pomo_tsp, pomo_cvrp."""
     sd = {}
     for k, shape, dt in CONTRACT[cfg]:
         if dt != "float32":

@@ -36,6 +36,7 @@ import torch  # noqa: E402
 import goldweights  # noqa: E402
 import rl4co.utils.decoding as ref_decoding  # noqa: E402
 from rl4co.envs.routing.cvrp.env import CVRPEnv  # noqa: E402
+from rl4co.envs.routing.sdvrp.env import SDVRPEnv  # noqa: E402
 from rl4co.envs.routing.tsp.env import TSPEnv  # noqa: E402
 from rl4co.models.zoo.am.policy import AttentionModelPolicy  # noqa: E402
 
@@ -109,7 +110,7 @@ def np_(t):
 def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_starts=None,
              keep_steps=None, keep_embeds=False, data_seed=1234, sample_seed=4321, actions=None,
              td_init=None, decode_kw=None):
-    Env = TSPEnv if env_name == "tsp" else CVRPEnv
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv}[env_name]
     env = Env(generator_params=dict(num_loc=num_loc), seed=data_seed)
     if td_init is None:
         torch.manual_seed(data_seed)
@@ -142,7 +143,7 @@ def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_st
         "step_mask": np.stack([np_(rec.masks[s]) for s in steps], 1),
         "n_decoder_steps": np.array(T, dtype=np.int64),
     }
-    if env_name == "cvrp":
+    if env_name in ("cvrp", "sdvrp"):
         fx["demand"] = np_(td_init["demand"])
         fx["vehicle_capacity"] = np_(td_init["vehicle_capacity"])
     if rec.noise:
@@ -169,7 +170,7 @@ def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_st
 
 def run_env_case(name, env_name, num_loc, batch, data_seed=99, act_seed=7):
     """Env-only golden: random feasible policy, every state tensor after every step."""
-    Env = TSPEnv if env_name == "tsp" else CVRPEnv
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv}[env_name]
     env = Env(generator_params=dict(num_loc=num_loc), seed=data_seed)
     torch.manual_seed(data_seed)
     gen = env.generator(batch_size=[batch])
@@ -181,7 +182,8 @@ def run_env_case(name, env_name, num_loc, batch, data_seed=99, act_seed=7):
     fx["reset_action_mask"] = np_(td["action_mask"])
     torch.manual_seed(act_seed)
     per = {k: [] for k in ("action", "action_mask", "done", "current_node")}
-    extra = ("first_node", "i") if env_name == "tsp" else ("used_capacity", "visited")
+    extra = {"tsp": ("first_node", "i"), "cvrp": ("used_capacity", "visited"),
+             "sdvrp": ("used_capacity", "demand_with_depot")}[env_name]
     for k in extra:
         per[k] = []
     while not td["done"].all():
@@ -271,6 +273,20 @@ def beam():
              decode_kw=dict(beam_width=12, select_best=False))
 
 
+def sdvrp():
+    """Fifth batch (python make_golden.py sdvrp): the split-delivery sibling env."""
+    import json
+    first4 = [0, 1, 2, 3]
+    sd = AttentionModelPolicy(env_name="sdvrp").state_dict()
+    with open(os.path.join(HERE, "state_dict_contract_sdvrp.json"), "w") as f:
+        json.dump({"am_sdvrp": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]}, f, indent=0)
+    run_case("sdvrp20_greedy", "sdvrp", 20, 4, "greedy", keep_embeds=True, data_seed=61)
+    run_case("sdvrp20_sampling", "sdvrp", 20, 4, "sampling", keep_steps=first4, data_seed=62)
+    run_case("sdvrp50_greedy", "sdvrp", 50, 4, "greedy", keep_steps=first4, data_seed=63)
+    run_case("sdvrp20_multistart_greedy", "sdvrp", 20, 3, "multistart_greedy", num_starts=20, keep_steps=first4, data_seed=64)
+    run_env_case("env_sdvrp20_random", "sdvrp", 20, 8)
+
+
 def filtering():
     """Fourth batch (python make_golden.py filtering): top-k / top-p (nucleus) filtering of process_logits."""
     first4 = [0, 1, 2, 3]
@@ -283,7 +299,9 @@ def filtering():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "filtering":
+    if len(sys.argv) > 1 and sys.argv[1] == "sdvrp":
+        sdvrp()
+    elif len(sys.argv) > 1 and sys.argv[1] == "filtering":
         filtering()
     elif len(sys.argv) > 1 and sys.argv[1] == "beam":
         beam()

@@ -22,6 +22,8 @@ POLICY_CASES = [
     "cvrp20_sampling_temp", "tsp20_greedy_noclip",
     # third batch: top-k / top-p filtering in process_logits
     "tsp20_sampling_topk5", "tsp20_sampling_topp", "cvrp20_sampling_topk_topp", "tsp100_greedy_topk",
+    # SDVRP (split delivery): dynamic embedding + partial-delivery state machine
+    "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy",
 ]
 
 
@@ -101,7 +103,7 @@ def test_per_step_logits_logprobs_masks(oracle, name):
     assert st.done.all()
 
 
-@pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random"])
+@pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random"])
 def test_env_state_machine_bit_exact(oracle, name):
     fx = golden(name)
     env = str(fx["env_name"])
@@ -121,6 +123,9 @@ def test_env_state_machine_bit_exact(oracle, name):
         if env == "tsp":
             assert np.array_equal(st.first, fx["step_first_node"][:, t]), t
             assert np.array_equal(st.istep, fx["step_i"][:, t].reshape(-1)), t
+        elif env == "sdvrp":
+            assert np.array_equal(st.rem, fx["step_demand_with_depot"][:, t]), t       # exact: min / add / sub only
+            assert np.array_equal(st.used, fx["step_used_capacity"][:, t].reshape(-1)), t
         else:
             assert np.array_equal(st.visited, fx["step_visited"][:, t]), t
             # one fp32 add + one mul per step, no reductions: exactly reproducible
@@ -129,8 +134,10 @@ def test_env_state_machine_bit_exact(oracle, name):
     np.testing.assert_allclose(reward, fx["reward"], rtol=1e-6, atol=0)
     if env == "tsp":
         assert oracle.check_tsp(fx["step_action"]) == 0
-    else:
+    elif env == "cvrp":
         assert oracle.check_cvrp(fx["step_action"], demand, 1.0) == 0
+    else:
+        assert (st.rem == 0).all()              # all demand delivered
 
 
 def test_validity_checks_reject_bad_tours(oracle):
