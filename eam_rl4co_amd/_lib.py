@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # EAMRL_HIP_LIB: development override (instrumented builds made by tools/); the default is the in-tree library
 LIB_PATH = os.environ.get("EAMRL_HIP_LIB") or os.path.join(_PKG, "lib", "libeamrl_hip.so")
 
-ENV_TSP, ENV_CVRP = 0, 1
+ENV_TSP, ENV_CVRP, ENV_SDVRP = 0, 1, 2
 GREEDY, SAMPLE, EVALUATE = 0, 1, 2
 NORM_BATCH_EVAL, NORM_INSTANCE = 0, 1
 ST_NAN_LOGITS, ST_INFEASIBLE, ST_STEP_OVERRUN = 1, 2, 4
@@ -20,13 +20,14 @@ _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 class Cache(C.Structure):
     """struct eamrl_cache"""
     _fields_ = [("K", _vp), ("V", _vp), ("Lp", _vp), ("Pa", _vp), ("Pb", _vp), ("cvec", _vp), ("gctx", _vp),
-                ("ld", _i64), ("B", _i64), ("M", C.c_int32), ("E", C.c_int32), ("H", C.c_int32)]
+                ("ld", _i64), ("B", _i64), ("M", C.c_int32), ("E", C.c_int32), ("H", C.c_int32),
+                ("dyn", _vp)]
 
 
 class State(C.Structure):
     """struct eamrl_state"""
     _fields_ = [("first", _vp), ("cur", _vp), ("istep", _vp), ("used", _vp), ("vcap", _vp), ("demand", _vp),
-                ("mask", _vp), ("visited", _vp), ("done", _vp)]
+                ("mask", _vp), ("visited", _vp), ("done", _vp), ("rem", _vp)]
 
 
 # name -> argtypes (all return int unless listed in _RESTYPES); mirrors include/eamrl.h one to one
@@ -37,6 +38,7 @@ PROTOTYPES = {
     "eamrl_tsp_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "eamrl_cvrp_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "eamrl_cvrp_step_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "eamrl_sdvrp_step_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "eamrl_linear": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
     "eamrl_linear_bn": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp],
     "eamrl_matmul_right": [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp],

@@ -79,6 +79,18 @@ __attribute__((visibility("default"))) int eamrl_cvrp_step_mask(uint8_t* visited
                     "eamrl_cvrp_step_mask");
 }
 
+__attribute__((visibility("default"))) int eamrl_sdvrp_step_mask(float* rem, float* used, const float* vcap, int64_t* cur,
+                                                                const int64_t* action, uint8_t* mask, uint8_t* done,
+                                                                int64_t R, int M, void* stream)
+{
+    REQUIRE(rem && used && vcap && cur && mask, "eamrl_sdvrp_step_mask");
+    REQUIRE(!action || done, "eamrl_sdvrp_step_mask");
+    REQUIRE(R >= 0 && M >= 2, "eamrl_sdvrp_step_mask");
+    if (R == 0) return 0;
+    return launched(launch_sdvrp(rem, used, vcap, cur, action, mask, done, R, M, (hipStream_t)stream),
+                    "eamrl_sdvrp_step_mask");
+}
+
 __attribute__((visibility("default"))) int eamrl_linear(const float* x, int64_t ldx, const float* W, int64_t ldw,
                                                        const float* bias, const float* res, int64_t ldres, float* y,
                                                        int64_t ldy, int64_t rows, int in_dim, int out_dim, int relu,
@@ -147,7 +159,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
                      uint32_t* status, DecArgs& a)
 {
     REQUIRE(c && s, what);
-    REQUIRE(env == EAMRL_ENV_TSP || env == EAMRL_ENV_CVRP, what);
+    REQUIRE(env == EAMRL_ENV_TSP || env == EAMRL_ENV_CVRP || env == EAMRL_ENV_SDVRP, what);
     REQUIRE(mode == EAMRL_GREEDY || mode == EAMRL_SAMPLE || mode == EAMRL_EVALUATE, what);
     REQUIRE(c->K && c->V && c->Lp && c->Pa && c->cvec, what);
     REQUIRE(c->B > 0 && c->M > 0 && c->E > 0 && c->H > 0, what);
@@ -159,6 +171,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
     REQUIRE(temp > 0.0f && top_k >= 0 && top_p >= 0.0f && top_p <= 1.0f, what);
     if (env == EAMRL_ENV_TSP) REQUIRE(c->Pb && s->first && s->istep, what);
     if (env == EAMRL_ENV_CVRP) REQUIRE(s->used && s->vcap && c->M >= 2, what);
+    if (env == EAMRL_ENV_SDVRP) REQUIRE(s->used && s->vcap && s->rem && c->dyn && c->M >= 2, what);
     if (mode == EAMRL_SAMPLE) REQUIRE(noise != nullptr, what);
     if (mode == EAMRL_EVALUATE) REQUIRE(given != nullptr, what);
     a = DecArgs{};
@@ -166,6 +179,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
     a.ld = c->ld; a.B = c->B; a.M = c->M; a.E = c->E; a.H = c->H;
     a.first = s->first; a.cur = s->cur; a.istep = s->istep; a.used = s->used; a.vcap = s->vcap; a.demand = s->demand;
     a.mask = s->mask; a.visited = s->visited; a.done = s->done;
+    a.rem = s->rem; a.dyn = c->dyn;
     a.R = R; a.mode = mode; a.noise = noise; a.given = given; a.clip = clip; a.temp = temp; a.top_k = top_k; a.top_p = top_p; a.status = status;
     return 0;
 }
@@ -209,7 +223,7 @@ __attribute__((visibility("default"))) int eamrl_am_rollout(int env, const eamrl
     a.fuse_env = 1; a.t_max = t_max; a.t_given = t_given;
     a.action = actions; a.logp = logps; a.steps_out = steps_out;
     const bool filtering = top_k > 0 || (top_p > 0.0f && top_p < 1.0f);        // only the streaming kernel filters
-    if (!g_debug[1] && !filtering && rollout_resident_supports(env, a))
+    if (!g_debug[1] && !filtering && env != EAMRL_ENV_SDVRP && rollout_resident_supports(env, a))
         return launched(launch_rollout_resident(env, a, (hipStream_t)stream), "eamrl_am_rollout");
     return launched(launch_rollout_stream(env, a, (hipStream_t)stream), "eamrl_am_rollout");
 }
@@ -237,7 +251,8 @@ __attribute__((visibility("default"))) int eamrl_check_solution(int env, const i
                                                                int32_t* bad, void* stream)
 {
     REQUIRE(actions && bad && R >= 0 && B > 0 && N > 0 && T > 0, "eamrl_check_solution");
-    if (env == EAMRL_ENV_CVRP) REQUIRE(demand && vcap, "eamrl_check_solution");
+    REQUIRE(env == EAMRL_ENV_TSP || env == EAMRL_ENV_CVRP || env == EAMRL_ENV_SDVRP, "eamrl_check_solution");
+    if (env != EAMRL_ENV_TSP) REQUIRE(demand && vcap, "eamrl_check_solution");
     if (R == 0) return 0;
     return launched(launch_check_solution(env, actions, demand, vcap, R, B, N, T, bad, (hipStream_t)stream),
                     "eamrl_check_solution");

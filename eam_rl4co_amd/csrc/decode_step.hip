@@ -42,10 +42,17 @@ __device__ __forceinline__ float block_max(float v, float* red)
 
 // Decode one row with the whole workgroup.  l.msk holds the row's action mask.  Outputs are
 // workgroup-uniform.  logprobs_row / logits_row may be null.
+//
+// SDVRP (ENV == EAMRL_ENV_SDVRP): `rem` (LDS, [M]) is the row's remaining demand and `dyn` (LDS, [3][E]) the dynamic
+// embedding vectors; every K / V / Lp element enters its chain as  x + rem[n] * dyn[i][c]  (product rounded, sum
+// rounded: the reference's cached + dynamic embeddings, zoo/am/decoder.py:176-183).  Both are unused otherwise.
 template <int ENV>
 __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const RowState& s, const float* noise_row,
-                           int64_t given, int64_t& out_a, float& out_lp, float* logprobs_row, float* logits_row)
+                           int64_t given, int64_t& out_a, float& out_lp, float* logprobs_row, float* logits_row,
+                           const float* rem = nullptr, const float* dyn = nullptr)
 {
+    constexpr bool SD = ENV == EAMRL_ENV_SDVRP;
+#define EAMRL_DYN(x_, rn_, w_) (SD ? (x_) + (rn_) * (w_) : (x_))
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int M = a.M, E = a.E, H = a.H, D = E / H;
     const int64_t bi = r % a.B;
@@ -76,12 +83,14 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
     for (int p0 = tid; p0 < M * H; p0 += DU2 * BLOCK) {
         float4 kk[DU2][4];
         bool on[DU2];
+        float rn[DU2];
 #pragma unroll
         for (int u = 0; u < DU2; ++u) {
             const int p = p0 + u * BLOCK;
             const int pc = p < M * H ? p : M * H - 1;
             const int n = pc / H, h = pc - n * H;
             on[u] = p < M * H && l.msk[n] != 0;
+            rn[u] = SD ? rem[n] : 0.0f;
             const float* kp = K + (int64_t)n * ld + h * D;
 #pragma unroll
             for (int d4 = 0; d4 < 4; ++d4)
@@ -93,13 +102,14 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             if (p >= M * H) break;
             const int n = p / H, h = p - n * H;
             const float* qp = l.q + h * D;
+            const float* wk = SD ? dyn + h * D : qp;
             float acc = 0.0f;
 #pragma unroll
             for (int d4 = 0; d4 < 4; ++d4) {
-                acc = fma_(qp[4 * d4], kk[u][d4].x, acc);
-                acc = fma_(qp[4 * d4 + 1], kk[u][d4].y, acc);
-                acc = fma_(qp[4 * d4 + 2], kk[u][d4].z, acc);
-                acc = fma_(qp[4 * d4 + 3], kk[u][d4].w, acc);
+                acc = fma_(qp[4 * d4], EAMRL_DYN(kk[u][d4].x, rn[u], wk[4 * d4]), acc);
+                acc = fma_(qp[4 * d4 + 1], EAMRL_DYN(kk[u][d4].y, rn[u], wk[4 * d4 + 1]), acc);
+                acc = fma_(qp[4 * d4 + 2], EAMRL_DYN(kk[u][d4].z, rn[u], wk[4 * d4 + 2]), acc);
+                acc = fma_(qp[4 * d4 + 3], EAMRL_DYN(kk[u][d4].w, rn[u], wk[4 * d4 + 3]), acc);
             }
             l.w[h * M + n] = on[u] ? acc * qk_scale : -INFINITY;
         }
@@ -112,13 +122,15 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         if (l.msk[n]) {
             const float* kp = K + (int64_t)n * ld + h * D;
             const float* qp = l.q + h * D;
+            const float* wk = SD ? dyn + h * D : qp;
+            const float rn = SD ? rem[n] : 0.0f;
             float acc = 0.0f;
             for (int d = 0; d < D; d += 4) {
                 float4 kk = *reinterpret_cast<const float4*>(kp + d);
-                acc = fma_(qp[d], kk.x, acc);
-                acc = fma_(qp[d + 1], kk.y, acc);
-                acc = fma_(qp[d + 2], kk.z, acc);
-                acc = fma_(qp[d + 3], kk.w, acc);
+                acc = fma_(qp[d], EAMRL_DYN(kk.x, rn, wk[d]), acc);
+                acc = fma_(qp[d + 1], EAMRL_DYN(kk.y, rn, wk[d + 1]), acc);
+                acc = fma_(qp[d + 2], EAMRL_DYN(kk.z, rn, wk[d + 2]), acc);
+                acc = fma_(qp[d + 3], EAMRL_DYN(kk.w, rn, wk[d + 3]), acc);
             }
             sc = acc * qk_scale;
         }
@@ -144,6 +156,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         const float* wh = l.w + h * M;
         const int n0 = g * C, n1 = min(M, n0 + C);
         float zg = 0.0f, ag = 0.0f;
+        const float wve = SD ? dyn[E + e] : 0.0f;
         // DU4 value loads in flight per thread; a masked node has w == +0 exactly, so adding its terms unconditionally
         // (with v = 0 in place of the skipped load) leaves both sums bit-identical
         for (int nb = n0; nb < n1; nb += DU4) {
@@ -152,7 +165,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             for (int u = 0; u < DU4; ++u) {
                 const int n = nb + u;
                 const bool onv = n < n1 && l.msk[n] != 0;
-                vv[u] = onv ? V[(int64_t)n * ld + e] : 0.0f;
+                vv[u] = onv ? EAMRL_DYN(V[(int64_t)n * ld + e], rem[n], wve) : 0.0f;
                 ww[u] = onv ? wh[n] : 0.0f;
             }
 #pragma unroll
@@ -181,12 +194,14 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         for (int p0 = tid; p0 < M * EAMRL_NCHUNK; p0 += 2 * BLOCK) {
             float4 lv[2][8];
             bool on[2];
+            float rn[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int p = p0 + u * BLOCK;
                 const int pc = p < M * EAMRL_NCHUNK ? p : M * EAMRL_NCHUNK - 1;
                 const int n = pc / EAMRL_NCHUNK, c = pc - n * EAMRL_NCHUNK;
                 on[u] = p < M * EAMRL_NCHUNK && l.msk[n] != 0;
+                rn[u] = (SD && on[u]) ? rem[n] : 0.0f;
                 const float* lp = Lp + (int64_t)n * ld + c * EC;
 #pragma unroll
                 for (int e4 = 0; e4 < 8; ++e4)
@@ -198,13 +213,14 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
                 if (p >= M * EAMRL_NCHUNK) break;
                 const int c = p % EAMRL_NCHUNK;
                 const float* hp = l.heads + c * EC;
+                const float* wl = SD ? dyn + 2 * E + c * EC : hp;
                 float cg = 0.0f;
 #pragma unroll
                 for (int e4 = 0; e4 < 8; ++e4) {
-                    cg = fma_(hp[4 * e4], lv[u][e4].x, cg);
-                    cg = fma_(hp[4 * e4 + 1], lv[u][e4].y, cg);
-                    cg = fma_(hp[4 * e4 + 2], lv[u][e4].z, cg);
-                    cg = fma_(hp[4 * e4 + 3], lv[u][e4].w, cg);
+                    cg = fma_(hp[4 * e4], EAMRL_DYN(lv[u][e4].x, rn[u], wl[4 * e4]), cg);
+                    cg = fma_(hp[4 * e4 + 1], EAMRL_DYN(lv[u][e4].y, rn[u], wl[4 * e4 + 1]), cg);
+                    cg = fma_(hp[4 * e4 + 2], EAMRL_DYN(lv[u][e4].z, rn[u], wl[4 * e4 + 2]), cg);
+                    cg = fma_(hp[4 * e4 + 3], EAMRL_DYN(lv[u][e4].w, rn[u], wl[4 * e4 + 3]), cg);
                 }
                 l.partL[p] = cg;       // masked node: all-zero operands -> chain of exact zeros, as before
             }
@@ -216,12 +232,14 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             if (l.msk[n]) {
                 const float* lp = Lp + (int64_t)n * ld + c * EC;
                 const float* hp = l.heads + c * EC;
+                const float* wl = SD ? dyn + 2 * E + c * EC : hp;
+                const float rn = SD ? rem[n] : 0.0f;
                 for (int e = 0; e < EC; e += 4) {
                     float4 v = *reinterpret_cast<const float4*>(lp + e);
-                    cg = fma_(hp[e], v.x, cg);
-                    cg = fma_(hp[e + 1], v.y, cg);
-                    cg = fma_(hp[e + 2], v.z, cg);
-                    cg = fma_(hp[e + 3], v.w, cg);
+                    cg = fma_(hp[e], EAMRL_DYN(v.x, rn, wl[e]), cg);
+                    cg = fma_(hp[e + 1], EAMRL_DYN(v.y, rn, wl[e + 1]), cg);
+                    cg = fma_(hp[e + 2], EAMRL_DYN(v.z, rn, wl[e + 2]), cg);
+                    cg = fma_(hp[e + 3], EAMRL_DYN(v.w, rn, wl[e + 3]), cg);
                 }
             }
             l.partL[p] = cg;
@@ -355,16 +373,43 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
     }
     out_a = sel;
     out_lp = l.x[sel];
+#undef EAMRL_DYN
 }
 
-// Apply the env transition to the LDS copy of the row (msk, and vis for CVRP) and the uniform state.
+// Apply the env transition to the LDS copy of the row (msk, vis for CVRP, rem for SDVRP) and the uniform state.
 template <int ENV>
-__device__ bool env_step_row(const DecArgs& a, const RowLds& l, uint8_t* vis, int64_t r, RowState& s, int64_t act)
+__device__ bool env_step_row(const DecArgs& a, const RowLds& l, uint8_t* vis, float* rem, int64_t r, RowState& s,
+                             int64_t act)
 {
     const int tid = threadIdx.x;
     const int M = a.M;
     __syncthreads();  // all readers of msk / x are done
-    if (ENV == EAMRL_ENV_TSP) {
+    if (ENV == EAMRL_ENV_SDVRP) {
+        // SDVRPEnv._step + get_action_mask (sdvrp/env.py:58-92,137-146): deliver min(remaining demand, free capacity)
+        const float sel = rem[act];
+        const float free_cap = s.vcap - s.used;
+        const float delivered = sel < free_cap ? sel : free_cap;
+        s.used = (s.used + delivered) * (act != 0 ? 1.0f : 0.0f);
+        s.cur = act;
+        __syncthreads();  // everyone has read rem[act]
+        if (tid == 0) rem[act] = sel + (-delivered);
+        __syncthreads();
+        const bool full = s.used >= s.vcap;
+        int any_free = 0, any_rem = 0;
+        for (int n = tid; n < M; n += BLOCK) {
+            const float rv = rem[n];
+            any_rem |= rv > 0.0f;
+            if (n >= 1) {
+                const int blocked = (rv == 0.0f) | full;
+                l.msk[n] = !blocked;
+                any_free |= !blocked;
+            }
+        }
+        any_free = __syncthreads_or(any_free);
+        any_rem = __syncthreads_or(any_rem);
+        if (tid == 0) l.msk[0] = !((s.cur == 0) && any_free);
+        return any_rem == 0;
+    } else if (ENV == EAMRL_ENV_TSP) {
         if (s.istep == 0) s.first = act;
         s.cur = act;
         s.istep += 1;
@@ -418,14 +463,15 @@ __device__ __forceinline__ void load_row_state(const DecArgs& a, int64_t r, RowS
 }
 
 template <int ENV>
-__device__ __forceinline__ void store_row_state(const DecArgs& a, const RowLds& l, const uint8_t* vis, int64_t r,
-                                                const RowState& s, bool done)
+__device__ __forceinline__ void store_row_state(const DecArgs& a, const RowLds& l, const uint8_t* vis, const float* rem,
+                                                int64_t r, const RowState& s, bool done)
 {
     const int tid = threadIdx.x;
     __syncthreads();
     for (int n = tid; n < a.M; n += BLOCK) {
         a.mask[r * a.M + n] = l.msk[n];
         if (ENV == EAMRL_ENV_CVRP) a.visited[r * a.M + n] = vis[n];
+        if (ENV == EAMRL_ENV_SDVRP) a.rem[r * a.M + n] = rem[n];
     }
     if (tid == 0) {
         a.cur[r] = s.cur;
@@ -435,30 +481,45 @@ __device__ __forceinline__ void store_row_state(const DecArgs& a, const RowLds& 
     }
 }
 
+// SDVRP rows keep two more LDS arrays behind `vis`: remaining demand [M] and the dynamic vectors [3][E].
+template <int ENV>
+__device__ __forceinline__ void load_row_lds(const DecArgs& a, const RowLds& l, uint8_t* vis, float* rem, float* dyn,
+                                             int64_t r, bool want_vis)
+{
+    const int tid = threadIdx.x;
+    for (int n = tid; n < a.M; n += BLOCK) {
+        l.msk[n] = a.mask[r * a.M + n];
+        if (ENV == EAMRL_ENV_CVRP && want_vis) vis[n] = a.visited[r * a.M + n];
+        if (ENV == EAMRL_ENV_SDVRP) rem[n] = a.rem[r * a.M + n];
+    }
+    if (ENV == EAMRL_ENV_SDVRP)
+        for (int e = tid; e < 3 * a.E; e += BLOCK) dyn[e] = a.dyn[e];
+}
+
 template <int ENV>
 __global__ __launch_bounds__(BLOCK) void k_decode_step(DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowLds l = carve_row_lds(smem, a.M, a.E, a.H);
-    uint8_t* vis = l.msk + ((a.M + 15) & ~15);
+    const int Mp = (a.M + 15) & ~15;
+    uint8_t* vis = l.msk + Mp;
+    float* rem = reinterpret_cast<float*>(vis + Mp);
+    float* dyn = rem + Mp;
     const int64_t r = blockIdx.x;
     const int tid = threadIdx.x;
     RowState s;
     load_row_state<ENV>(a, r, s);
-    for (int n = tid; n < a.M; n += BLOCK) {
-        l.msk[n] = a.mask[r * a.M + n];
-        if (ENV == EAMRL_ENV_CVRP && a.fuse_env) vis[n] = a.visited[r * a.M + n];
-    }
+    load_row_lds<ENV>(a, l, vis, rem, dyn, r, a.fuse_env != 0);
     __syncthreads();
     int64_t act;
     float lp;
     decode_row<ENV>(a, l, r, s, a.noise ? a.noise + r * a.M : nullptr, a.given ? a.given[r] : 0, act, lp,
                     a.logprobs_all ? a.logprobs_all + r * a.M : nullptr,
-                    a.logits_raw ? a.logits_raw + r * a.M : nullptr);
+                    a.logits_raw ? a.logits_raw + r * a.M : nullptr, rem, dyn);
     if (tid == 0) { a.action[r] = act; a.logp[r] = lp; }
     if (a.fuse_env) {
-        const bool done = env_step_row<ENV>(a, l, vis, r, s, act);
-        store_row_state<ENV>(a, l, vis, r, s, done);
+        const bool done = env_step_row<ENV>(a, l, vis, rem, r, s, act);
+        store_row_state<ENV>(a, l, vis, rem, r, s, done);
     }
 }
 
@@ -468,15 +529,15 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_stream(DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowLds l = carve_row_lds(smem, a.M, a.E, a.H);
-    uint8_t* vis = l.msk + ((a.M + 15) & ~15);
+    const int Mp = (a.M + 15) & ~15;
+    uint8_t* vis = l.msk + Mp;
+    float* rem = reinterpret_cast<float*>(vis + Mp);
+    float* dyn = rem + Mp;
     const int64_t r = blockIdx.x;
     const int tid = threadIdx.x;
     RowState s;
     load_row_state<ENV>(a, r, s);
-    for (int n = tid; n < a.M; n += BLOCK) {
-        l.msk[n] = a.mask[r * a.M + n];
-        if (ENV == EAMRL_ENV_CVRP) vis[n] = a.visited[r * a.M + n];
-    }
+    load_row_lds<ENV>(a, l, vis, rem, dyn, r, true);
     bool done = a.done[r] != 0;
     __syncthreads();
     int t = 0;
@@ -485,12 +546,12 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_stream(DecArgs a)
         float lp;
         const float* nz = a.noise ? a.noise + (r * a.t_max + t) * (int64_t)a.M : nullptr;
         const int64_t gv = a.given ? (t < a.t_given ? a.given[r * a.t_given + t] : 0) : 0;
-        decode_row<ENV>(a, l, r, s, nz, gv, act, lp, nullptr, nullptr);
+        decode_row<ENV>(a, l, r, s, nz, gv, act, lp, nullptr, nullptr, rem, dyn);
         if (tid == 0) { a.action[r * a.t_max + t] = act; a.logp[r * a.t_max + t] = lp; }
-        done = env_step_row<ENV>(a, l, vis, r, s, act);
+        done = env_step_row<ENV>(a, l, vis, rem, r, s, act);
         ++t;
     }
-    store_row_state<ENV>(a, l, vis, r, s, done);
+    store_row_state<ENV>(a, l, vis, rem, r, s, done);
     if (tid == 0) {
         atomicMax(a.steps_out, t);
         if (!done) atomicOr(a.status, EAMRL_ST_STEP_OVERRUN);
@@ -516,19 +577,25 @@ __global__ void k_rollout_pad_cvrp(DecArgs a)
 
 static int launch_decode(int env, const DecArgs& a, bool rollout, hipStream_t st)
 {
-    const size_t lds = row_lds_bytes(a.M, a.E, a.H) + (((size_t)a.M + 15) & ~(size_t)15);
+    const size_t Mp = ((size_t)a.M + 15) & ~(size_t)15;
+    size_t lds = row_lds_bytes(a.M, a.E, a.H) + Mp;                       // + visited bytes
+    if (env == EAMRL_ENV_SDVRP) lds += 4 * Mp + 12 * (size_t)a.E;          // + remaining demand + dynamic vectors
     if (lds > 160 * 1024) return EAMRL_E_ARG;
     dim3 grid((unsigned)a.R), block(BLOCK);
     void (*k)(DecArgs);
-    if (rollout) k = env == EAMRL_ENV_TSP ? k_rollout_stream<EAMRL_ENV_TSP> : k_rollout_stream<EAMRL_ENV_CVRP>;
-    else k = env == EAMRL_ENV_TSP ? k_decode_step<EAMRL_ENV_TSP> : k_decode_step<EAMRL_ENV_CVRP>;
+    if (rollout)
+        k = env == EAMRL_ENV_TSP ? k_rollout_stream<EAMRL_ENV_TSP>
+          : env == EAMRL_ENV_CVRP ? k_rollout_stream<EAMRL_ENV_CVRP> : k_rollout_stream<EAMRL_ENV_SDVRP>;
+    else
+        k = env == EAMRL_ENV_TSP ? k_decode_step<EAMRL_ENV_TSP>
+          : env == EAMRL_ENV_CVRP ? k_decode_step<EAMRL_ENV_CVRP> : k_decode_step<EAMRL_ENV_SDVRP>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return EAMRL_E_LAUNCH;
     }
     hipLaunchKernelGGL(k, grid, block, lds, st, a);
-    if (rollout && env == EAMRL_ENV_CVRP)
+    if (rollout && env != EAMRL_ENV_TSP)
         hipLaunchKernelGGL(k_rollout_pad_cvrp, dim3((unsigned)((a.R + 255) / 256)), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }

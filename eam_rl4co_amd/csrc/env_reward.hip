@@ -2,6 +2,7 @@
 //
 //   k_tsp_step         TSPEnv._step                        rl4co/envs/routing/tsp/env.py:62-88
 //   k_cvrp_step_mask   CVRPEnv._step + get_action_mask     rl4co/envs/routing/cvrp/env.py:68-100,132-144
+//   k_sdvrp_step_mask  SDVRPEnv._step + get_action_mask    rl4co/envs/routing/sdvrp/env.py:58-92,137-146
 //   k_tour_length      get_reward                          rl4co/utils/ops.py:59-95, tsp/env.py:152-159, cvrp/env.py:146-155
 //   k_sum_logp         get_log_likelihood                  rl4co/utils/decoding.py:38-64
 //   k_check_*          check_solution_validity             tsp/env.py:161-168, cvrp/env.py:157-185
@@ -84,6 +85,100 @@ __global__ __launch_bounds__(EB) void k_cvrp_step_mask(uint8_t* visited, float* 
             done[r] = (allc && v0) ? 1 : 0;
         }
     }
+}
+
+// SDVRP: rem = demand_with_depot.  STEP = 0: mask only; STEP = 1: deliver min(rem[action], free capacity), then mask.
+template <int STEP>
+__global__ __launch_bounds__(EB) void k_sdvrp_step_mask(float* rem, float* used, const float* vcap, int64_t* cur,
+                                                        const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R,
+                                                        int M)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float* rr = rem + r * M;
+    float u = used[r];
+    const float cap = vcap[r];
+    int64_t c = cur[r];
+    int64_t a = -1;
+    float left = 0.0f;
+    if (STEP) {
+        a = action[r];
+        a = a < 0 ? 0 : (a > M - 1 ? M - 1 : a);     // an out-of-range action must not become an out-of-bounds access
+        const float sel = rr[a];
+        const float free_cap = cap - u;
+        const float delivered = sel < free_cap ? sel : free_cap;
+        u = (u + delivered) * (a != 0 ? 1.0f : 0.0f);
+        left = sel + (-delivered);
+        c = a;
+    }
+    const bool full = u >= cap;
+    int any_free = 0, any_rem = 0;
+    for (int n = lane; n < M; n += 64) {
+        float rv = rr[n];
+        if (STEP && n == a) { rv = left; rr[n] = left; }
+        any_rem |= rv > 0.0f;
+        if (n >= 1) {
+            const int blocked = (rv == 0.0f) | full;
+            mask[r * M + n] = !blocked;
+            any_free |= !blocked;
+        }
+    }
+    const bool anyf = __ballot(any_free != 0) != 0ull;
+    const bool anyr = __ballot(any_rem != 0) != 0ull;
+    if (lane == 0) {
+        mask[r * M] = !((c == 0) && anyf);
+        if (STEP) {
+            used[r] = u;
+            cur[r] = c;
+            done[r] = anyr ? 0 : 1;
+        }
+    }
+}
+
+// SDVRPEnv.check_solution_validity (sdvrp/env.py:148-171): replay the deliveries over the vector
+// (-vehicle_capacity, demand...).  One wavefront per row, the vector in LDS; the replay is sequential by definition.
+__global__ __launch_bounds__(EB) void k_check_sdvrp(const int64_t* actions, const float* demand, const float* vcap,
+                                                    int64_t R, int64_t B, int N, int T, int32_t* bad)
+{
+    extern __shared__ float dem_all[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wv;
+    if (r >= R) return;
+    const int M = N + 1;
+    float* d = dem_all + (size_t)wv * M;
+    const float cap = vcap[r];
+    const float* dem = demand + (r % B) * N;
+    for (int n = lane; n < M; n += 64) d[n] = n == 0 ? -cap : dem[n - 1];
+    __builtin_amdgcn_wave_barrier();
+    const int64_t* act = actions + r * T;
+    float usedc = 0.0f;
+    int64_t prev = -1;
+    int twice = 0, range = 0;
+    for (int t = 0; t < T; ++t) {
+        const int64_t a = act[t];
+        if (a < 0 || a > N) { range = 1; break; }
+        if (t > 0 && prev == 0 && a == 0) {           // "Cannot visit depot twice if any nonzero demand"
+            int nz = 0;
+            for (int n = lane; n < M; n += 64) nz |= d[n] != 0.0f;
+            if (__ballot(nz != 0) != 0ull) twice = 1;
+        }
+        const float da = d[a];
+        const float free_cap = cap - usedc;
+        const float dl = da < free_cap ? da : free_cap;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) d[a] = da - dl;
+        __builtin_amdgcn_wave_barrier();
+        usedc = usedc + dl;
+        if (a == 0) usedc = 0.0f;
+        prev = a;
+    }
+    int nz = 0;
+    for (int n = lane; n < M; n += 64) nz |= d[n] != 0.0f;
+    const bool left = __ballot(nz != 0) != 0ull;
+    if (lane != 0) return;
+    if (range || left) atomicAdd(&bad[0], 1);
+    if (twice) atomicAdd(&bad[1], 1);
 }
 
 __global__ __launch_bounds__(EB) void k_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R,
@@ -261,6 +356,18 @@ int launch_cvrp(int step, uint8_t* visited, float* used, const float* vcap, cons
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 
+int launch_sdvrp(float* rem, float* used, const float* vcap, int64_t* cur, const int64_t* action, uint8_t* mask,
+                 uint8_t* done, int64_t R, int M, hipStream_t st)
+{
+    if (action)
+        hipLaunchKernelGGL(k_sdvrp_step_mask<1>, dim3(row_blocks(R)), dim3(EB), 0, st, rem, used, vcap, cur, action, mask,
+                           done, R, M);
+    else
+        hipLaunchKernelGGL(k_sdvrp_step_mask<0>, dim3(row_blocks(R)), dim3(EB), 0, st, rem, used, vcap, cur, action, mask,
+                           done, R, M);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
 int launch_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R, int64_t B, int M, int T,
                        int with_depot, hipStream_t st)
 {
@@ -290,6 +397,14 @@ int launch_check_solution(int env, const int64_t* actions, const float* demand, 
                           int N, int T, int32_t* bad, hipStream_t st)
 {
     if (N + 1 > 4096) return EAMRL_E_ARG;
+    if (env == EAMRL_ENV_SDVRP) {
+        const size_t lds = (size_t)ROWS_PER_BLOCK * (N + 1) * sizeof(float);
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_check_sdvrp),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return EAMRL_E_LAUNCH;
+        hipLaunchKernelGGL(k_check_sdvrp, dim3(row_blocks(R)), dim3(EB), lds, st, actions, demand, vcap, R, B, N, T, bad);
+        return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+    }
     hipLaunchKernelGGL(k_check_solution, dim3(row_blocks(R)), dim3(EB), 0, st, env, actions, demand, vcap, R, B, N, T, bad);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }

@@ -31,6 +31,8 @@ int launch_tsp_step(uint8_t* mask, int64_t* first, int64_t* cur, int64_t* istep,
                     uint8_t* done, int64_t R, int N, hipStream_t st);
 int launch_cvrp(int step, uint8_t* visited, float* used, const float* vcap, const float* demand, int64_t* cur,
                 const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N, hipStream_t st);
+int launch_sdvrp(float* rem, float* used, const float* vcap, int64_t* cur, const int64_t* action, uint8_t* mask,
+                 uint8_t* done, int64_t R, int M, hipStream_t st);
 int launch_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R, int64_t B, int M, int T,
                        int with_depot, hipStream_t st);
 int launch_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, hipStream_t st);

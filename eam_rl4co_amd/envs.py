@@ -221,13 +221,13 @@ class RL4COEnvBase:
 
     def get_num_starts(self, td):
         n = td["action_mask"].shape[-1]
-        return n - 1 if self.name == "cvrp" else n          # depot cannot be a start node (utils/ops.py:120-130)
+        return n - 1 if self.name in ("cvrp", "sdvrp") else n          # depot cannot be a start node (utils/ops.py:120-130)
 
     def select_start_nodes(self, td, num_starts):
         """POMO start nodes: flat row j = s*B + b starts at node s (+1 with a depot) (utils/ops.py:133-169)."""
         num_loc = getattr(self.generator, "num_loc", 0xFFFFFFFF)
         sel = torch.arange(num_starts, device=td.device).repeat_interleave(td.shape[0]) % num_loc
-        return sel + 1 if self.name == "cvrp" else sel
+        return sel + 1 if self.name in ("cvrp", "sdvrp") else sel
 
     def check_solution_validity(self, td, actions) -> None:
         raise NotImplementedError
@@ -424,12 +424,62 @@ class CVRPEnv(RL4COEnvBase):
         return cur_actions
 
 
-ENV_REGISTRY = {"tsp": TSPEnv, "cvrp": CVRPEnv}
+class SDVRPEnv(CVRPEnv):
+    """Split Delivery VRP (rl4co/envs/routing/sdvrp/env.py:17-200): CVRP instances whose customers may be served in
+    several visits; the state keeps the remaining demand (`demand_with_depot`) instead of a visited set."""
+
+    name = "sdvrp"
+
+    def _reset(self, td=None, batch_size=None):
+        dev = td.device
+        demand = td["demand"]
+        rem = torch.cat((torch.zeros_like(demand[..., 0:1]), demand), -1).contiguous()
+        out = TensorDict({
+            "locs": torch.cat((td["depot"][..., None, :], td["locs"]), -2),
+            "demand": demand,
+            "demand_with_depot": rem,
+            "current_node": torch.zeros(*batch_size, 1, dtype=torch.int64, device=dev),
+            "used_capacity": torch.zeros(*batch_size, 1, dtype=torch.float32, device=dev),
+            "vehicle_capacity": torch.full((*batch_size, 1), self.generator.vehicle_capacity, dtype=torch.float32,
+                                           device=dev),
+        }, batch_size=batch_size)
+        # Reset-state mask in closed form (vehicle empty, at the depot): a customer is feasible iff it has demand and
+        # the capacity is positive; the depot is infeasible while any customer is (sdvrp/env.py:137-146).
+        free = ~((rem[..., 1:] == 0) | (out["used_capacity"] >= out["vehicle_capacity"]))
+        out.set("action_mask", torch.cat((~free.any(-1, keepdim=True), free), -1))
+        return out
+
+    def _step(self, td):
+        mask = td["action_mask"]
+        if not mask.is_contiguous():
+            mask = mask.contiguous()
+        done = _flat(td["done"], torch.bool)
+        rem = td["demand_with_depot"]
+        ops.sdvrp_step_mask_(rem, _flat(td["used_capacity"], torch.float32), _flat(td["vehicle_capacity"], torch.float32),
+                             _flat(td["current_node"], torch.int64), td["action"].reshape(-1).contiguous(), mask, done)
+        td.update({"action_mask": mask, "done": done, "reward": torch.zeros_like(done)})
+        return td
+
+    def get_action_mask(self, td):
+        rem = td["demand_with_depot"]
+        mask = torch.empty(rem.shape, dtype=torch.bool, device=rem.device)
+        ops.sdvrp_step_mask_(rem.contiguous(), _flat(td["used_capacity"], torch.float32),
+                             _flat(td["vehicle_capacity"], torch.float32), _flat(td["current_node"], torch.int64), None,
+                             mask)
+        return mask
+
+    def check_solution_validity(self, td, actions) -> None:
+        bad = ops.check_solution("sdvrp", actions.contiguous(), td["demand"].contiguous(), td["vehicle_capacity"]).tolist()
+        assert bad[1] == 0, "Cannot visit depot twice if any nonzero demand"
+        assert bad[0] == 0, "All demand must be satisfied"
+
+
+ENV_REGISTRY = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv}
 
 
 def get_env(env_name: str, *args, **kwargs) -> RL4COEnvBase:
     cls = ENV_REGISTRY.get(env_name)
     if cls is None:
         raise ValueError(f"Unknown environment {env_name}. Available environments: {list(ENV_REGISTRY)} "
-                         "(only the TSP / CVRP rollout path is built for MI355X)")
+                         "(only the TSP / CVRP / SDVRP rollout path is built for MI355X)")
     return cls(*args, **kwargs)

@@ -8,11 +8,11 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ENV_CVRP, ENV_TSP, EVALUATE, GREEDY, NORM_BATCH_EVAL, NORM_INSTANCE, SAMPLE,  # noqa: F401
+from ._lib import (ENV_CVRP, ENV_SDVRP, ENV_TSP, EVALUATE, GREEDY, NORM_BATCH_EVAL, NORM_INSTANCE, SAMPLE,  # noqa: F401
                    ST_INFEASIBLE, ST_NAN_LOGITS, ST_STEP_OVERRUN)
 
 MODES = {"greedy": GREEDY, "sampling": SAMPLE, "evaluate": EVALUATE}
-ENVS = {"tsp": ENV_TSP, "cvrp": ENV_CVRP}
+ENVS = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP}
 
 
 def _need_gpu(t: torch.Tensor, name: str):
@@ -212,6 +212,24 @@ def cvrp_step_mask_(visited, used, vcap, demand, cur, action, mask, done):
 # ------------------------------------------------------------------------------------------------------
 # reward
 # ------------------------------------------------------------------------------------------------------
+def sdvrp_step_mask_(rem, used, vcap, cur, action, mask, done=None):
+    """SDVRPEnv._step + get_action_mask in place (sdvrp/env.py:58-92,137-146); action None: mask only."""
+    lib = _lib.load()
+    R, M = rem.shape
+    _chk(rem, "demand_with_depot", torch.float32)
+    _chk(used, "used_capacity", torch.float32, (R,))
+    _chk(vcap, "vehicle_capacity", torch.float32, (R,))
+    _chk(cur, "current_node", torch.int64, (R,))
+    _chk(mask, "action_mask", torch.bool, (R, M))
+    if action is not None:
+        _chk(action, "action", torch.int64, (R,))
+        _chk(done, "done", torch.bool, (R,))
+    _lib.check(lib.eamrl_sdvrp_step_mask(_ptr(rem), _ptr(used), _ptr(vcap), _ptr(cur), _ptr(action), _ptr(_bytes(mask)),
+                                         _ptr(_bytes(done)) if done is not None else None, R, M, _stream(mask)),
+               "eamrl_sdvrp_step_mask")
+    return mask
+
+
 def tour_length_reward(locs, actions, with_depot):
     lib = _lib.load()
     _chk(locs, "locs", torch.float32)
@@ -238,7 +256,7 @@ def sum_logp(logp):
 
 
 def check_solution(env_name, actions, demand=None, vcap=None, num_loc=None):
-    """-> device int32[2]: (invalid tours, over-capacity rows)."""
+    """-> device int32[2]: (invalid tours, over-capacity rows); sdvrp: (rows with demand left, double depot visits)."""
     lib = _lib.load()
     _chk(actions, "actions", torch.int64)
     R, T = actions.shape
@@ -254,7 +272,7 @@ def check_solution(env_name, actions, demand=None, vcap=None, num_loc=None):
         if vc.numel() != R:
             vc = vc.repeat(R // vc.numel())
         _chk(vc, "vehicle_capacity", torch.float32, (R,))
-        _lib.check(lib.eamrl_check_solution(ENV_CVRP, _ptr(actions), _ptr(demand), _ptr(vc), R, B, N, T, _ptr(bad),
+        _lib.check(lib.eamrl_check_solution(ENVS[env_name], _ptr(actions), _ptr(demand), _ptr(vc), R, B, N, T, _ptr(bad),
                                             _stream(actions)), "eamrl_check_solution")
     return bad
 
@@ -353,8 +371,9 @@ class DecodeCache:
     (zoo/am/decoder.py:206-235); P_* and Lp are the weight folds described in DESIGN.md.
     """
 
-    def __init__(self, env_name, buf, cvec, gctx, embeddings, num_heads):
+    def __init__(self, env_name, buf, cvec, gctx, embeddings, num_heads, dyn=None):
         self.env_name, self.buf, self.cvec, self.gctx = env_name, buf, cvec, gctx
+        self.dyn = dyn          # sdvrp: [3, E] dynamic-embedding vectors (key, value, folded logit key)
         self.node_embeddings = embeddings
         self.B, self.M, self.ld = buf.shape
         self.E = embeddings.shape[-1]
@@ -393,6 +412,7 @@ class DecodeCache:
         c.Pb = C.c_void_p(base + self.slots["Pb"] * step) if "Pb" in self.slots else None
         c.cvec, c.gctx = _ptr(self.cvec), _ptr(self.gctx)
         c.ld, c.B, c.M, c.E, c.H = self.ld, self.B, self.M, self.E, self.H
+        c.dyn = _ptr(self.dyn)
         return c
 
 
@@ -412,17 +432,20 @@ class RolloutState:
         self.istep = torch.zeros(R, **i64)
         self.done = torch.zeros(R, dtype=torch.bool, device=device)
         self.mask = torch.ones(R, M, dtype=torch.bool, device=device)
-        self.used = self.vcap = self.visited = None
+        self.used = self.vcap = self.visited = self.rem = None
         self.demand = demand
-        if env_name == "cvrp":
+        if env_name in ("cvrp", "sdvrp"):
             self.used = torch.zeros(R, dtype=torch.float32, device=device)
             self.vcap = torch.ones(R, dtype=torch.float32, device=device)
+        if env_name == "cvrp":
             self.visited = torch.zeros(R, M, dtype=torch.uint8, device=device)
+        if env_name == "sdvrp":
+            self.rem = torch.zeros(R, M, dtype=torch.float32, device=device)   # demand_with_depot
 
     def reorder_(self, idx):
         """Rows taken from rows `idx` (beam search: every beam continues the state of its parent beam).  vcap is
         per instance and the row order keeps r % B, so it needs no reordering, nor does demand."""
-        for name in ("first", "cur", "istep", "done", "mask", "used", "visited"):
+        for name in ("first", "cur", "istep", "done", "mask", "used", "visited", "rem"):
             v = getattr(self, name)
             if v is not None:
                 setattr(self, name, v.index_select(0, idx).contiguous())
@@ -432,6 +455,7 @@ class RolloutState:
         s.first, s.cur, s.istep = _ptr(self.first), _ptr(self.cur), _ptr(self.istep)
         s.used, s.vcap, s.demand = _ptr(self.used), _ptr(self.vcap), _ptr(self.demand)
         s.mask, s.visited, s.done = _ptr(_bytes(self.mask)), _ptr(self.visited), _ptr(_bytes(self.done))
+        s.rem = _ptr(getattr(self, "rem", None))
         return s
 
 
@@ -448,8 +472,12 @@ def _validate_state(st: RolloutState, cache: DecodeCache):
     else:
         _chk(st.used, "used_capacity", torch.float32, (R,))
         _chk(st.vcap, "vehicle_capacity", torch.float32, (R,))
-        _chk(st.visited, "visited", torch.uint8, (R, M))
-        _chk(st.demand, "demand", torch.float32, (cache.B, M - 1))
+        if st.env_name == "sdvrp":
+            _chk(st.rem, "demand_with_depot", torch.float32, (R, M))
+            _chk(cache.dyn, "dynamic embedding vectors", torch.float32, (3, cache.E))
+        else:
+            _chk(st.visited, "visited", torch.uint8, (R, M))
+            _chk(st.demand, "demand", torch.float32, (cache.B, M - 1))
 
 
 def decode_step(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0,
@@ -484,7 +512,7 @@ def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, giv
     _validate_state(st, cache)
     R, M, dev = st.R, st.M, st.mask.device
     if t_max is None:
-        t_max = M if st.env_name == "tsp" else 2 * M + 1
+        t_max = {"tsp": M, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1}[st.env_name]
     t_given = 0
     if noise is not None:
         _chk(noise, "noise", torch.float32)
@@ -500,7 +528,7 @@ def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, giv
             raise ValueError("given actions must be [R, T]")
         t_given = given.shape[1]
         if noise is None:
-            t_max = min(t_max, t_given) if st.env_name == "cvrp" else t_max
+            t_max = min(t_max, t_given) if st.env_name != "tsp" else t_max
     actions = torch.zeros(R, t_max, dtype=torch.int64, device=dev)
     logps = torch.zeros(R, t_max, dtype=torch.float32, device=dev)
     info = torch.zeros(2, dtype=torch.int32, device=dev)  # [steps, status]

@@ -156,7 +156,8 @@ class AttentionModelEncoder(nn.Module):
             raise NotImplementedError("moe_kwargs / sdpa_fn injection is outside the MI355X rollout path")
         self.env_name = env_name
         if init_embedding is None:
-            init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding}[env_name](embed_dim)
+            init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding,
+                              "sdvrp": VRPInitEmbedding}[env_name](embed_dim)
         self.init_embedding = init_embedding
         self.net = GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden) \
             if net is None else net
@@ -190,6 +191,17 @@ class StaticEmbedding(nn.Module):
         return 0, 0, 0
 
 
+class SDVRPDynamicEmbedding(nn.Module):
+    """Parameters of the SDVRP dynamic embedding (nn/env_embeddings/dynamic.py:59-78): Linear(1, 3E) of the remaining
+    demand, added to the cached glimpse key / value / logit key at every step (inside the decode kernels)."""
+
+    def __init__(self, embed_dim, linear_bias=False):
+        super().__init__()
+        if linear_bias:
+            raise NotImplementedError("SDVRPDynamicEmbedding with bias is not built for MI355X")
+        self.projection = nn.Linear(1, 3 * embed_dim, bias=False)
+
+
 class AttentionModelDecoder(nn.Module):
     """Pointer decoder.  `_precompute_cache` is the one-shot part (GEMMs), `forward` one decode step."""
 
@@ -201,13 +213,13 @@ class AttentionModelDecoder(nn.Module):
             env_name = env_name.name
         if any(x is not None for x in (context_embedding, dynamic_embedding, sdpa_fn, pointer, moe_kwargs)) or linear_bias:
             raise NotImplementedError("custom context/dynamic embeddings, pointer, sdpa_fn, MoE and decoder biases are "
-                                      "outside the MI355X rollout path (TSP / CVRP AttentionModel only)")
+                                      "outside the MI355X rollout path (TSP / CVRP / SDVRP AttentionModel only)")
         assert embed_dim % num_heads == 0
         self.env_name, self.embed_dim, self.num_heads = env_name, embed_dim, num_heads
         self.context_embedding = _ContextParams(embed_dim, 2 * embed_dim if env_name == "tsp" else embed_dim + 1,
                                                 placeholder=(env_name == "tsp"))
-        self.dynamic_embedding = StaticEmbedding()
-        self.is_dynamic_embedding = False
+        self.dynamic_embedding = SDVRPDynamicEmbedding(embed_dim) if env_name == "sdvrp" else StaticEmbedding()
+        self.is_dynamic_embedding = env_name == "sdvrp"
         self.pointer = _PointerParams(embed_dim, num_heads, mask_inner, out_bias_pointer_attn, check_nan)
         self.project_node_embeddings = nn.Linear(embed_dim, 3 * embed_dim, bias=False)
         self.project_fixed_context = nn.Linear(embed_dim, embed_dim, bias=False)
@@ -231,7 +243,12 @@ class AttentionModelDecoder(nn.Module):
         gctx = None
         if self.use_graph_context:
             gctx = ops.linear(ops.mean_nodes(emb), self.project_fixed_context.weight)
-        return ops.DecodeCache(self.env_name, buf, cvec.contiguous(), gctx, emb, self.num_heads)
+        dyn = None
+        if self.is_dynamic_embedding:       # key and value columns as they are; the logit-key column times project_out
+            w = self.dynamic_embedding.projection.weight.detach().reshape(3, E)
+            lw = ops.matmul_right(w[2:3].contiguous(), self.pointer.project_out.weight.contiguous())
+            dyn = torch.cat((w[0:2], lw), 0).contiguous()
+        return ops.DecodeCache(self.env_name, buf, cvec.contiguous(), gctx, emb, self.num_heads, dyn=dyn)
 
     def _weight_constants(self):
         """Tensors that depend on the weights only, recomputed when a parameter changes (optimizer step, load):
@@ -264,6 +281,22 @@ class AttentionModelDecoder(nn.Module):
         return logits, td["action_mask"]
 
 
+def _env_step_(st: ops.RolloutState, action):
+    """The env transition (+ mask) of `st.env_name` on the flat state, in place."""
+    if st.env_name == "tsp":
+        ops.tsp_step_(st.mask, st.first, st.cur, st.istep, action, st.done)
+    elif st.env_name == "cvrp":
+        ops.cvrp_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, action, st.mask, st.done)
+    else:
+        ops.sdvrp_step_mask_(st.rem, st.used, st.vcap, st.cur, action, st.mask, st.done)
+
+
+def _max_decode_steps(env_name, M, npre=0):
+    """TSP: one step per remaining node; CVRP: every customer visit is followed by at most one depot visit; SDVRP: as
+    CVRP plus at most one split delivery per trip."""
+    return {"tsp": M - npre, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1}[env_name]
+
+
 # ------------------------------------------------------------------------------------------------------------
 # TensorDict <-> flat rollout state
 # ------------------------------------------------------------------------------------------------------------
@@ -293,15 +326,18 @@ def state_from_td(env_name, td, num_starts: int = 0) -> ops.RolloutState:
     st.cur = rep(td["current_node"], torch.int64)
     done = td["done"] if "done" in td.keys() else torch.zeros(B, dtype=torch.bool, device=dev)
     st.done = rep(done, torch.bool)
-    st.first = st.istep = st.used = st.vcap = st.visited = st.demand = None
+    st.first = st.istep = st.used = st.vcap = st.visited = st.demand = st.rem = None
     if env_name == "tsp":
         st.first = rep(td["first_node"], torch.int64)
         st.istep = rep(td["i"], torch.int64)
     else:
         st.used = rep(td["used_capacity"], torch.float32)
         st.vcap = rep(td["vehicle_capacity"], torch.float32)
-        st.visited = rep(td["visited"], torch.uint8)
         st.demand = td["demand"].contiguous()
+        if env_name == "cvrp":
+            st.visited = rep(td["visited"], torch.uint8)
+        else:
+            st.rem = rep(td["demand_with_depot"], torch.float32)
     return st
 
 
@@ -313,7 +349,8 @@ def state_to_td(env_name, st: ops.RolloutState, td, locs_rows=None):
         out.update({"first_node": st.first, "current_node": st.cur, "i": st.istep.reshape(R, 1)})
     else:
         out.update({"current_node": st.cur.reshape(R, 1), "used_capacity": st.used.reshape(R, 1),
-                    "vehicle_capacity": st.vcap.reshape(R, 1), "visited": st.visited})
+                    "vehicle_capacity": st.vcap.reshape(R, 1)})
+        out.update({"visited": st.visited} if env_name == "cvrp" else {"demand_with_depot": st.rem})
     B = td.batch_size[0]
     S = R // B
     for k, v in td.items():
@@ -345,8 +382,8 @@ class AttentionModelPolicy(nn.Module):
             log.error("Found %d unused kwargs: %s", len(unused_kwargs), unused_kwargs)
         if isinstance(env_name, RL4COEnvBase):
             env_name = env_name.name
-        if env_name not in ("tsp", "cvrp"):
-            raise NotImplementedError(f"env_name={env_name!r}: the MI355X rollout path covers 'tsp' and 'cvrp'")
+        if env_name not in ("tsp", "cvrp", "sdvrp"):
+            raise NotImplementedError(f"env_name={env_name!r}: the MI355X rollout path covers 'tsp', 'cvrp' and 'sdvrp'")
         if moe_kwargs not in (None, {"encoder": None, "decoder": None}) or any(
                 x is not None for x in (sdpa_fn, sdpa_fn_encoder, sdpa_fn_decoder, encoder_network)):
             raise NotImplementedError("MoE / sdpa_fn / encoder_network injection is outside the MI355X rollout path")
@@ -442,16 +479,12 @@ class AttentionModelPolicy(nn.Module):
             else:
                 start = env.select_start_nodes(td, num_starts=S)
             start = start.to(torch.int64).contiguous()
-            if self.env_name == "tsp":
-                ops.tsp_step_(st.mask, st.first, st.cur, st.istep, start, st.done)
-            else:
-                ops.cvrp_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, start, st.mask, st.done)
+            _env_step_(st, start)
             pre_actions, pre_logps = [start[:, None]], [torch.zeros(st.R, 1, dtype=torch.float32, device=start.device)]
 
         # main decoding loop: one launch
         M = st.M
-        # TSP: one step per remaining node; CVRP: every customer visit is followed by at most one depot visit
-        t_max = (M - len(pre_actions)) if self.env_name == "tsp" else 2 * M + 1
+        t_max = _max_decode_steps(self.env_name, M, len(pre_actions))
         t_max = int(max(1, min(t_max, max_steps)))
         given = None
         if actions is not None:
@@ -480,14 +513,14 @@ class AttentionModelPolicy(nn.Module):
         # x + 0 is exact in the lane tree), nor the log-likelihood sum, nor validity.
         actions_pad = torch.cat(pre_actions + [acts], 1) if pre_actions else acts
         logp_pad = torch.cat(pre_logps + [lps], 1) if pre_logps else lps
-        native_env = type(env).__name__ in ("TSPEnv", "CVRPEnv") and type(env).__module__ == RL4COEnvBase.__module__
+        native_env = type(env).__name__ in ("TSPEnv", "CVRPEnv", "SDVRPEnv") and type(env).__module__ == RL4COEnvBase.__module__
         fast = info is not None and native_env and not select_best
         reward_pad = ll_pad = bad = None
         if fast:
             locs = td["locs"].contiguous()
             if calc_reward:
-                reward_pad = ops.tour_length_reward(locs, actions_pad, with_depot=(self.env_name == "cvrp"))
-                if env.check_solution:
+                reward_pad = ops.tour_length_reward(locs, actions_pad, with_depot=(self.env_name != "tsp"))
+                if env.check_solution and self.env_name != "sdvrp":   # sdvrp: replayed on the exact slice in _finish
                     bad = (ops.check_solution("tsp", actions_pad) if self.env_name == "tsp" else
                            ops.check_solution("cvrp", actions_pad, td["demand"].contiguous(), st.vcap))
             if return_sum_log_likelihood and "mask" not in td.keys():
@@ -537,6 +570,10 @@ class AttentionModelPolicy(nn.Module):
                     else:
                         assert bad_counts[0] == 0, "Invalid tour"
                         assert bad_counts[1] == 0, "Used more than capacity"
+                elif self.env_name == "sdvrp" and env.check_solution:
+                    # the reference's replay starts from (-capacity, demand...) and its verdict depends on where the
+                    # action tensor ends, so it runs on the exact [R, T] slice rather than on the padded one
+                    env.check_solution_validity(td_out, actions_out.contiguous())
                 if self.env_name == "tsp" and npre + T != p["actions_pad"].shape[1]:
                     td_out.set("reward", env.get_reward(td_out, actions_out.contiguous(), check_solution=False))
                 else:
@@ -588,10 +625,7 @@ class AttentionModelPolicy(nn.Module):
         st = state_from_td(self.env_name, td, BW)
         start = (select_start_nodes_fn(td, env, BW) if select_start_nodes_fn is not None
                  else env.select_start_nodes(td, num_starts=BW)).to(torch.int64).contiguous()
-        if self.env_name == "tsp":
-            ops.tsp_step_(st.mask, st.first, st.cur, st.istep, start, st.done)
-        else:
-            ops.cvrp_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, start, st.mask, st.done)
+        _env_step_(st, start)
         dev = start.device
         R, M = st.R, st.M
         inst = torch.arange(B, device=dev).repeat(BW)
@@ -599,8 +633,7 @@ class AttentionModelPolicy(nn.Module):
         parents = [torch.zeros(R, dtype=torch.int64, device=dev)]
         parent_lp = torch.zeros(R, dtype=torch.float32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        t_max = (M - 1) if self.env_name == "tsp" else 2 * M + 1
-        t_max = int(max(1, min(t_max, max_steps)))
+        t_max = int(max(1, min(_max_decode_steps(self.env_name, M, 1), max_steps)))
         t = 0
         while t < t_max and not bool(st.done.all()):
             _, _, all_lp, _, _ = ops.decode_step(st, cache, "greedy", clip=tanh_clipping, temp=temperature,
@@ -609,10 +642,7 @@ class AttentionModelPolicy(nn.Module):
             node, beam, parent_lp, slp = ops.beam_topk(all_lp, parent_lp, B, BW)
             beam = beam.to(torch.int64)
             st.reorder_(inst + beam * B)
-            if self.env_name == "tsp":
-                ops.tsp_step_(st.mask, st.first, st.cur, st.istep, node, st.done)
-            else:
-                ops.cvrp_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, node, st.mask, st.done)
+            _env_step_(st, node)
             actions.append(node)
             step_lps.append(slp)
             parents.append(beam)

@@ -34,6 +34,7 @@ extern "C" {
 /* environments */
 #define EAMRL_ENV_TSP 0
 #define EAMRL_ENV_CVRP 1
+#define EAMRL_ENV_SDVRP 2 /* split delivery: CVRP instances, customers may be served in several visits */
 /* selection modes  [rl4co/utils/decoding.py:430-465] */
 #define EAMRL_GREEDY 0
 #define EAMRL_SAMPLE 1   /* argmax(p / noise), noise ~ Exp(1) supplied by the caller (== torch.multinomial) */
@@ -78,6 +79,13 @@ int eamrl_cvrp_mask(const uint8_t* visited, const float* used, const float* vcap
 int eamrl_cvrp_step_mask(uint8_t* visited, float* used, const float* vcap, const float* demand, int64_t* cur,
                          const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N,
                          void* stream);
+
+/* SDVRPEnv._step + get_action_mask  [rl4co/envs/routing/sdvrp/env.py:58-92,137-146].  In place.
+ * rem [R][M] f32 = demand_with_depot (remaining demand, depot slot 0), used/vcap [R] f32, cur [R] i64,
+ * mask [R][M] u8, done [R] u8.  action == NULL: only the mask is recomputed (get_action_mask; done may be NULL).
+ * The vehicle delivers min(rem[action], vcap - used); a row is done when no remaining demand is > 0. */
+int eamrl_sdvrp_step_mask(float* rem, float* used, const float* vcap, int64_t* cur, const int64_t* action,
+                          uint8_t* mask, uint8_t* done, int64_t R, int M, void* stream);
 
 /* ---- one-shot encoder + cache ------------------------------------------------------------------- */
 
@@ -129,6 +137,10 @@ typedef struct eamrl_cache {
     int64_t ld;        /* row stride of K/V/Lp/Pa/Pb in floats (>= E) */
     int64_t B;         /* instances */
     int32_t M, E, H;   /* nodes (incl. depot), embed dim, heads */
+    const float* dyn;  /* SDVRP only, else NULL: [3][E] dynamic-embedding vectors (SDVRPDynamicEmbedding,
+                        * nn/env_embeddings/dynamic.py:59-78): row n of K / V / Lp enters the step as
+                        * X[n][c] + rem[n] * dyn[i][c]  (i = 0 K, 1 V, 2 Lp; the Lp vector is the logit-key
+                        * column of the projection times pointer.project_out) */
 } eamrl_cache;
 
 /* Per-row rollout state (the TensorDict keys the reference's env keeps, tsp/env.py:105-115,
@@ -143,6 +155,7 @@ typedef struct eamrl_state {
     uint8_t* mask;     /* [R][M] action_mask (1 = feasible) */
     uint8_t* visited;  /* [R][M] CVRP visited */
     uint8_t* done;     /* [R] */
+    float* rem;        /* [R][M] SDVRP demand_with_depot (remaining demand), else NULL */
 } eamrl_state;
 
 /* One decode step for R rows = AttentionModelDecoder.forward + DecodingStrategy.step
@@ -180,7 +193,9 @@ int eamrl_tour_length(const float* locs, const int64_t* actions, float* reward, 
 int eamrl_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, void* stream);
 
 /* check_solution_validity on the device: bad[0] += invalid tours, bad[1] += over-capacity rows
- * [tsp/env.py:161-168; cvrp/env.py:157-185].  bad: device int32[2], caller zeroes. */
+ * [tsp/env.py:161-168; cvrp/env.py:157-185].  bad: device int32[2], caller zeroes.
+ * EAMRL_ENV_SDVRP replays the deliveries [sdvrp/env.py:148-171]: bad[0] += rows with demand left at the end,
+ * bad[1] += rows that visit the depot twice in a row while any entry of the replay's demand vector is nonzero. */
 int eamrl_check_solution(int env, const int64_t* actions, const float* demand, const float* vcap, int64_t R,
                          int64_t B, int N, int T, int32_t* bad, void* stream);
 

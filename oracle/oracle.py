@@ -411,6 +411,7 @@ def policy_beam_search(sd, env_name, locs, demand=None, beam_width=None, select_
     actions, step_lps, parents = [start], [np.zeros(R, np.float32)], [np.zeros(R, np.int64)]
     parent_lp = np.zeros(R, np.float32)
     while not st.done.all():
+        assert len(actions) <= 3 * M + 1, "beam search exceeded the maximum number of steps"
         _, _, _, logprobs = decode_step(st, cache, "greedy", clip=clip, temp=temp, num_heads=num_heads, want_all=True)
         cand = (logprobs + parent_lp[:, None]).astype(np.float32)                     # [R, M]
         flat = cand.reshape(BW, B, M).transpose(1, 0, 2).reshape(B, BW * M)          # [B, BW*M], index w*M + n
@@ -421,7 +422,7 @@ def policy_beam_search(sd, env_name, locs, demand=None, beam_width=None, select_
                 node[k * B + b], beam[k * B + b], new_parent[k * B + b] = c % M, c // M, flat[b, c]
         idx = inst + beam * B
         slp = logprobs[idx, node]
-        for name in ("first", "cur", "istep", "done", "mask", "used", "visited"):
+        for name in ("first", "cur", "istep", "done", "mask", "used", "visited", "rem"):
             v = getattr(st, name)
             if v is not None:
                 setattr(st, name, np.ascontiguousarray(v[idx]))

@@ -285,6 +285,7 @@ def sdvrp():
     run_case("sdvrp50_greedy", "sdvrp", 50, 4, "greedy", keep_steps=first4, data_seed=63)
     run_case("sdvrp20_multistart_greedy", "sdvrp", 20, 3, "multistart_greedy", num_starts=20, keep_steps=first4, data_seed=64)
     run_env_case("env_sdvrp20_random", "sdvrp", 20, 8)
+    run_case("sdvrp20_beam", "sdvrp", 20, 3, "beam_search", keep_steps=first4, data_seed=65, decode_kw=dict(beam_width=6, select_best=True))
 
 
 def filtering():

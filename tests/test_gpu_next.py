@@ -475,7 +475,7 @@ def test_beam_topk_kernel(B, BW, M):
         np.testing.assert_array_equal(slp.cpu().numpy()[b::B], lp.reshape(BW, B, M)[order // M, b, order % M])
 
 
-@pytest.mark.parametrize("name", ["tsp20_beam", "tsp20_beam5_all", "cvrp20_beam", "tsp50_beam12_all"])
+@pytest.mark.parametrize("name", ["tsp20_beam", "tsp20_beam5_all", "cvrp20_beam", "tsp50_beam12_all", "sdvrp20_beam"])
 def test_beam_search_reproduces_reference_tours(oracle, name):
     fx = golden(name)
     cfg = cfg_for(fx)

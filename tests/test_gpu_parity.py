@@ -56,7 +56,7 @@ def make_td(env_name, locs, demand=None):
     """Post-reset TensorDict on the GPU from golden inputs (CVRP locs already include the depot)."""
     import eam_rl4co_amd as ea
 
-    env = ea.get_env(env_name, generator_params=dict(num_loc=locs.shape[1] - (env_name == "cvrp")))
+    env = ea.get_env(env_name, generator_params=dict(num_loc=locs.shape[1] - (env_name != "tsp")))
     if env_name == "tsp":
         td = ea.TensorDict({"locs": torch.from_numpy(locs)}, batch_size=[locs.shape[0]])
     else:
@@ -201,7 +201,8 @@ def test_encoder_and_cache_bit_exact(oracle, name):
 
 
 STEP_CASES = ["tsp20_greedy", "tsp100_greedy", "cvrp20_greedy", "cvrp100_greedy", "cvrp100_sampling",
-              "tsp20_multistart_greedy", "cvrp20_multistart_greedy", "pomo_tsp20_multistart_sampling"]
+              "tsp20_multistart_greedy", "cvrp20_multistart_greedy", "pomo_tsp20_multistart_sampling",
+              "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy"]
 
 
 @pytest.mark.parametrize("name", STEP_CASES)
@@ -209,7 +210,7 @@ def test_decode_step_api_bit_exact_every_step(oracle, name):
     """Step API (decode kernel + stand-alone env kernels) replaying the reference's actions: logits,
     log-probs, selected action, masks and all state equal the oracle at EVERY step."""
     from eam_rl4co_amd import ops
-    from eam_rl4co_amd.policy import state_from_td
+    from eam_rl4co_amd.policy import _env_step_, state_from_td
 
     fx = golden(name)
     cfg = cfg_for(fx)
@@ -230,10 +231,7 @@ def test_decode_step_api_bit_exact_every_step(oracle, name):
     if ns > 1:
         a0 = np.ascontiguousarray(actions[:, 0])
         ost.step(a0)
-        if env_name == "tsp":
-            ops.tsp_step_(st.mask, st.first, st.cur, st.istep, t(a0), st.done)
-        else:
-            ops.cvrp_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, t(a0), st.mask, st.done)
+        _env_step_(st, t(a0))
         col = 1
     has_noise = "noise" in fx
     for step in range(int(fx["n_decoder_steps"])):
@@ -252,13 +250,15 @@ def test_decode_step_api_bit_exact_every_step(oracle, name):
         assert_bits_equal(lp, olp, f"logp step {step}")
         # env transition through the stand-alone kernels
         ost.step(oa)
+        _env_step_(st, a)
         if env_name == "tsp":
-            ops.tsp_step_(st.mask, st.first, st.cur, st.istep, a, st.done)
             assert_bits_equal(st.first, ost.first, "first")
             assert_bits_equal(st.istep, ost.istep, "i")
-        else:
-            ops.cvrp_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, a, st.mask, st.done)
+        elif env_name == "cvrp":
             assert_bits_equal(st.visited, ost.visited, "visited")
+            assert_bits_equal(st.used, ost.used, "used")
+        else:
+            assert_bits_equal(st.rem, ost.rem, "remaining demand")
             assert_bits_equal(st.used, ost.used, "used")
         assert_bits_equal(st.mask.to(torch.uint8), ost.mask, f"mask step {step}")
         assert_bits_equal(st.cur, ost.cur, "cur")
@@ -271,7 +271,8 @@ POLICY_CASES = ["tsp20_greedy", "tsp20_sampling", "tsp20_evaluate", "tsp20_multi
                 "cvrp100_greedy", "cvrp100_sampling", "pomo_tsp20_multistart_sampling",
                 "tsp50_greedy", "cvrp50_sampling", "tsp200_greedy", "cvrp200_greedy", "pomo_cvrp20_multistart_greedy",
                 "cvrp20_sampling_temp", "tsp20_greedy_noclip",
-                "tsp20_sampling_topk5", "tsp20_sampling_topp", "cvrp20_sampling_topk_topp", "tsp100_greedy_topk"]
+                "tsp20_sampling_topk5", "tsp20_sampling_topp", "cvrp20_sampling_topk_topp", "tsp100_greedy_topk",
+                "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy"]
 
 
 @pytest.mark.parametrize("stream_kernel", [0, 1])
@@ -322,7 +323,7 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
     assert_bits_equal(out["reward"], o["reward"], "reward vs oracle")
 
 
-@pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random"])
+@pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random"])
 def test_env_api_matches_reference_state_machine(name):
     """env.reset / env.step / env.get_reward through the RL4COEnvBase API against the reference's recorded states."""
     import eam_rl4co_amd as ea
@@ -345,12 +346,22 @@ def test_env_api_matches_reference_state_machine(name):
             assert_bits_equal(td["first_node"], fx["step_first_node"][:, step], "first")
             assert_bits_equal(td["i"], fx["step_i"][:, step], "i")
         else:
-            assert_bits_equal(td["visited"], fx["step_visited"][:, step], "visited")
+            if env_name == "cvrp":
+                assert_bits_equal(td["visited"], fx["step_visited"][:, step], "visited")
+            else:
+                assert_bits_equal(td["demand_with_depot"], fx["step_demand_with_depot"][:, step], "remaining demand")
             assert_bits_equal(td["used_capacity"], fx["step_used_capacity"][:, step], "used")
             assert_bits_equal(env.get_action_mask(td), fx["step_action_mask"][:, step], "get_action_mask")
     reward = env.get_reward(td, t(fx["step_action"]))
     np.testing.assert_allclose(reward.cpu().numpy(), fx["reward"], rtol=1e-6, atol=0)
     bad = fx["step_action"].copy()
+    if env_name == "sdvrp":     # the reference's own asserts (sdvrp/env.py:148-171)
+        with pytest.raises(AssertionError, match="All demand must be satisfied"):
+            env.get_reward(td, t(np.ascontiguousarray(bad[:, :5])))      # the tours stop early
+        twice = np.concatenate([np.zeros((bad.shape[0], 2), np.int64), fx["step_action"]], 1)
+        with pytest.raises(AssertionError, match="Cannot visit depot twice"):
+            env.get_reward(td, t(twice))
+        return
     bad[0, -1] = bad[0, 0] if env_name == "tsp" else bad[0, np.nonzero(bad[0])[0][0]]
     with pytest.raises(AssertionError, match="Invalid tour"):
         env.get_reward(td, t(bad))
@@ -368,7 +379,8 @@ def test_random_policy_rollout_helper_shapes():
 
 
 @pytest.mark.parametrize("env_name,N,B,mode", [("tsp", 100, 1024, "greedy"), ("cvrp", 100, 1024, "sampling"),
-                                                ("tsp", 20, 128, "greedy"), ("cvrp", 500, 16, "greedy")])
+                                                ("tsp", 20, 128, "greedy"), ("cvrp", 500, 16, "greedy"),
+                                                ("sdvrp", 100, 256, "sampling"), ("sdvrp", 200, 32, "greedy")])
 def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
     """BASELINE.json configs at full size (C2, C3, C1, C5 with a reduced batch so the CPU oracle finishes in
     seconds): tours bit-identical to the oracle, plus size-independent properties."""
@@ -380,13 +392,13 @@ def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
     td_cpu = env.reset(batch_size=[B])
     td = td_cpu.to(DEV)
     locs = td_cpu["locs"].numpy()
-    demand = td_cpu["demand"].numpy() if env_name == "cvrp" else None
+    demand = td_cpu["demand"].numpy() if env_name != "tsp" else None
     M = locs.shape[1]
     kw = {}
     noise = None
     if mode == "sampling":
         g = torch.Generator().manual_seed(7)
-        noise = torch.empty(B, 2 * M + 1, M).exponential_(1, generator=g)
+        noise = torch.empty(B, (3 if env_name == "sdvrp" else 2) * M + 1, M).exponential_(1, generator=g)
         kw["noise"] = noise.to(DEV)
     out = pol(td, env, phase="test", decode_type=mode, return_sum_log_likelihood=False, **kw)
     acts = out["actions"].cpu().numpy()
@@ -395,8 +407,12 @@ def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
         assert (np.sort(acts, 1) == np.arange(N)).all()
         pts = np.take_along_axis(locs, acts[..., None].repeat(2, -1), 1).astype(np.float64)
     else:
-        srt = np.sort(acts, 1)
-        assert (srt[:, -N:] == np.arange(1, N + 1)).all() and (srt[:, :-N] == 0).all()
+        if env_name == "cvrp":
+            srt = np.sort(acts, 1)
+            assert (srt[:, -N:] == np.arange(1, N + 1)).all() and (srt[:, :-N] == 0).all()
+        else:       # split deliveries: every customer at least once, and everything delivered
+            assert all(set(range(1, N + 1)) <= set(row) for row in acts)
+            assert float(pol._last_td["demand_with_depot"].abs().max()) == 0.0
         pts = np.take_along_axis(locs, acts[..., None].repeat(2, -1), 1).astype(np.float64)
         pts = np.concatenate([locs[:, :1].astype(np.float64), pts], 1)
     length = np.linalg.norm(np.roll(pts, -1, 1) - pts, axis=-1).sum(1)
