@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/s of the AttentionModel construction rollout on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tsp100|cvrp100|tsp20|cvrp500] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tsp100|cvrp100|tsp20|cvrp500|pomo100|sdvrp100] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one full rollout of one batch: encoder + decoder cache + the whole decode loop (state update,
@@ -38,6 +38,7 @@ WORKLOADS = {
     "tsp20": ("tsp", 20, 128, "greedy"),           # configs[0]
     "cvrp100": ("cvrp", 100, 1024, "sampling"),    # configs[2]
     "cvrp500": ("cvrp", 500, 512, "greedy"),       # configs[4]
+    "sdvrp100": ("sdvrp", 100, 1024, "greedy"),    # sibling env: split deliveries, dynamic embedding
     # configs[3], per-GPU share: POMO policy (6 layers, instance norm, no graph context), num_starts = num_loc
     "pomo100": ("tsp", 100, 1024, "multistart_sampling"),
 }
@@ -58,6 +59,8 @@ def algorithmic_bytes_per_decode_step(env, M, E=128, S=1):
         return 12 * M * E + S * (8 * E + 2 * M + 28)
     if env == "tsp":
         return 12 * M * E + 4 * E * 2 + 2 * M + 28
+    if env == "sdvrp":      # mask r/w + remaining demand r/w instead of the visited bytes
+        return 12 * M * E + 4 * E * 1 + 2 * M + 32 + 8 * M
     return 12 * M * E + 4 * E * 1 + 2 * M + 32 + 2 * M
 
 
@@ -100,11 +103,11 @@ def cpu_baseline(env_name, num_loc, decode_type, num_starts=0, pomo=False, secon
         torch.manual_seed(1234)
         td = env.reset(batch_size=[batch])
         locs = td["locs"].numpy()
-        demand = td["demand"].numpy() if env_name == "cvrp" else None
+        demand = td["demand"].numpy() if env_name != "tsp" else None
         noise = None
         if "sampling" in decode_type:
             M = locs.shape[1]
-            noise = torch.empty(batch * S, 2 * M + 1, M).exponential_(1).numpy()
+            noise = torch.empty(batch * S, (3 if env_name == "sdvrp" else 2) * M + 1, M).exponential_(1).numpy()
         t0 = time.perf_counter()
         out = orc.policy_rollout(sd, env_name, locs, demand, decode_type=decode_type, num_starts=num_starts, noise=noise)
         return time.perf_counter() - t0, out["steps"]

@@ -164,7 +164,8 @@ typedef struct eamrl_state {
  * log_softmax -> greedy / sampling / evaluate.  top_k > 0: entries below the k-th largest scaled logit are dropped
  * (ties kept); 0 < top_p < 1: the lower tail whose running softmax mass (ascending order) is <= 1 - top_p is dropped
  * [utils/decoding.py:110-136,170-176]; 0 = off.  Reads the state, does not modify it unless fuse_env_step != 0, in which
- * case it also applies TSPEnv._step / CVRPEnv._step (+mask) with the selected action.
+ * case it also applies TSPEnv._step / CVRPEnv._step / SDVRPEnv._step (+mask) with the selected action.
+ * EAMRL_ENV_SDVRP: cache->dyn and state->rem are required (dynamic embedding of the remaining demand, see eamrl_cache).
  * noise [R][M] (SAMPLE) / given [R] (EVALUATE) else NULL.  Outputs: action [R], logp [R];
  * optional logprobs_all [R][M] (store_all_logp) and logits_raw [R][M] (pre-clip decoder logits). */
 int eamrl_am_decode_step(int env, const eamrl_cache* cache_host, const eamrl_state* state_host, int64_t R,
@@ -176,7 +177,7 @@ int eamrl_am_decode_step(int env, const eamrl_cache* cache_host, const eamrl_sta
  * repeats {decode step, env step} until every row is done or t_max steps were taken.  actions/logps are
  * [R][t_max] (right-padded: finished CVRP rows keep selecting the depot, logp 0).  noise [R][t_max][M],
  * given [R][t_given].  steps_out (device int32): number of steps executed = max over rows.  With top_k / top_p
- * filtering the streaming kernel is used (the register-resident one does not filter). */
+ * filtering, and for EAMRL_ENV_SDVRP, the streaming kernel is used (the register-resident one does neither). */
 int eamrl_am_rollout(int env, const eamrl_cache* cache_host, const eamrl_state* state_host, int64_t R, int mode,
                      const float* noise, const int64_t* given, int t_given, float tanh_clip, float temperature,
                      int top_k, float top_p, int t_max, int64_t* actions, float* logps, int32_t* steps_out,
