@@ -223,7 +223,7 @@ __attribute__((visibility("default"))) int eamrl_am_rollout(int env, const eamrl
     a.fuse_env = 1; a.t_max = t_max; a.t_given = t_given;
     a.action = actions; a.logp = logps; a.steps_out = steps_out;
     const bool filtering = top_k > 0 || (top_p > 0.0f && top_p < 1.0f);        // only the streaming kernel filters
-    if (!g_debug[1] && !filtering && env != EAMRL_ENV_SDVRP && rollout_resident_supports(env, a))
+    if (!g_debug[1] && !filtering && rollout_resident_supports(env, a))
         return launched(launch_rollout_resident(env, a, (hipStream_t)stream), "eamrl_am_rollout");
     return launched(launch_rollout_stream(env, a, (hipStream_t)stream), "eamrl_am_rollout");
 }

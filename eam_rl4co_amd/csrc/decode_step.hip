@@ -43,16 +43,21 @@ __device__ __forceinline__ float block_max(float v, float* red)
 // Decode one row with the whole workgroup.  l.msk holds the row's action mask.  Outputs are
 // workgroup-uniform.  logprobs_row / logits_row may be null.
 //
-// SDVRP (ENV == EAMRL_ENV_SDVRP): `rem` (LDS, [M]) is the row's remaining demand and `dyn` (LDS, [3][E]) the dynamic
-// embedding vectors; every K / V / Lp element enters its chain as  x + rem[n] * dyn[i][c]  (product rounded, sum
-// rounded: the reference's cached + dynamic embeddings, zoo/am/decoder.py:176-183).  Both are unused otherwise.
+// SDVRP (ENV == EAMRL_ENV_SDVRP): `rem` (LDS, [M]) is the row's remaining demand and `dyn` (LDS, [3][E] + scratch) the
+// dynamic-embedding vectors wk | wv | lw.  The reference adds rem[n] * vector to row n of the cached K / V / logit key
+// every step (zoo/am/decoder.py:176-183); that rank-1 update is folded:
+//   score[h][n] = fma(rem[n], q_h.wk_h, q_h.K[n]_h)      heads[e] = fma(lane_tree_n(w[n] * rem[n]), wv[e], sum_n w[n] V[n][e]) / Z
+//   logit partial[n][c] = fma(rem[n], heads_c.lw_c, heads_c.Lp[n]_c)
+// so K / V / Lp are read exactly as for CVRP.  Both pointers are unused otherwise.
 template <int ENV>
 __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const RowState& s, const float* noise_row,
                            int64_t given, int64_t& out_a, float& out_lp, float* logprobs_row, float* logits_row,
                            const float* rem = nullptr, const float* dyn = nullptr)
 {
     constexpr bool SD = ENV == EAMRL_ENV_SDVRP;
-#define EAMRL_DYN(x_, rn_, w_) (SD ? (x_) + (rn_) * (w_) : (x_))
+    float* sd_qw = const_cast<float*>(dyn) + 3 * a.E;          // [H]          q_h . wk_h
+    float* sd_pr = sd_qw + a.H;                                // [H]          lane-tree sum of w * rem
+    float* sd_hl = sd_pr + a.H;                                // [NCHUNK]     heads_c . lw_c
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int M = a.M, E = a.E, H = a.H, D = E / H;
     const int64_t bi = r % a.B;
@@ -77,6 +82,14 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
 
     // ---- D2 scores s[h][n] = chain_d(q, K) / sqrt(D) ------------------------------------------------
     const float qk_scale = 1.0f / __builtin_sqrtf((float)D);
+    if (SD) {       // q_h . wk_h, one thread per head
+        if (tid < H) {
+            float qw = 0.0f;
+            for (int d = 0; d < D; ++d) qw = fma_(l.q[tid * D + d], dyn[tid * D + d], qw);
+            sd_qw[tid] = qw;
+        }
+        __syncthreads();
+    }
     if (D == 16) {
     // DU2 (node, head) pairs per thread and trip: all 16 key loads of a trip are in flight before the first is used
     // (this kernel lives on HBM / L2 latency; a load-use loop would expose it once per pair)
@@ -102,15 +115,15 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             if (p >= M * H) break;
             const int n = p / H, h = p - n * H;
             const float* qp = l.q + h * D;
-            const float* wk = SD ? dyn + h * D : qp;
             float acc = 0.0f;
 #pragma unroll
             for (int d4 = 0; d4 < 4; ++d4) {
-                acc = fma_(qp[4 * d4], EAMRL_DYN(kk[u][d4].x, rn[u], wk[4 * d4]), acc);
-                acc = fma_(qp[4 * d4 + 1], EAMRL_DYN(kk[u][d4].y, rn[u], wk[4 * d4 + 1]), acc);
-                acc = fma_(qp[4 * d4 + 2], EAMRL_DYN(kk[u][d4].z, rn[u], wk[4 * d4 + 2]), acc);
-                acc = fma_(qp[4 * d4 + 3], EAMRL_DYN(kk[u][d4].w, rn[u], wk[4 * d4 + 3]), acc);
+                acc = fma_(qp[4 * d4], kk[u][d4].x, acc);
+                acc = fma_(qp[4 * d4 + 1], kk[u][d4].y, acc);
+                acc = fma_(qp[4 * d4 + 2], kk[u][d4].z, acc);
+                acc = fma_(qp[4 * d4 + 3], kk[u][d4].w, acc);
             }
+            if (SD) acc = fma_(rn[u], sd_qw[h], acc);
             l.w[h * M + n] = on[u] ? acc * qk_scale : -INFINITY;
         }
     }
@@ -122,16 +135,15 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         if (l.msk[n]) {
             const float* kp = K + (int64_t)n * ld + h * D;
             const float* qp = l.q + h * D;
-            const float* wk = SD ? dyn + h * D : qp;
-            const float rn = SD ? rem[n] : 0.0f;
             float acc = 0.0f;
             for (int d = 0; d < D; d += 4) {
                 float4 kk = *reinterpret_cast<const float4*>(kp + d);
-                acc = fma_(qp[d], EAMRL_DYN(kk.x, rn, wk[d]), acc);
-                acc = fma_(qp[d + 1], EAMRL_DYN(kk.y, rn, wk[d + 1]), acc);
-                acc = fma_(qp[d + 2], EAMRL_DYN(kk.z, rn, wk[d + 2]), acc);
-                acc = fma_(qp[d + 3], EAMRL_DYN(kk.w, rn, wk[d + 3]), acc);
+                acc = fma_(qp[d], kk.x, acc);
+                acc = fma_(qp[d + 1], kk.y, acc);
+                acc = fma_(qp[d + 2], kk.z, acc);
+                acc = fma_(qp[d + 3], kk.w, acc);
             }
+            if (SD) acc = fma_(rem[n], sd_qw[h], acc);
             sc = acc * qk_scale;
         }
         l.w[h * M + n] = sc;
@@ -145,7 +157,17 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         float m = -INFINITY;
         for (int n = lane; n < M; n += 64) m = __builtin_fmaxf(m, wh[n]);
         m = wave_max(m);
-        for (int n = lane; n < M; n += 64) wh[n] = l.msk[n] ? d_expf(wh[n] - m) : 0.0f;
+        float rs = 0.0f;
+        for (int nb = 0; nb < M; nb += 64) {
+            const int n = nb + lane;
+            const float wn = (n < M && l.msk[n]) ? d_expf(wh[n] - m) : 0.0f;
+            if (n < M) wh[n] = wn;
+            if (SD) {       // R_h: 64-blocks of w * rem through the lane tree, blocks added left to right
+                const float tr = wave_tree_sum(n < M ? wn * rem[n] : 0.0f);
+                rs = nb == 0 ? tr : rs + tr;
+            }
+        }
+        if (SD && lane == 0) sd_pr[h] = rs;
     }
     __syncthreads();
 
@@ -156,7 +178,6 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         const float* wh = l.w + h * M;
         const int n0 = g * C, n1 = min(M, n0 + C);
         float zg = 0.0f, ag = 0.0f;
-        const float wve = SD ? dyn[E + e] : 0.0f;
         // DU4 value loads in flight per thread; a masked node has w == +0 exactly, so adding its terms unconditionally
         // (with v = 0 in place of the skipped load) leaves both sums bit-identical
         for (int nb = n0; nb < n1; nb += DU4) {
@@ -165,7 +186,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             for (int u = 0; u < DU4; ++u) {
                 const int n = nb + u;
                 const bool onv = n < n1 && l.msk[n] != 0;
-                vv[u] = onv ? EAMRL_DYN(V[(int64_t)n * ld + e], rem[n], wve) : 0.0f;
+                vv[u] = onv ? V[(int64_t)n * ld + e] : 0.0f;
                 ww[u] = onv ? wh[n] : 0.0f;
             }
 #pragma unroll
@@ -183,9 +204,19 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         float A = l.partA[e], Z = l.partZ[h];
 #pragma unroll
         for (int g = 1; g < EAMRL_NCHUNK; ++g) { A = A + l.partA[g * E + e]; Z = Z + l.partZ[g * H + h]; }
+        if (SD) A = fma_(sd_pr[h], dyn[E + e], A);
         l.heads[e] = A / Z;
     }
     __syncthreads();
+    const int EC0 = E / EAMRL_NCHUNK;
+    if (SD) {       // heads_c . lw_c, one thread per column chunk
+        if (tid < EAMRL_NCHUNK) {
+            float hl = 0.0f;
+            for (int e = tid * EC0; e < (tid + 1) * EC0; ++e) hl = fma_(l.heads[e], dyn[2 * E + e], hl);
+            sd_hl[tid] = hl;
+        }
+        __syncthreads();
+    }
 
     // ---- D5 logit partials over NCHUNK column chunks ---------------------------------------------------------
     const int EC = E / EAMRL_NCHUNK;
@@ -213,15 +244,15 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
                 if (p >= M * EAMRL_NCHUNK) break;
                 const int c = p % EAMRL_NCHUNK;
                 const float* hp = l.heads + c * EC;
-                const float* wl = SD ? dyn + 2 * E + c * EC : hp;
                 float cg = 0.0f;
 #pragma unroll
                 for (int e4 = 0; e4 < 8; ++e4) {
-                    cg = fma_(hp[4 * e4], EAMRL_DYN(lv[u][e4].x, rn[u], wl[4 * e4]), cg);
-                    cg = fma_(hp[4 * e4 + 1], EAMRL_DYN(lv[u][e4].y, rn[u], wl[4 * e4 + 1]), cg);
-                    cg = fma_(hp[4 * e4 + 2], EAMRL_DYN(lv[u][e4].z, rn[u], wl[4 * e4 + 2]), cg);
-                    cg = fma_(hp[4 * e4 + 3], EAMRL_DYN(lv[u][e4].w, rn[u], wl[4 * e4 + 3]), cg);
+                    cg = fma_(hp[4 * e4], lv[u][e4].x, cg);
+                    cg = fma_(hp[4 * e4 + 1], lv[u][e4].y, cg);
+                    cg = fma_(hp[4 * e4 + 2], lv[u][e4].z, cg);
+                    cg = fma_(hp[4 * e4 + 3], lv[u][e4].w, cg);
                 }
+                if (SD) cg = fma_(rn[u], sd_hl[c], cg);
                 l.partL[p] = cg;       // masked node: all-zero operands -> chain of exact zeros, as before
             }
         }
@@ -232,15 +263,14 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             if (l.msk[n]) {
                 const float* lp = Lp + (int64_t)n * ld + c * EC;
                 const float* hp = l.heads + c * EC;
-                const float* wl = SD ? dyn + 2 * E + c * EC : hp;
-                const float rn = SD ? rem[n] : 0.0f;
                 for (int e = 0; e < EC; e += 4) {
                     float4 v = *reinterpret_cast<const float4*>(lp + e);
-                    cg = fma_(hp[e], EAMRL_DYN(v.x, rn, wl[e]), cg);
-                    cg = fma_(hp[e + 1], EAMRL_DYN(v.y, rn, wl[e + 1]), cg);
-                    cg = fma_(hp[e + 2], EAMRL_DYN(v.z, rn, wl[e + 2]), cg);
-                    cg = fma_(hp[e + 3], EAMRL_DYN(v.w, rn, wl[e + 3]), cg);
+                    cg = fma_(hp[e], v.x, cg);
+                    cg = fma_(hp[e + 1], v.y, cg);
+                    cg = fma_(hp[e + 2], v.z, cg);
+                    cg = fma_(hp[e + 3], v.w, cg);
                 }
+                if (SD) cg = fma_(rem[n], sd_hl[c], cg);
             }
             l.partL[p] = cg;
         }
@@ -373,7 +403,6 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
     }
     out_a = sel;
     out_lp = l.x[sel];
-#undef EAMRL_DYN
 }
 
 // Apply the env transition to the LDS copy of the row (msk, vis for CVRP, rem for SDVRP) and the uniform state.
@@ -579,7 +608,8 @@ static int launch_decode(int env, const DecArgs& a, bool rollout, hipStream_t st
 {
     const size_t Mp = ((size_t)a.M + 15) & ~(size_t)15;
     size_t lds = row_lds_bytes(a.M, a.E, a.H) + Mp;                       // + visited bytes
-    if (env == EAMRL_ENV_SDVRP) lds += 4 * Mp + 12 * (size_t)a.E;          // + remaining demand + dynamic vectors
+    if (env == EAMRL_ENV_SDVRP)                                            // + remaining demand + dynamic vectors + folds
+        lds += 4 * Mp + 12 * (size_t)a.E + 4 * (2 * (size_t)a.H + EAMRL_NCHUNK);
     if (lds > 160 * 1024) return EAMRL_E_ARG;
     dim3 grid((unsigned)a.R), block(BLOCK);
     void (*k)(DecArgs);

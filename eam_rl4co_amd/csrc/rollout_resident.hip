@@ -20,7 +20,7 @@
 //
 // Reference loop replaced: rl4co/models/common/constructive/base.py:236-250 with
 // rl4co/models/zoo/am/decoder.py:161-198, rl4co/models/nn/attention.py:282-328,
-// rl4co/utils/decoding.py:140-190,346-465 and rl4co/envs/routing/{tsp,cvrp}/env.py step functions.
+// rl4co/utils/decoding.py:140-190,346-465 and rl4co/envs/routing/{tsp,cvrp,sdvrp}/env.py step functions.
 #include "kernels.hpp"
 
 namespace eamrl {
@@ -41,7 +41,8 @@ __device__ unsigned long long g_stamps[8];
 #define STAMP(i) do { } while (0)
 #endif
 
-template <int CP>
+// TM: episode length bound (2M+1 steps for TSP / CVRP, 3M+1 for SDVRP); SDF: floats of the SDVRP-only arrays
+template <int CP, int TM, int SDF>
 struct ResLds {
     static constexpr int WROW = 4 * CP + 4;     // floats per head row of w (chunk-padded, +4 spreads banks)
     float q[RE];
@@ -50,9 +51,11 @@ struct ResLds {
     float partA[EAMRL_NCHUNK * RE];
     float partZ[EAMRL_NCHUNK * RH];
     float cpart[RNP * 4];
-    float dem[RNP];
-    float lp_out[2 * RNP + 2];                  // selected log-probs of the episode (t_max <= 2M+1), written out once
-    int16_t act_out[2 * RNP + 2];               // selected actions of the episode
+    float dem[RNP];                             // CVRP: demand; SDVRP: remaining demand (demand_with_depot)
+    float lp_out[TM];                           // selected log-probs of the episode, written out once
+    int16_t act_out[TM];                        // selected actions of the episode
+    float dynv[3 * SDF];                        // SDVRP: dynamic-embedding vectors wk | wv | lw
+    float partR[RH];                            // SDVRP: R_h = lane-tree sum of w * rem
     int done;
     uint8_t msk[RNP];
     uint8_t vis[RNP];
@@ -62,11 +65,19 @@ struct ResLds {
 // CP: chunk stride of a w row in LDS (multiple of 4, >= chunk length C); CR: V registers per chunk (C <= CR <= CP)
 // MS (multistart batches, R = S*B rows in "(s b)" order): workgroup (b, g) = blockIdx b + g*B keeps instance b's
 // operands in registers and rolls out its starts g, g+G, g+2G, ... one after the other.
+//
+// SDVRP: the dynamic embedding (rem[n] * vector added to row n of K / V / logit key every step) is a rank-1 update and
+// is folded (decode_step.hip): one fma per score / glimpse column / logit partial on top of the chains
+// over the register-resident, never modified K / V / Lp.
+constexpr int res_tmax(int env) { return (env == EAMRL_ENV_SDVRP ? 3 : 2) * RNP + 2; }
+constexpr int res_sdf(int env) { return env == EAMRL_ENV_SDVRP ? RE : 4; }
+
 template <int ENV, int CP, int CR, bool MS>
 __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, int G)
 {
+    constexpr bool SD = ENV == EAMRL_ENV_SDVRP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using L = ResLds<CP>;
+    using L = ResLds<CP, res_tmax(ENV), res_sdf(ENV)>;
     L& l = *reinterpret_cast<L*>(smem);
     float* Plds = reinterpret_cast<float*>(smem + ((sizeof(L) + 15) & ~size_t(15)));
     constexpr int WROW = L::WROW;
@@ -128,6 +139,8 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             }
         }
         for (int i = tid; i < RH * WROW; i += RB) l.w[i] = 0.0f;   // chunk padding stays 0 for the whole episode
+        if (SD)
+            for (int i = tid; i < 3 * RE; i += RB) l.dynv[i] = a.dyn[i];
     }
     // slots of the two nodes in a w row; absent nodes (n >= M) point at the row's never-read spare slot 4*CP
     const int pos0 = in0 ? (n0 / C) * CP + (n0 - (n0 / C) * C) : 4 * CP;
@@ -142,6 +155,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         l.msk[tid] = (tid < M) ? a.mask[r * M + tid] : 0;
         l.vis[tid] = (ENV == EAMRL_ENV_CVRP && tid < M) ? a.visited[r * M + tid] : 0;
         if (ENV == EAMRL_ENV_CVRP) l.dem[tid] = (tid < M - 1) ? a.demand[bi * (M - 1) + tid] : 0.0f;
+        if (SD) l.dem[tid] = (tid < M) ? a.rem[r * M + tid] : 0.0f;
     }
     if (tid == 0) l.done = a.done[r] != 0;
     __syncthreads();
@@ -203,12 +217,17 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         // ---- S1: scores, per-head max and softmax weights of heads 2w, 2w+1 for both nodes (all inside the wave) ----
         // Branch-free and written so that the two heads' chains, butterflies and exponentials interleave.
         {
-            float s0[2] = {0.0f, 0.0f}, s1[2] = {0.0f, 0.0f};
+            float s0[2] = {0.0f, 0.0f}, s1[2] = {0.0f, 0.0f}, qw[2] = {0.0f, 0.0f};
 #pragma unroll
             for (int d = 0; d < RD; d += 4) {
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const float4 qq = *reinterpret_cast<const float4*>(l.q + (2 * wv + hh) * RD + d);
+                    if (SD) {       // q_h . wk_h (wavefront-uniform, every lane keeps its own copy)
+                        const float4 dk = *reinterpret_cast<const float4*>(l.dynv + (2 * wv + hh) * RD + d);
+                        qw[hh] = fma_(qq.x, dk.x, qw[hh]); qw[hh] = fma_(qq.y, dk.y, qw[hh]);
+                        qw[hh] = fma_(qq.z, dk.z, qw[hh]); qw[hh] = fma_(qq.w, dk.w, qw[hh]);
+                    }
                     s0[hh] = fma_(qq.x, kreg[0][hh * RD + d], s0[hh]);     s1[hh] = fma_(qq.x, kreg[1][hh * RD + d], s1[hh]);
                     s0[hh] = fma_(qq.y, kreg[0][hh * RD + d + 1], s0[hh]); s1[hh] = fma_(qq.y, kreg[1][hh * RD + d + 1], s1[hh]);
                     s0[hh] = fma_(qq.z, kreg[0][hh * RD + d + 2], s0[hh]); s1[hh] = fma_(qq.z, kreg[1][hh * RD + d + 2], s1[hh]);
@@ -219,6 +238,10 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             float m[2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
+                if (SD) {       // remaining demand of the lane's nodes (slots >= M hold 0); re-read where needed: no live range
+                    s0[hh] = fma_(l.dem[n0], qw[hh], s0[hh]);
+                    s1[hh] = fma_(l.dem[n1], qw[hh], s1[hh]);
+                }
                 sc[hh].x = f0 ? s0[hh] * 0.25f : -INFINITY;              // 1/sqrt(16)
                 sc[hh].y = f1 ? s1[hh] * 0.25f : -INFINITY;
                 m[hh] = vmax_raw(sc[hh].x, sc[hh].y);
@@ -229,8 +252,13 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             for (int hh = 0; hh < 2; ++hh) {
                 const f32x2 e2 = d_expf2_nonpos(sc[hh] - splat2(m[hh]));        // masked / absent nodes: value discarded below
                 float* wrow = l.w + (2 * wv + hh) * WROW;
-                wrow[pos0] = f0 ? e2.x : 0.0f;                           // absent nodes write 0 into the row's spare slot
-                wrow[pos1] = f1 ? e2.y : 0.0f;
+                const float w0 = f0 ? e2.x : 0.0f, w1 = f1 ? e2.y : 0.0f;
+                wrow[pos0] = w0;                                         // absent nodes write 0 into the row's spare slot
+                wrow[pos1] = w1;
+                if (SD) {       // R_h = lane tree of w * rem over the two 64-blocks (the second is all zeros when M <= 64)
+                    const float R = wave_tree_sum(w0 * l.dem[n0]) + wave_tree_sum(w1 * l.dem[n1]);
+                    if (lane == 0) l.partR[2 * wv + hh] = R;
+                }
             }
         }
         __syncthreads();
@@ -266,18 +294,25 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                 float A = l.partA[e], Z = l.partZ[h];
 #pragma unroll
                 for (int g = 1; g < EAMRL_NCHUNK; ++g) { A = A + l.partA[g * RE + e]; Z = Z + l.partZ[g * RH + h]; }
+                if (SD) A = fma_(l.partR[h], l.dynv[RE + e], A);
                 hw[lane] = A / Z;
             }
             __builtin_amdgcn_wave_barrier();        // same wavefront: LDS executes its accesses in order
-            float c0 = 0.0f, c1 = 0.0f;
+            float c0 = 0.0f, c1 = 0.0f, hl = 0.0f;
 #pragma unroll
             for (int e = 0; e < 32; e += 4) {
                 const float4 h4 = *reinterpret_cast<const float4*>(hw + e);
+                if (SD) {       // heads_c . lw_c of this wavefront's column chunk
+                    const float4 dl = *reinterpret_cast<const float4*>(l.dynv + 2 * RE + 32 * wv + e);
+                    hl = fma_(h4.x, dl.x, hl); hl = fma_(h4.y, dl.y, hl);
+                    hl = fma_(h4.z, dl.z, hl); hl = fma_(h4.w, dl.w, hl);
+                }
                 c0 = fma_(h4.x, lreg[0][e], c0);     c1 = fma_(h4.x, lreg[1][e], c1);
                 c0 = fma_(h4.y, lreg[0][e + 1], c0); c1 = fma_(h4.y, lreg[1][e + 1], c1);
                 c0 = fma_(h4.z, lreg[0][e + 2], c0); c1 = fma_(h4.z, lreg[1][e + 2], c1);
                 c0 = fma_(h4.w, lreg[0][e + 3], c0); c1 = fma_(h4.w, lreg[1][e + 3], c1);
             }
+            if (SD) { c0 = fma_(l.dem[n0], hl, c0); c1 = fma_(l.dem[n1], hl, c1); }
             l.cpart[n0 * 4 + wv] = c0;
             l.cpart[n1 * 4 + wv] = c1;
         }
@@ -363,6 +398,37 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                 if (lane == 0) { l.msk[sel] = 0; l.done = done; }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) l.q[lane + 64 * k] = (p1f[k] + Plds[cur * RE + lane + 64 * k]) + gq[k];
+            } else if (SD) {
+                // SDVRPEnv._step + get_action_mask (sdvrp/env.py:58-92,137-146): deliver min(remaining demand, free capacity)
+                const float selrem = l.dem[sel];
+                const float free_cap = vcap - used;
+                const float delivered = selrem < free_cap ? selrem : free_cap;
+                used = (used + delivered) * (sel != 0 ? 1.0f : 0.0f);
+                cur = sel;
+                const float left = selrem + (-delivered);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) l.dem[sel] = left;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 2; ++k) l.q[lane + 64 * k] = fma_(cv[k], vcap - used, Plds[cur * RE + lane + 64 * k]) + gq[k];
+                const bool full = used >= vcap;
+                int free_n = 0, rem_n = 0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int nn = lane + 64 * k;
+                    if (nn < M) {
+                        const float rv = l.dem[nn];
+                        rem_n |= rv > 0.0f;
+                        if (nn >= 1) {
+                            const int blocked = (rv == 0.0f) | full;
+                            l.msk[nn] = !blocked;
+                            free_n |= !blocked;
+                        }
+                    }
+                }
+                const bool any_free = __ballot(free_n) != 0ull;
+                done = __ballot(rem_n) == 0ull;
+                if (lane == 0) { l.msk[0] = !((cur == 0) && any_free); l.done = done; }
             } else {
                 const int N = M - 1;
                 int di = sel - 1;
@@ -413,6 +479,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
     if (tid < M) {
         a.mask[r * M + tid] = l.msk[tid];
         if (ENV == EAMRL_ENV_CVRP) a.visited[r * M + tid] = l.vis[tid];
+        if (SD) a.rem[r * M + tid] = l.dem[tid];
     }
     if (wv == fw && lane == 0) {
         a.cur[r] = cur;
@@ -442,7 +509,7 @@ __global__ void k_rollout_pad_cvrp_res(DecArgs a)
 template <int ENV, int CP, int CR, bool MS>
 int launch_ms(const DecArgs& a, int S, int G, hipStream_t st)
 {
-    const size_t lds = ((sizeof(ResLds<CP>) + 15) & ~size_t(15)) + (size_t)a.M * RE * sizeof(float);
+    const size_t lds = ((sizeof(ResLds<CP, res_tmax(ENV), res_sdf(ENV)>) + 15) & ~size_t(15)) + (size_t)a.M * RE * sizeof(float);
     auto k = k_rollout_resident<ENV, CP, CR, MS>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -466,7 +533,7 @@ int launch_cp(const DecArgs& a, hipStream_t st)
         rc = launch_ms<ENV, CP, CR, false>(a, 1, 1, st);
     }
     if (rc) return rc;
-    if (ENV == EAMRL_ENV_CVRP)
+    if (ENV != EAMRL_ENV_TSP)
         hipLaunchKernelGGL(k_rollout_pad_cvrp_res, dim3((unsigned)((a.R + 255) / 256)), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
@@ -475,7 +542,7 @@ template <int ENV>
 int launch_env(const DecArgs& a, hipStream_t st)
 {
     const int C = (a.M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
-    if (a.t_max > 2 * RNP + 2) return EAMRL_E_ARG;
+    if (a.t_max > res_tmax(ENV)) return EAMRL_E_ARG;
     if (C <= 8) return launch_cp<ENV, 8, 8>(a, st);
     if (C <= 16) return launch_cp<ENV, 16, 16>(a, st);
     if (C <= 25) return launch_cp<ENV, 28, 25>(a, st);      // M <= 100
@@ -500,12 +567,13 @@ extern "C" __attribute__((visibility("default"))) int eamrl_debug_read_stamps(un
 
 bool rollout_resident_supports(int env, const DecArgs& a)
 {
-    return a.E == RE && a.H == RH && a.M <= RNP && a.M >= 2 && a.ld % 4 == 0 && a.t_max <= 2 * RNP + 2;
+    return a.E == RE && a.H == RH && a.M <= RNP && a.M >= 2 && a.ld % 4 == 0 && a.t_max <= res_tmax(env);
 }
 
 int launch_rollout_resident(int env, const DecArgs& a, hipStream_t st)
 {
-    return env == EAMRL_ENV_TSP ? launch_env<EAMRL_ENV_TSP>(a, st) : launch_env<EAMRL_ENV_CVRP>(a, st);
+    return env == EAMRL_ENV_TSP ? launch_env<EAMRL_ENV_TSP>(a, st)
+         : env == EAMRL_ENV_CVRP ? launch_env<EAMRL_ENV_CVRP>(a, st) : launch_env<EAMRL_ENV_SDVRP>(a, st);
 }
 
 }  // namespace eamrl

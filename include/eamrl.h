@@ -137,10 +137,10 @@ typedef struct eamrl_cache {
     int64_t ld;        /* row stride of K/V/Lp/Pa/Pb in floats (>= E) */
     int64_t B;         /* instances */
     int32_t M, E, H;   /* nodes (incl. depot), embed dim, heads */
-    const float* dyn;  /* SDVRP only, else NULL: [3][E] dynamic-embedding vectors (SDVRPDynamicEmbedding,
-                        * nn/env_embeddings/dynamic.py:59-78): row n of K / V / Lp enters the step as
-                        * X[n][c] + rem[n] * dyn[i][c]  (i = 0 K, 1 V, 2 Lp; the Lp vector is the logit-key
-                        * column of the projection times pointer.project_out) */
+    const float* dyn;  /* SDVRP only, else NULL: [3][E] dynamic-embedding vectors wk | wv | lw (SDVRPDynamicEmbedding,
+                        * nn/env_embeddings/dynamic.py:59-78; lw = the logit-key column of the projection times
+                        * pointer.project_out).  The reference adds rem[n] * vector to row n of the cached key /
+                        * value / logit key each step; the kernels fold that rank-1 update. */
 } eamrl_cache;
 
 /* Per-row rollout state (the TensorDict keys the reference's env keeps, tsp/env.py:105-115,
@@ -177,7 +177,7 @@ int eamrl_am_decode_step(int env, const eamrl_cache* cache_host, const eamrl_sta
  * repeats {decode step, env step} until every row is done or t_max steps were taken.  actions/logps are
  * [R][t_max] (right-padded: finished CVRP rows keep selecting the depot, logp 0).  noise [R][t_max][M],
  * given [R][t_given].  steps_out (device int32): number of steps executed = max over rows.  With top_k / top_p
- * filtering, and for EAMRL_ENV_SDVRP, the streaming kernel is used (the register-resident one does neither). */
+ * filtering the streaming kernel is used (the register-resident one does not filter). */
 int eamrl_am_rollout(int env, const eamrl_cache* cache_host, const eamrl_state* state_host, int64_t R, int mode,
                      const float* noise, const int64_t* given, int t_given, float tanh_clip, float temperature,
                      int top_k, float top_p, int t_max, int64_t* actions, float* logps, int32_t* steps_out,

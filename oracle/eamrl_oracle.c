@@ -407,8 +407,9 @@ typedef struct {
     const float *cvec;            /* TSP: c0[E] (placeholder query); CVRP: wcap[E] */
     const float *gctx;            /* [Binst][E] or NULL */
     float clip, temp;
-    const float* dyn;   /* SDVRP dynamic embedding [3][E]: glimpse-key, glimpse-value and folded logit-key vectors that are
-                         * scaled by a node's remaining demand and added to its K / V / Lp rows   nn/env_embeddings/dynamic.py:60-78 */
+    const float* dyn;   /* SDVRP dynamic embedding [3][E]: glimpse-key, glimpse-value and folded logit-key vectors that the
+                         * reference scales by a node's remaining demand and adds to its K / V / Lp rows (folded here,
+                         * see decode_row)                                              nn/env_embeddings/dynamic.py:59-78 */
     int top_k;          /* process_logits top-k filtering (0 = off)                      utils/decoding.py:110-115 */
     float top_p;        /* process_logits nucleus filtering (0 or >= 1 = off)            utils/decoding.py:118-136 */
 } orc_dec_t;
@@ -440,41 +441,52 @@ static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, in
         }
         q[e] = ctx + g;
     }
-    /* SDVRP: row n of K / V / Lp gets rem[n] * (its dynamic vector) added, element by element (product rounded, then
-     * the sum rounded), before it enters the chains below -- the reference's cached + dynamic embeddings */
+    /* SDVRP: the reference adds rem[n] * (a dynamic vector) to row n of the cached glimpse key / value / logit key
+     * before every step.  That is a rank-1 update, so it is folded like the other weight products:
+     *   score[h][n]  = chain_d(q, K[n]) + rem[n] * chain_d(q, wk)             (one fma on top of the K chain)
+     *   glimpse[e]   = (sum_n w[n] V[n][e]  +  R_h * wv[e]) / Z,   R_h = lane_tree_n(w[n] * rem[n])
+     *   partial[n][g]= chain_e(heads, Lp[n]) + rem[n] * chain_e(heads, lw)     (per column chunk g)
+     * identical to the reference in exact arithmetic; this order is the definition all implementations share. */
     const float* dk = (c->env == ORC_ENV_SDVRP) ? c->dyn : NULL;
     const float* dv = dk ? c->dyn + E : NULL;
     const float* dl = dk ? c->dyn + 2 * E : NULL;
-#define DYN(base_, vec_, n_, col_) ((vec_) ? (base_) + rem[n_] * (vec_)[col_] : (base_))
     /* D2-D4 glimpse */
     const int C = (M + ORC_NCHUNK - 1) / ORC_NCHUNK;
     const float qk_scale = 1.0f / sqrtf((float)D);
     for (int h = 0; h < H; ++h) {
         float* wh = w + (long)h * M;
         float mx = -INFINITY;
+        float qw = 0.0f;
+        if (dk) for (int d = 0; d < D; ++d) qw = fmaf(q[h * D + d], dk[h * D + d], qw);
         for (int n = 0; n < M; ++n) {
             if (!mask[n]) { wh[n] = -INFINITY; continue; }
             float acc = 0.0f;
-            for (int d = 0; d < D; ++d) acc = fmaf(q[h * D + d], DYN(K[(long)n * E + h * D + d], dk, n, h * D + d), acc);
+            for (int d = 0; d < D; ++d) acc = fmaf(q[h * D + d], K[(long)n * E + h * D + d], acc);
+            if (dk) acc = fmaf(rem[n], qw, acc);
             acc = acc * qk_scale;                 /* 1/sqrt(D); D=16 -> exactly 0.25 */
             wh[n] = acc;
             if (acc > mx) mx = acc;
         }
         for (int n = 0; n < M; ++n) wh[n] = mask[n] ? d_expf(wh[n] - mx) : 0.0f;
-        float Z = 0.0f;
+        float Z = 0.0f, Rw = 0.0f;
         for (int g = 0; g < ORC_NCHUNK; ++g) {
             float zg = 0.0f;
             for (int n = g * C; n < M && n < (g + 1) * C; ++n) zg = zg + wh[n];
             Z = (g == 0) ? zg : Z + zg;
+        }
+        if (dv) {                           /* ex[] is free until the log-softmax below */
+            for (int n = 0; n < M; ++n) ex[n] = wh[n] * rem[n];
+            Rw = lane_tree(ex, M);
         }
         for (int d = 0; d < D; ++d) {
             float A = 0.0f;
             for (int g = 0; g < ORC_NCHUNK; ++g) {
                 float ag = 0.0f;
                 for (int n = g * C; n < M && n < (g + 1) * C; ++n)
-                    ag = fmaf(wh[n], DYN(V[(long)n * E + h * D + d], dv, n, h * D + d), ag);
+                    ag = fmaf(wh[n], V[(long)n * E + h * D + d], ag);
                 A = (g == 0) ? ag : A + ag;
             }
+            if (dv) A = fmaf(Rw, dv[h * D + d], A);
             heads[h * D + d] = A / Z;
         }
     }
@@ -483,11 +495,17 @@ static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, in
     const float sqrtE = sqrtf((float)E);
     float mx = -INFINITY;
     int nan_seen = 0;
+    float hl[ORC_NCHUNK];
+    for (int g = 0; g < ORC_NCHUNK; ++g) {
+        hl[g] = 0.0f;
+        if (dl) for (int e = g * EC; e < (g + 1) * EC; ++e) hl[g] = fmaf(heads[e], dl[e], hl[g]);
+    }
     for (int n = 0; n < M; ++n) {
         float u = 0.0f;
         for (int g = 0; g < ORC_NCHUNK; ++g) {
             float cg = 0.0f;
-            for (int e = g * EC; e < (g + 1) * EC; ++e) cg = fmaf(heads[e], DYN(Lp[(long)n * E + e], dl, n, e), cg);
+            for (int e = g * EC; e < (g + 1) * EC; ++e) cg = fmaf(heads[e], Lp[(long)n * E + e], cg);
+            if (dl) cg = fmaf(rem[n], hl[g], cg);
             u = (g == 0) ? cg : u + cg;
         }
         float logit = u / sqrtE;

@@ -41,8 +41,11 @@ def lib():
     if _LIB is None:
         name = "liboracle.so" if _cpu_has_fma() else "liboracle_generic.so"
         path = os.path.join(_HERE, "build", name)
-        if not os.path.exists(path):
-            build()
+        try:
+            build()                     # make: a no-op when the library is newer than the C source
+        except (OSError, subprocess.CalledProcessError):
+            if not os.path.exists(path):
+                raise
         _LIB = C.CDLL(path)
         _LIB.orc_lane_tree.restype = C.c_float
         _LIB.orc_check_tsp.restype = C.c_long
