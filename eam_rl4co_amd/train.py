@@ -99,6 +99,32 @@ def _cvrp_states(actions, demand_rows, vcap, M):
     return torch.stack(curs, 1), torch.stack(rems, 1), torch.stack(masks, 1)
 
 
+def _sdvrp_states(actions, demand_rows, vcap, M):
+    """-> cur [R,T], free capacity [R,T], mask [R,T,M] and remaining demand [R,T,M] before each step
+    (sdvrp/env.py:58-92,137-146)."""
+    R, T = actions.shape
+    dev = actions.device
+    rem = torch.cat((torch.zeros(R, 1, dtype=torch.float32, device=dev), demand_rows), 1)
+    used = torch.zeros(R, dtype=torch.float32, device=dev)
+    cur = torch.zeros(R, dtype=torch.int64, device=dev)
+    curs, frees, masks, rems = [], [], [], []
+    ar = torch.arange(R, device=dev)
+    for t in range(T):
+        blocked = (rem[:, 1:] == 0) | (used >= vcap)[:, None]
+        depot_blocked = (cur == 0) & (~blocked).any(-1)
+        masks.append(~torch.cat((depot_blocked[:, None], blocked), 1))
+        curs.append(cur)
+        frees.append(vcap - used)
+        rems.append(rem)
+        a = actions[:, t]
+        delivered = torch.minimum(rem[ar, a], vcap - used)
+        used = (used + delivered) * (a != 0).float()
+        rem = rem.clone()
+        rem[ar, a] = rem[ar, a] - delivered
+        cur = a
+    return torch.stack(curs, 1), torch.stack(frees, 1), torch.stack(masks, 1), torch.stack(rems, 1)
+
+
 # ------------------------------------------------------------------------------------------------------------
 def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, temperature=None, tanh_clipping=None,
                             chunk_rows: int = 4096):
@@ -136,18 +162,34 @@ def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, tempe
             ctx_in = torch.cat((embr[ar, first], embr[ar, cur]), -1)                       # [Rc, T, 2E]
             if not multistart:   # step 0 uses the learned placeholder (context.py:118-131)
                 ctx_in = torch.cat((dec.context_embedding.W_placeholder.expand(Rc, 1, 2 * E), ctx_in[:, 1:]), 1)
-        else:
+        elif policy.env_name == "cvrp":
             cur, rem, mask = _cvrp_states(act, rep(td["demand"]), rep(td["vehicle_capacity"].reshape(-1)), M)
             ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)                          # [Rc, T, E+1]
+        else:
+            cur, rem, mask, dem_t = _sdvrp_states(act, rep(td["demand"]), rep(td["vehicle_capacity"].reshape(-1)), M)
+            ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)
         q = F.linear(ctx_in, Wctx)
         if gctx is not None:
             q = q + rep(gctx)[:, None, :]
         qh = q.view(Rc, T, H, D).permute(0, 2, 1, 3)
         kh = Kr.view(Rc, M, H, D).permute(0, 2, 1, 3)
         vh = Vr.view(Rc, M, H, D).permute(0, 2, 1, 3)
-        heads = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=mask[:, None])         # [Rc, H, T, D]
+        if policy.env_name == "sdvrp":
+            # dynamic embedding (dynamic.py:59-78): K/V/L rows + remaining demand * projection columns.  The update is
+            # rank one, so it enters as a score bias and two outer products instead of [Rc, T, M, E] tensors
+            wk, wv, wl = dec.dynamic_embedding.projection.weight.view(3, E)
+            qw = (qh * wk.view(1, H, 1, D)).sum(-1)                                              # [Rc, H, T]
+            bias = (dem_t[:, None] * qw[..., None]) / math.sqrt(D)                               # [Rc, H, T, M]
+            bias = bias.masked_fill(~mask[:, None], float("-inf"))
+            att = torch.softmax(torch.matmul(qh, kh.transpose(-1, -2)) / math.sqrt(D) + bias, dim=-1)
+            heads = torch.matmul(att, vh) + (att * dem_t[:, None]).sum(-1, keepdim=True) * wv.view(1, H, 1, D)
+        else:
+            heads = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=mask[:, None])     # [Rc, H, T, D]
         glimpse = F.linear(heads.permute(0, 2, 1, 3).reshape(Rc, T, E), dec.pointer.project_out.weight)
-        logits = torch.bmm(glimpse, Lr.transpose(1, 2)) / math.sqrt(E)
+        logits = torch.bmm(glimpse, Lr.transpose(1, 2))
+        if policy.env_name == "sdvrp":
+            logits = logits + dem_t * (glimpse @ wl)[..., None]
+        logits = logits / math.sqrt(E)
         if clip > 0:
             logits = torch.tanh(logits) * clip
         logits = logits.masked_fill(~mask, float("-inf")) / temperature

@@ -177,7 +177,8 @@ def test_reference_lightning_checkpoint_loads(tmp_path):
 # N3: gradients by teacher-forced re-evaluation
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,cfg", [("tsp20_sampling", "am_tsp"), ("cvrp20_sampling", "am_cvrp"),
-                                      ("pomo_tsp20_multistart_sampling", "pomo_tsp")])
+                                      ("pomo_tsp20_multistart_sampling", "pomo_tsp"), ("sdvrp20_sampling", "am_sdvrp"),
+                                      ("sdvrp20_multistart_greedy", "am_sdvrp")])
 def test_reevaluation_matches_native_logp_and_reference(name, cfg):
     """evaluate_log_likelihood (autograd, all steps at once) == native per-step log-probs (atol 1e-4) == reference."""
     from eam_rl4co_amd.train import evaluate_log_likelihood
@@ -222,7 +223,7 @@ def test_reinforce_step_pomo_and_flat_allreduce():
 # ---------------------------------------------------------------------------------------------------------
 # HIP graph replay of the whole rollout
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("env_name,mode", [("tsp", "greedy"), ("cvrp", "greedy"), ("cvrp", "sampling")])
+@pytest.mark.parametrize("env_name,mode", [("tsp", "greedy"), ("cvrp", "greedy"), ("cvrp", "sampling"), ("sdvrp", "greedy")])
 def test_graphed_rollout_equals_eager(env_name, mode):
     import eam_rl4co_amd as ea
 
