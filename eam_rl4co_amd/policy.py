@@ -274,7 +274,7 @@ class AttentionModelDecoder(nn.Module):
 
     def forward(self, td, cached: ops.DecodeCache, num_starts: int = 0):
         """(logits, mask) for the current state, as the reference decoder returns them (decoder.py:161-198)."""
-        st = state_from_td(self.env_name, td)
+        st = state_from_td(self.env_name, td, copy=False)      # read-only: the step is not fused
         _, _, _, logits, status = ops.decode_step(st, cached, "greedy", clip=0.0, temp=1.0, want_logits=True)
         if self.pointer.check_nan:
             ops.raise_on_status(int(status.item()) & ops.ST_NAN_LOGITS)
@@ -300,9 +300,11 @@ def _max_decode_steps(env_name, M, npre=0):
 # ------------------------------------------------------------------------------------------------------------
 # TensorDict <-> flat rollout state
 # ------------------------------------------------------------------------------------------------------------
-def state_from_td(env_name, td, num_starts: int = 0) -> ops.RolloutState:
-    """Flat state tensors for R = max(S,1)*B rows.  With S <= 1 the td's own tensors are used (updated in place);
-    with multistart they are replicated in the reference's (s b) order (utils/ops.py:13-33 batchify)."""
+def state_from_td(env_name, td, num_starts: int = 0, copy: bool = True) -> ops.RolloutState:
+    """Flat state tensors for R = max(S,1)*B rows, replicated in the reference's (s b) order for multistart
+    (utils/ops.py:13-33 batchify).  The kernels update the state in place, so the tensors are copies: like the
+    reference's rollout, a policy call leaves the caller's TensorDict as it was (the same td can be rolled out again,
+    e.g. by a rollout baseline).  copy=False hands out views of the td's own tensors (read-only uses)."""
     mask = td["action_mask"]
     B, M = mask.shape
     S = max(int(num_starts), 1)
@@ -314,11 +316,14 @@ def state_from_td(env_name, td, num_starts: int = 0) -> ops.RolloutState:
     st.env_name, st.R, st.M = env_name, B * S, M
 
     def rep(t, dtype):
+        src = t
         t = t.reshape(B, -1) if t.dim() > 1 else t.reshape(B)
         if t.dtype != dtype:
             t = t.to(dtype)
         if S > 1:
             t = t.repeat(S, *([1] * (t.dim() - 1)))
+        elif copy and t.data_ptr() == src.data_ptr():     # still the caller's storage
+            t = t.clone()
         t = t.contiguous()
         return t.reshape(-1) if t.dim() == 2 and t.shape[1] == 1 else t
 
@@ -777,12 +782,11 @@ class GraphedRollout:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(max(1, warmup)):      # sets kernel attributes, fills caches, warms the allocator
-                policy._finish(policy._enqueue(self.static_td.clone(), env, **self.kw))
+                policy._finish(policy._enqueue(self.static_td, env, **self.kw))
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
-            self._work = self.static_td.clone()          # the rollout updates its state tensors in place
-            self._pending = policy._enqueue(self._work, env, **self.kw)
+            self._pending = policy._enqueue(self.static_td, env, **self.kw)     # works on copies of the state tensors
 
     @torch.no_grad()
     def __call__(self, td) -> dict:

@@ -220,6 +220,24 @@ def test_reinforce_step_pomo_and_flat_allreduce():
     assert np.isfinite(first)
 
 
+@pytest.mark.parametrize("env_name", ["tsp", "cvrp", "sdvrp"])
+def test_policy_call_leaves_the_callers_tensordict_untouched(env_name):
+    """As in the reference, a rollout works on its own copy of the state: the same reset td can be rolled out twice
+    (REINFORCE followed by a rollout baseline does exactly that) with identical results."""
+    import eam_rl4co_amd as ea
+
+    pol = make_policy("am_" + env_name)
+    env = ea.get_env(env_name, generator_params=dict(num_loc=20), seed=11)
+    td = env.reset(batch_size=[8]).to(DEV)
+    before = {k: v.clone() for k, v in td.items()}
+    a = pol(td, env, phase="test", decode_type="greedy")
+    for k, v in before.items():
+        assert torch.equal(td[k], v), k
+    b = pol(td, env, phase="test", decode_type="greedy")
+    assert_bits_equal(a["actions"], b["actions"], "actions")
+    assert_bits_equal(a["reward"], b["reward"], "reward")
+
+
 # ---------------------------------------------------------------------------------------------------------
 # HIP graph replay of the whole rollout
 # ---------------------------------------------------------------------------------------------------------
