@@ -49,7 +49,7 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
-enum { ORC_ENV_TSP = 0, ORC_ENV_CVRP = 1, ORC_ENV_SDVRP = 2 };
+enum { ORC_ENV_TSP = 0, ORC_ENV_CVRP = 1, ORC_ENV_SDVRP = 2, ORC_ENV_PCTSP = 3 };
 enum { ORC_GREEDY = 0, ORC_SAMPLE = 1, ORC_EVALUATE = 2 };
 #define ORC_NCHUNK 4 /* node chunks for the glimpse accumulation, column chunks for the logit dot */
 
@@ -394,6 +394,39 @@ ORC_API void orc_sdvrp_step(float* rem, float* used, const float* vcap, int64_t*
     orc_sdvrp_mask(rem, used, vcap, cur, mask, R, M);
 }
 
+/* PCTSPEnv.get_action_mask  [rl4co/envs/routing/pctsp/env.py:156-163].  visited [R][M], prize_tot [R] (cur_total_prize):
+ * a customer is feasible until visited and until the depot has been visited; the depot is infeasible while the collected
+ * prize is below 1 and an unvisited customer remains. */
+ORC_API void orc_pctsp_mask(const uint8_t* visited, const float* prize_tot, uint8_t* mask, long R, int M)
+{
+    for (long r = 0; r < R; ++r) {
+        const uint8_t* v = visited + r * M;
+        int unvisited = 0;
+        for (int n = 1; n < M; ++n) {
+            mask[r * M + n] = !(v[n] | v[0]);
+            unvisited |= !v[n];
+        }
+        mask[r * M] = !((prize_tot[r] < 1.0f) && unvisited);
+    }
+}
+
+/* PCTSPEnv._step (+ mask)  [pctsp/env.py:64-97].  prize / penalty [Binst][M] with a zero depot slot; pen_tot may be NULL */
+ORC_API void orc_pctsp_step(uint8_t* visited, float* prize_tot, float* pen_tot, const float* prize, const float* penalty,
+                            int64_t* cur, int64_t* istep, const int64_t* action, uint8_t* mask, uint8_t* done,
+                            long R, long Binst, int M)
+{
+    for (long r = 0; r < R; ++r) {
+        const int64_t a = action[r];
+        prize_tot[r] = prize_tot[r] + prize[(r % Binst) * M + a];
+        if (pen_tot) pen_tot[r] = pen_tot[r] + penalty[(r % Binst) * M + a];
+        visited[r * M + a] = 1;
+        done[r] = (istep[r] > 0) && (a == 0);
+        cur[r] = a;
+        istep[r] += 1;
+    }
+    orc_pctsp_mask(visited, prize_tot, mask, R, M);
+}
+
 /* ------------------------------------------------------------------------------------------
  * decode step (decoder + process_logits + selection); one row = one instance or one (start,instance)
  * ---------------------------------------------------------------------------------------- */
@@ -600,6 +633,8 @@ ORC_API int orc_decode_step(int env, long R, long Binst, int M, int E, int H,
 #pragma omp for schedule(static)
         for (long r = 0; r < R; ++r) {
             float remaining = (env != ORC_ENV_TSP) ? (vcap[r] - used[r]) : 0.0f;
+            /* PCTSPContext: clamp(prize_required - cur_total_prize, min=0)   nn/env_embeddings/context.py:194-208 */
+            if (env == ORC_ENV_PCTSP && remaining < 0.0f) remaining = 0.0f;
             int st = decode_row(&c, r, first ? first[r] : 0, cur[r], istep ? istep[r] : 1, remaining,
                                 rem ? rem + r * (long)M : NULL, mask + r * (long)M, mode, noise ? noise + r * (long)M : NULL,
                                 given ? given[r] : 0, out_action + r, out_logp + r,
@@ -647,6 +682,47 @@ ORC_API void orc_tour_length(const float* locs, const int64_t* actions, float* r
         }
         free(d);
     }
+}
+
+/* PCTSPEnv._get_reward  [pctsp/env.py:165-187]: saved penalties - (tour length from / to the depot + all penalties).
+ * penalty [Binst][M] with a zero depot slot.  Sums of penalties go through the lane tree like the tour length. */
+ORC_API void orc_pctsp_reward(const float* locs, const float* penalty, const int64_t* actions, float* reward,
+                              long R, long Binst, int M, int T)
+{
+    float* len = (float*)malloc(sizeof(float) * R);
+    orc_tour_length(locs, actions, len, R, Binst, M, T, 1);          /* = -length */
+    float* sv = (float*)malloc(sizeof(float) * (T > M ? T : M));
+    for (long r = 0; r < R; ++r) {
+        const float* pen = penalty + (r % Binst) * (long)M;
+        for (int t = 0; t < T; ++t) sv[t] = pen[actions[r * T + t]];
+        const float saved = lane_tree(sv, T);
+        const float total = lane_tree(pen + 1, M - 1);
+        reward[r] = saved - ((0.0f - len[r]) + total);
+    }
+    free(sv); free(len);
+}
+
+/* PCTSPEnv.check_solution_validity  [pctsp/env.py:189-205].  Returns rows with a customer visited twice (or an id out of
+ * range) + 1000000 * rows that neither collect a total prize >= 1 - 1e-5 nor visit every customer. */
+ORC_API long orc_check_pctsp(const int64_t* actions, const float* prize, long R, long Binst, int M, int T)
+{
+    long dup = 0, low = 0;
+    uint8_t* seen = (uint8_t*)malloc(M);
+    for (long r = 0; r < R; ++r) {
+        memset(seen, 0, M);
+        int ok = 1, cnt = 0;
+        float p = 0.0f;
+        for (int t = 0; t < T; ++t) {
+            int64_t a = actions[r * T + t];
+            if (a < 0 || a >= M) { ok = 0; break; }
+            if (a != 0) { if (seen[a]) { ok = 0; break; } seen[a] = 1; ++cnt; }
+            p = p + prize[(r % Binst) * M + a];
+        }
+        if (!ok) { ++dup; continue; }
+        if (!((p >= (float)(1.0 - 1e-5)) || cnt == M - 1)) ++low;
+    }
+    free(seen);
+    return dup + 1000000 * low;
 }
 
 /* sum of per-step selected log-probs, sequential over t */
@@ -744,6 +820,7 @@ ORC_API int orc_rollout(int env, long R, long Binst, int M, int E, int H,
         for (long r = 0; r < R; ++r) { actions[r * (long)Tmax + t] = a[r]; logps[r * (long)Tmax + t] = lp[r]; }
         if (env == ORC_ENV_TSP) orc_tsp_step(mask, first, cur, istep, a, done, R, M);
         else if (env == ORC_ENV_CVRP) orc_cvrp_step(visited, used, vcap, demand, cur, a, mask, done, R, Binst, M - 1);
+        else if (env == ORC_ENV_PCTSP) orc_pctsp_step(visited, used, NULL, demand, NULL, cur, istep, a, mask, done, R, Binst, M);
         else orc_sdvrp_step(rem, used, vcap, cur, a, mask, done, R, M);
         ++t;
     }

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ENV_TSP, ENV_CVRP, ENV_SDVRP = 0, 1, 2
+ENV_TSP, ENV_CVRP, ENV_SDVRP, ENV_PCTSP = 0, 1, 2, 3
 GREEDY, SAMPLE, EVALUATE = 0, 1, 2
 MODES = {"greedy": GREEDY, "sampling": SAMPLE, "evaluate": EVALUATE}
 
@@ -169,13 +169,19 @@ def mean_nodes(emb):
 # encoder + cache (AttentionModelEncoder.forward, AttentionModelDecoder._precompute_cache)
 # ---------------------------------------------------------------------------------------------
 def encode(sd, env_name, locs, demand=None, num_heads=8):
-    """-> (init_embeds, embeddings).  locs: TSP [B,N,2]; CVRP [B,N+1,2] with depot first."""
+    """-> (init_embeds, embeddings).  locs: TSP [B,N,2]; CVRP [B,N+1,2] with depot first.
+    PCTSP: `demand` is the dict of instance tensors (expected_prize [B,N], real_prize / penalty [B,N+1], prize_required);
+    node features = (x, y, expected prize, penalty)  [nn/env_embeddings/init.py:227-257]."""
     pre = "encoder.init_embedding."
     if env_name == "tsp":
         h = linear(locs, sd[pre + "init_embed.weight"], sd[pre + "init_embed.bias"])
     else:
         depot = linear(locs[:, :1], sd[pre + "init_embed_depot.weight"], sd[pre + "init_embed_depot.bias"])
-        feat = np.concatenate([_f32(locs[:, 1:]), _f32(demand)[..., None]], -1)
+        if env_name == "pctsp":
+            extra = [_f32(demand["expected_prize"])[..., None], _f32(demand["penalty"])[:, 1:, None]]
+        else:
+            extra = [_f32(demand)[..., None]]
+        feat = np.concatenate([_f32(locs[:, 1:])] + extra, -1)
         cust = linear(feat, sd[pre + "init_embed.weight"], sd[pre + "init_embed.bias"])
         h = np.concatenate([depot, cust], 1)
     init_h = h.copy()
@@ -231,8 +237,10 @@ class State:
 
     def __init__(self, env_name, locs, demand=None, vehicle_capacity=1.0, num_starts=0):
         self.env_name = env_name
-        self.env = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP}[env_name]
+        self.env = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP, "pctsp": ENV_PCTSP}[env_name]
         self.rem = None
+        if env_name == "pctsp":      # used = cur_total_prize, vcap = prize_required, demand = real_prize (depot slot 0)
+            demand, vehicle_capacity = demand["real_prize"], float(np.asarray(demand["prize_required"]).reshape(-1)[0])
         self.locs = _f32(locs)
         self.Binst, self.M = self.locs.shape[:2]
         S = max(int(num_starts), 1)
@@ -247,6 +255,11 @@ class State:
             self.demand = None
             self.visited = None
             self.mask = np.ones((R, self.M), np.uint8)
+        elif env_name == "pctsp":
+            self.demand = _f32(demand)
+            self.visited = np.zeros((R, self.M), np.uint8)
+            self.mask = np.empty((R, self.M), np.uint8)
+            lib().orc_pctsp_mask(_p(self.visited), _p(self.used), _p(self.mask), C.c_long(R), C.c_int(self.M))
         elif env_name == "sdvrp":        # remaining demand per row, depot slot 0 (sdvrp/env.py:94-118)
             self.demand = _f32(demand)
             self.visited = None
@@ -267,6 +280,10 @@ class State:
         if self.env == ENV_TSP:
             lib().orc_tsp_step(_p(self.mask), _p(self.first), _p(self.cur), _p(self.istep), _p(a), _p(self.done),
                                C.c_long(self.R), C.c_int(self.M))
+        elif self.env == ENV_PCTSP:
+            lib().orc_pctsp_step(_p(self.visited), _p(self.used), None, _p(self.demand), None, _p(self.cur), _p(self.istep),
+                                 _p(a), _p(self.mask), _p(self.done), C.c_long(self.R), C.c_long(self.Binst),
+                                 C.c_int(self.M))
         elif self.env == ENV_SDVRP:
             lib().orc_sdvrp_step(_p(self.rem), _p(self.used), _p(self.vcap), _p(self.cur), _p(a), _p(self.mask),
                                  _p(self.done), C.c_long(self.R), C.c_int(self.M))
@@ -342,6 +359,22 @@ def tour_length_reward(locs, actions, with_depot, binst=None):
     return out
 
 
+def pctsp_reward(locs, penalty, actions):
+    locs, penalty, actions = _f32(locs), _f32(penalty), _i64(actions)
+    R, T = actions.shape
+    Binst, M = locs.shape[:2]
+    out = np.empty(R, np.float32)
+    lib().orc_pctsp_reward(_p(locs), _p(penalty), _p(actions), _p(out), C.c_long(R), C.c_long(Binst), C.c_int(M), C.c_int(T))
+    return out
+
+
+def check_pctsp(actions, real_prize):
+    actions, real_prize = _i64(actions), _f32(real_prize)
+    lib().orc_check_pctsp.restype = C.c_long
+    return int(lib().orc_check_pctsp(_p(actions), _p(real_prize), C.c_long(actions.shape[0]), C.c_long(real_prize.shape[0]),
+                                     C.c_int(real_prize.shape[1]), C.c_int(actions.shape[1])))
+
+
 def sum_logp(logp):
     logp = _f32(logp)
     R, T = logp.shape
@@ -390,7 +423,10 @@ def policy_rollout(sd, env_name, locs, demand=None, decode_type="greedy", num_st
                         top_k=top_k, top_p=top_p)
     actions = np.concatenate(pre_a + [acts], 1)
     logp = np.concatenate(pre_lp + [lps], 1)
-    reward = tour_length_reward(locs, actions, with_depot=(env_name != "tsp"))
+    if env_name == "pctsp":
+        reward = pctsp_reward(locs, demand["penalty"], actions)
+    else:
+        reward = tour_length_reward(locs, actions, with_depot=(env_name != "tsp"))
     return {"actions": actions, "logp_steps": logp, "log_likelihood": sum_logp(logp), "reward": reward,
             "steps": acts.shape[1], "embeddings": emb, "cache": cache}
 

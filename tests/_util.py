@@ -10,8 +10,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 with open(os.path.join(GOLDEN, "state_dict_contract.json")) as _f:
     CONTRACT = json.load(_f)
-with open(os.path.join(GOLDEN, "state_dict_contract_sdvrp.json")) as _f:      # the split-delivery sibling env
-    CONTRACT.update(json.load(_f))
+for _name in ("state_dict_contract_sdvrp.json", "state_dict_contract_pctsp.json"):      # the sibling envs
+    with open(os.path.join(GOLDEN, _name)) as _f:
+        CONTRACT.update(json.load(_f))
 
 
 def golden(name):
@@ -34,3 +35,11 @@ def golden_weights(cfg):
 def cfg_for(fx):
     pomo = "policy_kw_num_encoder_layers" in fx
     return ("pomo_" if pomo else "am_") + str(fx["env_name"])
+
+
+def instance_of(fx):
+    """The per-instance tensors besides locs, as the oracle / make_td take them: the demand array (CVRP, SDVRP), the
+    dict of prize tensors (PCTSP) or None (TSP)."""
+    if str(fx["env_name"]) == "pctsp":
+        return {k: fx[k] for k in ("expected_prize", "real_prize", "penalty", "prize_required")}
+    return fx.get("demand")

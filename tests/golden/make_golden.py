@@ -36,6 +36,7 @@ import torch  # noqa: E402
 import goldweights  # noqa: E402
 import rl4co.utils.decoding as ref_decoding  # noqa: E402
 from rl4co.envs.routing.cvrp.env import CVRPEnv  # noqa: E402
+from rl4co.envs.routing.pctsp.env import PCTSPEnv  # noqa: E402
 from rl4co.envs.routing.sdvrp.env import SDVRPEnv  # noqa: E402
 from rl4co.envs.routing.tsp.env import TSPEnv  # noqa: E402
 from rl4co.models.zoo.am.policy import AttentionModelPolicy  # noqa: E402
@@ -110,7 +111,7 @@ def np_(t):
 def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_starts=None,
              keep_steps=None, keep_embeds=False, data_seed=1234, sample_seed=4321, actions=None,
              td_init=None, decode_kw=None):
-    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv}[env_name]
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv}[env_name]
     env = Env(generator_params=dict(num_loc=num_loc), seed=data_seed)
     if td_init is None:
         torch.manual_seed(data_seed)
@@ -146,6 +147,9 @@ def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_st
     if env_name in ("cvrp", "sdvrp"):
         fx["demand"] = np_(td_init["demand"])
         fx["vehicle_capacity"] = np_(td_init["vehicle_capacity"])
+    if env_name == "pctsp":
+        for k in ("expected_prize", "real_prize", "penalty", "prize_required"):
+            fx[k] = np_(td_init[k])
     if rec.noise:
         fx["noise"] = np.stack([np_(q) for q in rec.noise], 1)  # [rows, T, M] Exp(1) draws
     if policy_kw:
@@ -170,7 +174,7 @@ def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_st
 
 def run_env_case(name, env_name, num_loc, batch, data_seed=99, act_seed=7):
     """Env-only golden: random feasible policy, every state tensor after every step."""
-    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv}[env_name]
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv}[env_name]
     env = Env(generator_params=dict(num_loc=num_loc), seed=data_seed)
     torch.manual_seed(data_seed)
     gen = env.generator(batch_size=[batch])
@@ -183,7 +187,8 @@ def run_env_case(name, env_name, num_loc, batch, data_seed=99, act_seed=7):
     torch.manual_seed(act_seed)
     per = {k: [] for k in ("action", "action_mask", "done", "current_node")}
     extra = {"tsp": ("first_node", "i"), "cvrp": ("used_capacity", "visited"),
-             "sdvrp": ("used_capacity", "demand_with_depot")}[env_name]
+             "sdvrp": ("used_capacity", "demand_with_depot"),
+             "pctsp": ("cur_total_prize", "cur_total_penalty", "visited", "i")}[env_name]
     for k in extra:
         per[k] = []
     while not td["done"].all():
@@ -273,6 +278,21 @@ def beam():
              decode_kw=dict(beam_width=12, select_best=False))
 
 
+def pctsp():
+    """Sixth batch (python make_golden.py pctsp): prize-collecting TSP."""
+    import json
+    first4 = [0, 1, 2, 3]
+    sd = AttentionModelPolicy(env_name="pctsp").state_dict()
+    with open(os.path.join(HERE, "state_dict_contract_pctsp.json"), "w") as f:
+        json.dump({"am_pctsp": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]}, f, indent=0)
+    run_case("pctsp20_greedy", "pctsp", 20, 4, "greedy", keep_embeds=True, data_seed=71)
+    run_case("pctsp20_sampling", "pctsp", 20, 4, "sampling", keep_steps=first4, data_seed=72)
+    run_case("pctsp50_greedy", "pctsp", 50, 4, "greedy", keep_steps=first4, data_seed=73)
+    run_case("pctsp100_sampling", "pctsp", 100, 4, "sampling", keep_steps=first4, data_seed=75)
+    run_case("pctsp20_multistart_greedy", "pctsp", 20, 3, "multistart_greedy", num_starts=20, keep_steps=first4, data_seed=74)
+    run_env_case("env_pctsp20_random", "pctsp", 20, 8)
+
+
 def sdvrp():
     """Fifth batch (python make_golden.py sdvrp): the split-delivery sibling env."""
     import json
@@ -300,7 +320,9 @@ def filtering():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "sdvrp":
+    if len(sys.argv) > 1 and sys.argv[1] == "pctsp":
+        pctsp()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sdvrp":
         sdvrp()
     elif len(sys.argv) > 1 and sys.argv[1] == "filtering":
         filtering()

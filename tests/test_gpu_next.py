@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import cfg_for, golden, golden_weights
+from _util import cfg_for, golden, golden_weights, instance_of
 from test_gpu_parity import DEV, assert_bits_equal, make_policy, make_td, t
 
 pytestmark = pytest.mark.gpu
@@ -186,7 +186,7 @@ def test_reevaluation_matches_native_logp_and_reference(name, cfg):
     fx = golden(name)
     pol = make_policy(cfg)
     env_name = str(fx["env_name"])
-    env, td = make_td(env_name, fx["locs"], fx.get("demand"))
+    env, td = make_td(env_name, fx["locs"], instance_of(fx))
     ns = int(fx["num_starts"])
     logp = evaluate_log_likelihood(pol, td, env, t(fx["actions"]), num_starts=ns)
     assert logp.requires_grad
@@ -500,14 +500,14 @@ def test_beam_search_reproduces_reference_tours(oracle, name):
     cfg = cfg_for(fx)
     env_name = str(fx["env_name"])
     pol = make_policy(cfg)
-    env, td = make_td(env_name, fx["locs"], fx.get("demand"))
+    env, td = make_td(env_name, fx["locs"], instance_of(fx))
     kw = dict(select_best=bool(fx["decode_kw_select_best"]))
     if "decode_kw_beam_width" in fx:
         kw["beam_width"] = int(fx["decode_kw_beam_width"])
     out = pol(td, env, phase="test", decode_type="beam_search", return_sum_log_likelihood=False, **kw)
     assert_bits_equal(out["actions"], fx["actions"], "beam-search tours vs reference")
     np.testing.assert_allclose(out["reward"].cpu().numpy(), fx["reward"], rtol=1e-6, atol=0)
-    o = oracle.policy_beam_search(golden_weights(cfg), env_name, fx["locs"], fx.get("demand"),
+    o = oracle.policy_beam_search(golden_weights(cfg), env_name, fx["locs"], instance_of(fx),
                                   beam_width=kw.get("beam_width"), select_best=kw["select_best"])
     assert_bits_equal(out["log_likelihood"], o["logp_steps"], "per-step logp vs oracle")
     assert_bits_equal(out["reward"], o["reward"], "reward vs oracle")

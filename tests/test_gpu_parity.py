@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import cfg_for, golden, golden_weights
+from _util import cfg_for, golden, golden_weights, instance_of
 
 pytestmark = pytest.mark.gpu
 
@@ -180,12 +180,12 @@ def test_encoder_and_cache_bit_exact(oracle, name):
     cfg = cfg_for(fx)
     env_name = str(fx["env_name"])
     pol = make_policy(cfg)
-    env, td = make_td(env_name, fx["locs"], fx.get("demand"))
+    env, td = make_td(env_name, fx["locs"], instance_of(fx))
     with torch.no_grad():
         emb, init_h = pol.encoder(td)
         cache = pol.decoder._precompute_cache(emb)
     sd = golden_weights(cfg)
-    o_init, o_emb = oracle.encode(sd, env_name, fx["locs"], fx.get("demand"))
+    o_init, o_emb = oracle.encode(sd, env_name, fx["locs"], instance_of(fx))
     assert_bits_equal(init_h, o_init, "init embedding")
     assert_bits_equal(emb, o_emb, "encoder output")
     oc = oracle.precompute(sd, env_name, o_emb, use_graph_context=pol.decoder.use_graph_context)
@@ -217,14 +217,14 @@ def test_decode_step_api_bit_exact_every_step(oracle, name):
     env_name = str(fx["env_name"])
     ns = int(fx["num_starts"])
     pol = make_policy(cfg)
-    env, td = make_td(env_name, fx["locs"], fx.get("demand"))
+    env, td = make_td(env_name, fx["locs"], instance_of(fx))
     sd = golden_weights(cfg)
     with torch.no_grad():
         emb, _ = pol.encoder(td)
         cache = pol.decoder._precompute_cache(emb)
-    _, o_emb = oracle.encode(sd, env_name, fx["locs"], fx.get("demand"))
+    _, o_emb = oracle.encode(sd, env_name, fx["locs"], instance_of(fx))
     oc = oracle.precompute(sd, env_name, o_emb, use_graph_context=pol.decoder.use_graph_context)
-    ost = oracle.State(env_name, fx["locs"], fx.get("demand"), num_starts=ns)
+    ost = oracle.State(env_name, fx["locs"], instance_of(fx), num_starts=ns)
     st = state_from_td(env_name, td, ns)
     actions = fx["actions"]
     col = 0
@@ -287,7 +287,7 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
     env_name = str(fx["env_name"])
     ns = int(fx["num_starts"])
     pol = make_policy(cfg)
-    env, td = make_td(env_name, fx["locs"], fx.get("demand"))
+    env, td = make_td(env_name, fx["locs"], instance_of(fx))
     decode_type = str(fx["decode_type"])
     kw = {}
     if name.endswith("evaluate"):
@@ -313,7 +313,7 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
     assert_bits_equal(out["actions"], fx["actions"], "tours vs reference")
     np.testing.assert_allclose(out["reward"].cpu().numpy(), fx["reward"], rtol=1e-6, atol=0)
     np.testing.assert_allclose(out["log_likelihood"].cpu().numpy(), fx["logp_steps"], rtol=0, atol=1e-5)
-    o = oracle.policy_rollout(golden_weights(cfg), env_name, fx["locs"], fx.get("demand"),
+    o = oracle.policy_rollout(golden_weights(cfg), env_name, fx["locs"], instance_of(fx),
                               decode_type=decode_type if "actions" not in kw else "evaluate", num_starts=ns,
                               noise=fx.get("noise"), given=fx["actions"] if "actions" in kw else None,
                               use_graph_context=pol.decoder.use_graph_context,

@@ -11,7 +11,7 @@ tolerance-level by nature:
 import numpy as np
 import pytest
 
-from _util import cfg_for, golden, golden_weights
+from _util import cfg_for, golden, golden_weights, instance_of
 
 POLICY_CASES = [
     "tsp20_greedy", "tsp20_sampling", "tsp20_evaluate", "tsp20_multistart_greedy", "tsp100_greedy", "tsp100_sampling",
@@ -24,6 +24,8 @@ POLICY_CASES = [
     "tsp20_sampling_topk5", "tsp20_sampling_topp", "cvrp20_sampling_topk_topp", "tsp100_greedy_topk",
     # SDVRP (split delivery): dynamic embedding + partial-delivery state machine
     "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy",
+    # PCTSP (prize collecting): prize-gated depot, penalty reward
+    "pctsp20_greedy", "pctsp20_sampling", "pctsp50_greedy", "pctsp100_sampling", "pctsp20_multistart_greedy",
 ]
 
 
@@ -35,7 +37,7 @@ def _run(orc, fx):
     if ns > 1 and "multistart" not in decode_type:
         decode_type = "multistart_" + decode_type
     return orc.policy_rollout(
-        sd, str(fx["env_name"]), fx["locs"], fx.get("demand"), decode_type=decode_type, num_starts=ns,
+        sd, str(fx["env_name"]), fx["locs"], instance_of(fx), decode_type=decode_type, num_starts=ns,
         noise=fx.get("noise"), given=given, use_graph_context=bool(fx.get("policy_kw_use_graph_context", True)),
         clip=float(fx.get("decode_kw_tanh_clipping", 10.0)), temp=float(fx.get("decode_kw_temperature", 1.0)),
         top_k=int(fx.get("decode_kw_top_k", 0)), top_p=float(fx.get("decode_kw_top_p", 0.0)))
@@ -54,12 +56,12 @@ def test_policy_rollout_matches_reference(oracle, name):
     np.testing.assert_allclose(out["log_likelihood"], fx["log_likelihood"], rtol=2e-6, atol=0)
 
 
-@pytest.mark.parametrize("name", ["tsp20_greedy", "cvrp20_greedy", "pomo_tsp20_multistart_sampling"])
+@pytest.mark.parametrize("name", ["tsp20_greedy", "cvrp20_greedy", "pomo_tsp20_multistart_sampling", "pctsp20_greedy"])
 def test_encoder_and_cache_match_reference(oracle, name):
     fx = golden(name)
     sd = golden_weights(cfg_for(fx))
     env = str(fx["env_name"])
-    init_h, emb = oracle.encode(sd, env, fx["locs"], fx.get("demand"))
+    init_h, emb = oracle.encode(sd, env, fx["locs"], instance_of(fx))
     np.testing.assert_allclose(init_h, fx["init_embeds"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(emb, fx["embeddings"], rtol=0, atol=1e-5)
     use_gc = fx["graph_context"].size > 0
@@ -79,9 +81,9 @@ def test_per_step_logits_logprobs_masks(oracle, name):
     sd = golden_weights(cfg_for(fx))
     env = str(fx["env_name"])
     ns = int(fx["num_starts"])
-    _, emb = oracle.encode(sd, env, fx["locs"], fx.get("demand"))
+    _, emb = oracle.encode(sd, env, fx["locs"], instance_of(fx))
     cache = oracle.precompute(sd, env, emb)
-    st = oracle.State(env, fx["locs"], fx.get("demand"), num_starts=ns)
+    st = oracle.State(env, fx["locs"], instance_of(fx), num_starts=ns)
     actions = fx["actions"]
     col = 0
     if ns > 1:
@@ -103,12 +105,18 @@ def test_per_step_logits_logprobs_masks(oracle, name):
     assert st.done.all()
 
 
-@pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random"])
+@pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random",
+                                  "env_pctsp20_random"])
 def test_env_state_machine_bit_exact(oracle, name):
     fx = golden(name)
     env = str(fx["env_name"])
     if env == "tsp":
         locs, demand = fx["gen_locs"], None
+    elif env == "pctsp":
+        locs = np.concatenate([fx["gen_depot"][:, None], fx["gen_locs"]], 1)
+        pad = lambda a: np.concatenate([np.zeros((a.shape[0], 1), np.float32), a], 1)
+        demand = {"expected_prize": fx["gen_deterministic_prize"], "real_prize": pad(fx["gen_deterministic_prize"]),
+                  "penalty": pad(fx["gen_penalty"]), "prize_required": 1.0}
     else:
         locs = np.concatenate([fx["gen_depot"][:, None], fx["gen_locs"]], 1)
         demand = fx["gen_demand"]
@@ -126,14 +134,28 @@ def test_env_state_machine_bit_exact(oracle, name):
         elif env == "sdvrp":
             assert np.array_equal(st.rem, fx["step_demand_with_depot"][:, t]), t       # exact: min / add / sub only
             assert np.array_equal(st.used, fx["step_used_capacity"][:, t].reshape(-1)), t
+        elif env == "pctsp":
+            assert np.array_equal(st.visited.astype(bool), fx["step_visited"][:, t]), t
+            assert np.array_equal(st.used, fx["step_cur_total_prize"][:, t]), t         # one fp32 add per step
+            assert np.array_equal(st.istep, fx["step_i"][:, t]), t
         else:
             assert np.array_equal(st.visited, fx["step_visited"][:, t]), t
             # one fp32 add + one mul per step, no reductions: exactly reproducible
             assert np.array_equal(st.used, fx["step_used_capacity"][:, t].reshape(-1)), t
-    reward = oracle.tour_length_reward(locs, fx["step_action"], with_depot=(env != "tsp"))
+    if env == "pctsp":
+        reward = oracle.pctsp_reward(locs, demand["penalty"], fx["step_action"])
+    else:
+        reward = oracle.tour_length_reward(locs, fx["step_action"], with_depot=(env != "tsp"))
     np.testing.assert_allclose(reward, fx["reward"], rtol=1e-6, atol=0)
     if env == "tsp":
         assert oracle.check_tsp(fx["step_action"]) == 0
+    elif env == "pctsp":
+        assert oracle.check_pctsp(fx["step_action"], demand["real_prize"]) == 0
+        twice = fx["step_action"].copy()
+        twice[0, 1] = twice[0, 0]                         # a customer visited twice
+        assert oracle.check_pctsp(twice, demand["real_prize"]) % 1000000 == 1
+        early = np.zeros_like(fx["step_action"]); early[:, 0] = fx["step_action"][:, 0]   # one customer, then home
+        assert oracle.check_pctsp(early, demand["real_prize"]) // 1000000 == early.shape[0]
     elif env == "cvrp":
         assert oracle.check_cvrp(fx["step_action"], demand, 1.0) == 0
     else:
@@ -258,7 +280,7 @@ def test_beam_search_matches_reference(oracle, name):
     """decode_type="beam_search" of the reference (beam_width = num_loc or given, with and without select_best)."""
     fx = golden(name)
     bw = int(fx["decode_kw_beam_width"]) if "decode_kw_beam_width" in fx else None
-    out = oracle.policy_beam_search(golden_weights(cfg_for(fx)), str(fx["env_name"]), fx["locs"], fx.get("demand"),
+    out = oracle.policy_beam_search(golden_weights(cfg_for(fx)), str(fx["env_name"]), fx["locs"], instance_of(fx),
                                     beam_width=bw, select_best=bool(fx["decode_kw_select_best"]))
     assert np.array_equal(out["actions"], fx["actions"]), "beam-search tours differ from the reference"
     np.testing.assert_allclose(out["reward"], fx["reward"], rtol=1e-6, atol=0)
