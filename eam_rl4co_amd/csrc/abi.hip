@@ -91,6 +91,30 @@ __attribute__((visibility("default"))) int eamrl_sdvrp_step_mask(float* rem, flo
                     "eamrl_sdvrp_step_mask");
 }
 
+__attribute__((visibility("default"))) int eamrl_pctsp_step_mask(uint8_t* visited, float* prize_tot, float* pen_tot,
+                                                                const float* prize, const float* penalty, int64_t* cur,
+                                                                int64_t* istep, const int64_t* action, uint8_t* mask,
+                                                                uint8_t* done, int64_t R, int64_t B, int M, void* stream)
+{
+    REQUIRE(visited && prize_tot && mask, "eamrl_pctsp_step_mask");
+    REQUIRE(!action || (prize && cur && istep && done), "eamrl_pctsp_step_mask");
+    REQUIRE(!pen_tot || penalty, "eamrl_pctsp_step_mask");
+    REQUIRE(R >= 0 && B > 0 && M >= 2, "eamrl_pctsp_step_mask");
+    if (R == 0) return 0;
+    return launched(launch_pctsp(visited, prize_tot, pen_tot, prize, penalty, cur, istep, action, mask, done, R, B, M,
+                                 (hipStream_t)stream), "eamrl_pctsp_step_mask");
+}
+
+__attribute__((visibility("default"))) int eamrl_pctsp_reward(const float* locs, const float* penalty, const int64_t* actions,
+                                                             float* reward, int64_t R, int64_t B, int M, int T,
+                                                             void* stream)
+{
+    REQUIRE(locs && penalty && actions && reward && R >= 0 && B > 0 && M >= 2 && T > 0, "eamrl_pctsp_reward");
+    if (R == 0) return 0;
+    return launched(launch_tour_length(locs, actions, reward, R, B, M, T, 1, (hipStream_t)stream, penalty),
+                    "eamrl_pctsp_reward");
+}
+
 __attribute__((visibility("default"))) int eamrl_linear(const float* x, int64_t ldx, const float* W, int64_t ldw,
                                                        const float* bias, const float* res, int64_t ldres, float* y,
                                                        int64_t ldy, int64_t rows, int in_dim, int out_dim, int relu,
@@ -159,7 +183,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
                      uint32_t* status, DecArgs& a)
 {
     REQUIRE(c && s, what);
-    REQUIRE(env == EAMRL_ENV_TSP || env == EAMRL_ENV_CVRP || env == EAMRL_ENV_SDVRP, what);
+    REQUIRE(env >= EAMRL_ENV_TSP && env <= EAMRL_ENV_PCTSP, what);
     REQUIRE(mode == EAMRL_GREEDY || mode == EAMRL_SAMPLE || mode == EAMRL_EVALUATE, what);
     REQUIRE(c->K && c->V && c->Lp && c->Pa && c->cvec, what);
     REQUIRE(c->B > 0 && c->M > 0 && c->E > 0 && c->H > 0, what);
@@ -172,6 +196,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
     if (env == EAMRL_ENV_TSP) REQUIRE(c->Pb && s->first && s->istep, what);
     if (env == EAMRL_ENV_CVRP) REQUIRE(s->used && s->vcap && c->M >= 2, what);
     if (env == EAMRL_ENV_SDVRP) REQUIRE(s->used && s->vcap && s->rem && c->dyn && c->M >= 2, what);
+    if (env == EAMRL_ENV_PCTSP) REQUIRE(s->used && s->vcap && c->M >= 2, what);
     if (mode == EAMRL_SAMPLE) REQUIRE(noise != nullptr, what);
     if (mode == EAMRL_EVALUATE) REQUIRE(given != nullptr, what);
     a = DecArgs{};
@@ -200,6 +225,7 @@ __attribute__((visibility("default"))) int eamrl_am_decode_step(int env, const e
     if (fuse_env_step) {
         REQUIRE(a.done, "eamrl_am_decode_step");
         if (env == EAMRL_ENV_CVRP) REQUIRE(a.visited && a.demand, "eamrl_am_decode_step");
+        if (env == EAMRL_ENV_PCTSP) REQUIRE(a.visited && a.demand && a.istep, "eamrl_am_decode_step");
     }
     a.fuse_env = fuse_env_step;
     a.action = action; a.logp = logp; a.logprobs_all = logprobs_all; a.logits_raw = logits_raw;
@@ -219,6 +245,7 @@ __attribute__((visibility("default"))) int eamrl_am_rollout(int env, const eamrl
     if (rc) return rc;
     REQUIRE(actions && logps && steps_out && a.done && t_max > 0, "eamrl_am_rollout");
     if (env == EAMRL_ENV_CVRP) REQUIRE(a.visited && a.demand, "eamrl_am_rollout");
+    if (env == EAMRL_ENV_PCTSP) REQUIRE(a.visited && a.demand && a.istep, "eamrl_am_rollout");
     if (mode == EAMRL_EVALUATE) REQUIRE(t_given > 0, "eamrl_am_rollout");
     a.fuse_env = 1; a.t_max = t_max; a.t_given = t_given;
     a.action = actions; a.logp = logps; a.steps_out = steps_out;
@@ -251,8 +278,9 @@ __attribute__((visibility("default"))) int eamrl_check_solution(int env, const i
                                                                int32_t* bad, void* stream)
 {
     REQUIRE(actions && bad && R >= 0 && B > 0 && N > 0 && T > 0, "eamrl_check_solution");
-    REQUIRE(env == EAMRL_ENV_TSP || env == EAMRL_ENV_CVRP || env == EAMRL_ENV_SDVRP, "eamrl_check_solution");
-    if (env != EAMRL_ENV_TSP) REQUIRE(demand && vcap, "eamrl_check_solution");
+    REQUIRE(env >= EAMRL_ENV_TSP && env <= EAMRL_ENV_PCTSP, "eamrl_check_solution");
+    if (env == EAMRL_ENV_CVRP || env == EAMRL_ENV_SDVRP) REQUIRE(demand && vcap, "eamrl_check_solution");
+    if (env == EAMRL_ENV_PCTSP) REQUIRE(demand != nullptr, "eamrl_check_solution");
     if (R == 0) return 0;
     return launched(launch_check_solution(env, actions, demand, vcap, R, B, N, T, bad, (hipStream_t)stream),
                     "eamrl_check_solution");

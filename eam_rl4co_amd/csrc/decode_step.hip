@@ -74,7 +74,10 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             if (s.istep == 0) ctx = a.cvec[e];
             else ctx = a.Pa[(bi * M + s.first) * ld + e] + a.Pb[(bi * M + s.cur) * ld + e];
         } else {
-            ctx = fma_(a.cvec[e], s.vcap - s.used, a.Pa[(bi * M + s.cur) * ld + e]);
+            // VRPContext: free capacity; PCTSPContext: clamp(prize_required - cur_total_prize, min=0)  (context.py:160-208)
+            float state = s.vcap - s.used;
+            if (ENV == EAMRL_ENV_PCTSP) state = state < 0.0f ? 0.0f : state;
+            ctx = fma_(a.cvec[e], state, a.Pa[(bi * M + s.cur) * ld + e]);
         }
         l.q[e] = ctx + g;
     }
@@ -438,6 +441,25 @@ __device__ bool env_step_row(const DecArgs& a, const RowLds& l, uint8_t* vis, fl
         any_rem = __syncthreads_or(any_rem);
         if (tid == 0) l.msk[0] = !((s.cur == 0) && any_free);
         return any_rem == 0;
+    } else if (ENV == EAMRL_ENV_PCTSP) {
+        // PCTSPEnv._step + get_action_mask (pctsp/env.py:64-97,156-163); a.demand = real_prize [B][M]
+        const float* prize = a.demand + (r % a.B) * M;
+        s.used = s.used + prize[act];
+        const bool done = (s.istep > 0) && (act == 0);
+        s.cur = act;
+        s.istep += 1;
+        if (tid == 0) vis[act] = 1;
+        __syncthreads();
+        const int v0 = vis[0] != 0;
+        int unvisited = 0;
+        for (int n = 1 + tid; n < M; n += BLOCK) {
+            const int v = vis[n] != 0;
+            l.msk[n] = !(v | v0);
+            unvisited |= !v;
+        }
+        unvisited = __syncthreads_or(unvisited);
+        if (tid == 0) l.msk[0] = !((s.used < 1.0f) && unvisited);
+        return done;
     } else if (ENV == EAMRL_ENV_TSP) {
         if (s.istep == 0) s.first = act;
         s.cur = act;
@@ -485,7 +507,7 @@ __device__ __forceinline__ void load_row_state(const DecArgs& a, int64_t r, RowS
         s.vcap = 0.0f;
     } else {
         s.first = 0;
-        s.istep = 1;
+        s.istep = (ENV == EAMRL_ENV_PCTSP) ? a.istep[r] : 1;
         s.used = a.used[r];
         s.vcap = a.vcap[r];
     }
@@ -499,7 +521,7 @@ __device__ __forceinline__ void store_row_state(const DecArgs& a, const RowLds& 
     __syncthreads();
     for (int n = tid; n < a.M; n += BLOCK) {
         a.mask[r * a.M + n] = l.msk[n];
-        if (ENV == EAMRL_ENV_CVRP) a.visited[r * a.M + n] = vis[n];
+        if (ENV == EAMRL_ENV_CVRP || ENV == EAMRL_ENV_PCTSP) a.visited[r * a.M + n] = vis[n];
         if (ENV == EAMRL_ENV_SDVRP) a.rem[r * a.M + n] = rem[n];
     }
     if (tid == 0) {
@@ -507,6 +529,7 @@ __device__ __forceinline__ void store_row_state(const DecArgs& a, const RowLds& 
         a.done[r] = done ? 1 : 0;
         if (ENV == EAMRL_ENV_TSP) { a.first[r] = s.first; a.istep[r] = s.istep; }
         else a.used[r] = s.used;
+        if (ENV == EAMRL_ENV_PCTSP) a.istep[r] = s.istep;
     }
 }
 
@@ -518,7 +541,7 @@ __device__ __forceinline__ void load_row_lds(const DecArgs& a, const RowLds& l, 
     const int tid = threadIdx.x;
     for (int n = tid; n < a.M; n += BLOCK) {
         l.msk[n] = a.mask[r * a.M + n];
-        if (ENV == EAMRL_ENV_CVRP && want_vis) vis[n] = a.visited[r * a.M + n];
+        if ((ENV == EAMRL_ENV_CVRP || ENV == EAMRL_ENV_PCTSP) && want_vis) vis[n] = a.visited[r * a.M + n];
         if (ENV == EAMRL_ENV_SDVRP) rem[n] = a.rem[r * a.M + n];
     }
     if (ENV == EAMRL_ENV_SDVRP)
@@ -566,6 +589,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_stream(DecArgs a)
     const int tid = threadIdx.x;
     RowState s;
     load_row_state<ENV>(a, r, s);
+    const int64_t i0 = s.istep;
     load_row_lds<ENV>(a, l, vis, rem, dyn, r, true);
     bool done = a.done[r] != 0;
     __syncthreads();
@@ -580,6 +604,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_stream(DecArgs a)
         done = env_step_row<ENV>(a, l, vis, rem, r, s, act);
         ++t;
     }
+    if (ENV == EAMRL_ENV_PCTSP) s.istep = i0;      // k_rollout_pad adds the batch's step count (see there)
     store_row_state<ENV>(a, l, vis, rem, r, s, done);
     if (tid == 0) {
         atomicMax(a.steps_out, t);
@@ -590,11 +615,14 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_stream(DecArgs a)
 // After the loop the reference keeps stepping finished CVRP rows with the depot until the slowest row
 // is done: rows whose last real action was a customer end at the depot with an
 // empty vehicle.  actions/logps are already right-padded with 0; this fixes the state tensors.
-__global__ void k_rollout_pad_cvrp(DecArgs a)
+// PCTSP: the reference keeps counting `i` for finished rows too, so every row ends at i0 + T; the rollout kernels store
+// i0 and this adds the batch's step count.
+__global__ void k_rollout_pad(DecArgs a, int env)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.R) return;
     const int T = *a.steps_out;
+    if (env == EAMRL_ENV_PCTSP) { a.istep[r] += T; return; }
     if (T <= 0 || !a.done[r]) return;
     // A row that needed fewer than T steps never wrote column T-1 (host pre-zeroed = depot); stepping a
     // finished row with the depot makes (cur, used) = (0, 0) and leaves mask/visited unchanged.
@@ -602,6 +630,12 @@ __global__ void k_rollout_pad_cvrp(DecArgs a)
         a.cur[r] = 0;
         a.used[r] = 0.0f;
     }
+}
+
+void launch_rollout_pad(int env, const DecArgs& a, hipStream_t st)
+{
+    if (env != EAMRL_ENV_TSP)
+        hipLaunchKernelGGL(k_rollout_pad, dim3((unsigned)((a.R + 255) / 256)), dim3(256), 0, st, a, env);
 }
 
 static int launch_decode(int env, const DecArgs& a, bool rollout, hipStream_t st)
@@ -615,18 +649,19 @@ static int launch_decode(int env, const DecArgs& a, bool rollout, hipStream_t st
     void (*k)(DecArgs);
     if (rollout)
         k = env == EAMRL_ENV_TSP ? k_rollout_stream<EAMRL_ENV_TSP>
-          : env == EAMRL_ENV_CVRP ? k_rollout_stream<EAMRL_ENV_CVRP> : k_rollout_stream<EAMRL_ENV_SDVRP>;
+          : env == EAMRL_ENV_CVRP ? k_rollout_stream<EAMRL_ENV_CVRP>
+          : env == EAMRL_ENV_SDVRP ? k_rollout_stream<EAMRL_ENV_SDVRP> : k_rollout_stream<EAMRL_ENV_PCTSP>;
     else
         k = env == EAMRL_ENV_TSP ? k_decode_step<EAMRL_ENV_TSP>
-          : env == EAMRL_ENV_CVRP ? k_decode_step<EAMRL_ENV_CVRP> : k_decode_step<EAMRL_ENV_SDVRP>;
+          : env == EAMRL_ENV_CVRP ? k_decode_step<EAMRL_ENV_CVRP>
+          : env == EAMRL_ENV_SDVRP ? k_decode_step<EAMRL_ENV_SDVRP> : k_decode_step<EAMRL_ENV_PCTSP>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return EAMRL_E_LAUNCH;
     }
     hipLaunchKernelGGL(k, grid, block, lds, st, a);
-    if (rollout && env != EAMRL_ENV_TSP)
-        hipLaunchKernelGGL(k_rollout_pad_cvrp, dim3((unsigned)((a.R + 255) / 256)), dim3(256), 0, st, a);
+    if (rollout) launch_rollout_pad(env, a, st);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 

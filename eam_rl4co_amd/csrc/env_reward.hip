@@ -3,7 +3,8 @@
 //   k_tsp_step         TSPEnv._step                        rl4co/envs/routing/tsp/env.py:62-88
 //   k_cvrp_step_mask   CVRPEnv._step + get_action_mask     rl4co/envs/routing/cvrp/env.py:68-100,132-144
 //   k_sdvrp_step_mask  SDVRPEnv._step + get_action_mask    rl4co/envs/routing/sdvrp/env.py:58-92,137-146
-//   k_tour_length      get_reward                          rl4co/utils/ops.py:59-95, tsp/env.py:152-159, cvrp/env.py:146-155
+//   k_pctsp_step_mask  PCTSPEnv._step + get_action_mask    rl4co/envs/routing/pctsp/env.py:64-97,156-163
+//   k_tour_length      get_reward (+ PCTSP penalties)                               rl4co/utils/ops.py:59-95, tsp/env.py:152-159, cvrp/env.py:146-155
 //   k_sum_logp         get_log_likelihood                  rl4co/utils/decoding.py:38-64
 //   k_check_*          check_solution_validity             tsp/env.py:161-168, cvrp/env.py:157-185
 //
@@ -181,8 +182,85 @@ __global__ __launch_bounds__(EB) void k_check_sdvrp(const int64_t* actions, cons
     if (twice) atomicAdd(&bad[1], 1);
 }
 
+// PCTSP: one wavefront per row.  STEP = 0: mask only; STEP = 1: collect prize (and penalty), mark visited, then mask.
+// prize / penalty [B][M] with a zero depot slot; pen_tot / penalty may be null together.
+template <int STEP>
+__global__ __launch_bounds__(EB) void k_pctsp_step_mask(uint8_t* visited, float* prize_tot, float* pen_tot,
+                                                        const float* prize, const float* penalty, int64_t* cur,
+                                                        int64_t* istep, const int64_t* action, uint8_t* mask,
+                                                        uint8_t* done, int64_t R, int64_t B, int M)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    uint8_t* vis = visited + r * M;
+    float pt = prize_tot[r];
+    int64_t a = -1;
+    int v0 = vis[0] != 0;
+    if (STEP) {
+        a = action[r];
+        a = a < 0 ? 0 : (a > M - 1 ? M - 1 : a);     // an out-of-range action must not become an out-of-bounds access
+        pt = pt + prize[(r % B) * M + a];
+        if (a == 0) v0 = 1;
+    }
+    int unvisited = 0;
+    for (int n = 1 + lane; n < M; n += 64) {
+        int v = vis[n] != 0;
+        if (STEP && n == a) { v = 1; vis[n] = 1; }
+        mask[r * M + n] = !(v | v0);
+        unvisited |= !v;
+    }
+    const bool unv = __ballot(unvisited != 0) != 0ull;
+    if (lane == 0) {
+        mask[r * M] = !((pt < 1.0f) && unv);
+        if (STEP) {
+            if (a == 0) vis[0] = 1;
+            prize_tot[r] = pt;
+            if (pen_tot) pen_tot[r] = pen_tot[r] + penalty[(r % B) * M + a];
+            const int64_t i = istep[r];
+            done[r] = (i > 0 && a == 0) ? 1 : 0;
+            cur[r] = a;
+            istep[r] = i + 1;
+        }
+    }
+}
+
+// PCTSPEnv.check_solution_validity (pctsp/env.py:189-205): one wavefront per row.  bad[0] += rows with a customer
+// visited twice (or an id out of range), bad[1] += rows that neither collect a prize >= 1 - 1e-5 nor visit everyone.
+__global__ __launch_bounds__(EB) void k_check_pctsp(const int64_t* actions, const float* prize, int64_t R, int64_t B, int M,
+                                                    int T, int32_t* bad)
+{
+    __shared__ uint32_t seen_all[ROWS_PER_BLOCK][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wv;
+    if (r >= R) return;
+    uint32_t* seen = seen_all[wv];
+    for (int i = lane; i < 128; i += 64) seen[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t* act = actions + r * T;
+    int bad_lane = 0, cnt = 0;
+    for (int t = lane; t < T; t += 64) {
+        const int64_t a = act[t];
+        if (a < 0 || a >= M) { bad_lane = 1; continue; }
+        if (a == 0) continue;
+        const uint32_t bit = 1u << (a & 31);
+        if (atomicOr(&seen[a >> 5], bit) & bit) bad_lane = 1;
+        else ++cnt;
+    }
+    const bool invalid = __ballot(bad_lane != 0) != 0ull;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane != 0) return;
+    if (invalid) { atomicAdd(&bad[0], 1); return; }
+    const float* pz = prize + (r % B) * M;
+    float p = 0.0f;
+    for (int t = 0; t < T; ++t) p = p + pz[act[t]];
+    if (!((p >= (float)(1.0 - 1e-5)) || cnt == M - 1)) atomicAdd(&bad[1], 1);
+}
+
+// penalty != null (PCTSP, with_depot): reward = saved penalties - (length + all penalties), pctsp/env.py:165-187;
+// the penalty sums go through the same lane tree as the legs.
 __global__ __launch_bounds__(EB) void k_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R,
-                                                    int64_t B, int M, int T, int with_depot)
+                                                    int64_t B, int M, int T, int with_depot, const float* penalty)
 {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -213,6 +291,24 @@ __global__ __launch_bounds__(EB) void k_tour_length(const float* locs, const int
         }
         const float s = wave_tree_sum(d);
         total = (b0 == 0) ? s : total + s;
+    }
+    if (penalty) {
+        const float* pen = penalty + (r % B) * (int64_t)M;
+        float saved = 0.0f, all = 0.0f;
+        for (int b0 = 0; b0 < T; b0 += 64) {
+            const int t = b0 + lane;
+            int64_t a = t < T ? act[t] : 0;
+            a = a < 0 ? 0 : (a >= M ? M - 1 : a);
+            const float s = wave_tree_sum(t < T ? pen[a] : 0.0f);
+            saved = (b0 == 0) ? s : saved + s;
+        }
+        for (int b0 = 0; b0 < M - 1; b0 += 64) {
+            const int n = b0 + lane;
+            const float s = wave_tree_sum(n < M - 1 ? pen[1 + n] : 0.0f);
+            all = (b0 == 0) ? s : all + s;
+        }
+        if (lane == 0) reward[r] = saved - (total + all);
+        return;
     }
     if (lane == 0) reward[r] = -total;
 }
@@ -368,10 +464,24 @@ int launch_sdvrp(float* rem, float* used, const float* vcap, int64_t* cur, const
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 
-int launch_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R, int64_t B, int M, int T,
-                       int with_depot, hipStream_t st)
+int launch_pctsp(uint8_t* visited, float* prize_tot, float* pen_tot, const float* prize, const float* penalty, int64_t* cur,
+                 int64_t* istep, const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int M,
+                 hipStream_t st)
 {
-    hipLaunchKernelGGL(k_tour_length, dim3(row_blocks(R)), dim3(EB), 0, st, locs, actions, reward, R, B, M, T, with_depot);
+    if (action)
+        hipLaunchKernelGGL(k_pctsp_step_mask<1>, dim3(row_blocks(R)), dim3(EB), 0, st, visited, prize_tot, pen_tot, prize,
+                           penalty, cur, istep, action, mask, done, R, B, M);
+    else
+        hipLaunchKernelGGL(k_pctsp_step_mask<0>, dim3(row_blocks(R)), dim3(EB), 0, st, visited, prize_tot, pen_tot, prize,
+                           penalty, cur, istep, action, mask, done, R, B, M);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R, int64_t B, int M, int T,
+                       int with_depot, hipStream_t st, const float* penalty)
+{
+    hipLaunchKernelGGL(k_tour_length, dim3(row_blocks(R)), dim3(EB), 0, st, locs, actions, reward, R, B, M, T, with_depot,
+                       penalty);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 
@@ -397,6 +507,10 @@ int launch_check_solution(int env, const int64_t* actions, const float* demand, 
                           int N, int T, int32_t* bad, hipStream_t st)
 {
     if (N + 1 > 4096) return EAMRL_E_ARG;
+    if (env == EAMRL_ENV_PCTSP) {       // demand = real_prize [B][N+1]
+        hipLaunchKernelGGL(k_check_pctsp, dim3(row_blocks(R)), dim3(EB), 0, st, actions, demand, R, B, N + 1, T, bad);
+        return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+    }
     if (env == EAMRL_ENV_SDVRP) {
         const size_t lds = (size_t)ROWS_PER_BLOCK * (N + 1) * sizeof(float);
         if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_check_sdvrp),

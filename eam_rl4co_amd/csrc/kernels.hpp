@@ -33,8 +33,11 @@ int launch_cvrp(int step, uint8_t* visited, float* used, const float* vcap, cons
                 const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N, hipStream_t st);
 int launch_sdvrp(float* rem, float* used, const float* vcap, int64_t* cur, const int64_t* action, uint8_t* mask,
                  uint8_t* done, int64_t R, int M, hipStream_t st);
+int launch_pctsp(uint8_t* visited, float* prize_tot, float* pen_tot, const float* prize, const float* penalty, int64_t* cur,
+                 int64_t* istep, const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int M,
+                 hipStream_t st);
 int launch_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R, int64_t B, int M, int T,
-                       int with_depot, hipStream_t st);
+                       int with_depot, hipStream_t st, const float* penalty = nullptr);
 int launch_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, hipStream_t st);
 int launch_check_solution(int env, const int64_t* actions, const float* demand, const float* vcap, int64_t R, int64_t B,
                           int N, int T, int32_t* bad, hipStream_t st);
@@ -42,6 +45,7 @@ int launch_beam_topk(const float* logprobs, const float* parent, int64_t B, int 
                      float* cum, float* step_lp, hipStream_t st);
 int launch_decode_step(int env, const DecArgs& a, hipStream_t st);
 int launch_rollout_stream(int env, const DecArgs& a, hipStream_t st);
+void launch_rollout_pad(int env, const DecArgs& a, hipStream_t st);   // final state of rows that finished early
 int launch_rollout_resident(int env, const DecArgs& a, hipStream_t st);
 bool rollout_resident_supports(int env, const DecArgs& a);
 int launch_ea_tsp(const float* locs, int64_t* pop, float* fitness, int64_t B, int S, int N, int G, double mutation_rate,

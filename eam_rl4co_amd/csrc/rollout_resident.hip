@@ -76,6 +76,7 @@ template <int ENV, int CP, int CR, bool MS>
 __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, int G)
 {
     constexpr bool SD = ENV == EAMRL_ENV_SDVRP;
+    constexpr bool PC = ENV == EAMRL_ENV_PCTSP;     // prize collecting: dem = real_prize, used = collected prize
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using L = ResLds<CP, res_tmax(ENV), res_sdf(ENV)>;
     L& l = *reinterpret_cast<L*>(smem);
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
     // ---- state: mask / visited in LDS; the scalar row state lives in wavefront 0 -----------------------------------------
     if (tid < RNP) {
         l.msk[tid] = (tid < M) ? a.mask[r * M + tid] : 0;
-        l.vis[tid] = (ENV == EAMRL_ENV_CVRP && tid < M) ? a.visited[r * M + tid] : 0;
+        l.vis[tid] = ((ENV == EAMRL_ENV_CVRP || PC) && tid < M) ? a.visited[r * M + tid] : 0;
+        if (PC) l.dem[tid] = (tid < M) ? a.demand[bi * M + tid] : 0.0f;
         if (ENV == EAMRL_ENV_CVRP) l.dem[tid] = (tid < M - 1) ? a.demand[bi * (M - 1) + tid] : 0.0f;
         if (SD) l.dem[tid] = (tid < M) ? a.rem[r * M + tid] : 0.0f;
     }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
 
     constexpr int fw = 0;      // the wavefront that runs the serial "finish" section of a step
 
-    int64_t first = 0, cur = 0, istep = 1;
+    int64_t first = 0, cur = 0, istep = 1, i0 = 0;
     float used = 0.0f, vcap = 0.0f;
     int count = 0;
     float gq[2] = {0.f, 0.f}, cv[2] = {0.f, 0.f}, p1f[2] = {0.f, 0.f}, mydem[2] = {0.f, 0.f};
@@ -171,8 +173,10 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         cur = a.cur[r];
         if (ENV == EAMRL_ENV_TSP) { first = a.first[r]; istep = a.istep[r]; }
         else { used = a.used[r]; vcap = a.vcap[r]; }
-        // remaining feasible (TSP) / visited (CVRP) node count, kept incrementally (== the reference's mask.sum / visited.sum)
-        const int c0 = (ENV == EAMRL_ENV_TSP) ? (in0 && l.msk[n0] != 0) : (in0 && l.vis[n0] != 0);
+        if (PC) { istep = a.istep[r]; i0 = istep; }
+        // remaining feasible (TSP) / visited (CVRP; PCTSP: visited customers) node count, kept incrementally
+        // (== the reference's mask.sum / visited.sum)
+        const int c0 = (ENV == EAMRL_ENV_TSP) ? (in0 && l.msk[n0] != 0) : (in0 && l.vis[n0] != 0 && !(PC && n0 == 0));
         const int c1 = (ENV == EAMRL_ENV_TSP) ? (in1 && l.msk[n1] != 0) : (in1 && l.vis[n1] != 0);
         count = __builtin_popcountll(__ballot(c0)) + __builtin_popcountll(__ballot(c1));
 #pragma unroll
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             if (ENV == EAMRL_ENV_CVRP && nn >= 1 && nn < M) mydem[k] = l.dem[nn - 1];
             float ctx;
             if (ENV == EAMRL_ENV_TSP) ctx = (istep == 0) ? cv[k] : p1f[k] + Plds[cur * RE + e];
+            else if (PC) ctx = fma_(cv[k], (vcap - used) < 0.0f ? 0.0f : (vcap - used), Plds[cur * RE + e]);
             else ctx = fma_(cv[k], vcap - used, Plds[cur * RE + e]);
             l.q[e] = ctx + gq[k];
         }
@@ -398,6 +403,26 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                 if (lane == 0) { l.msk[sel] = 0; l.done = done; }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) l.q[lane + 64 * k] = (p1f[k] + Plds[cur * RE + lane + 64 * k]) + gq[k];
+            } else if (PC) {
+                // PCTSPEnv._step + get_action_mask (pctsp/env.py:64-97,156-163)
+                used = used + l.dem[sel];
+                done = (istep > 0) && (sel == 0);
+                cur = sel;
+                istep += 1;
+                count += (sel != 0 && l.vis[sel] == 0);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) { l.vis[sel] = 1; l.done = done; }
+                __builtin_amdgcn_wave_barrier();
+                const float state = (vcap - used) < 0.0f ? 0.0f : (vcap - used);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) l.q[lane + 64 * k] = fma_(cv[k], state, Plds[cur * RE + lane + 64 * k]) + gq[k];
+                const int v0 = l.vis[0] != 0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int nn = lane + 64 * k;
+                    if (nn >= 1 && nn < M) l.msk[nn] = !((l.vis[nn] != 0) | v0);
+                }
+                if (lane == 0) l.msk[0] = !((used < 1.0f) && (count < M - 1));
             } else if (SD) {
                 // SDVRPEnv._step + get_action_mask (sdvrp/env.py:58-92,137-146): deliver min(remaining demand, free capacity)
                 const float selrem = l.dem[sel];
@@ -478,7 +503,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
     }
     if (tid < M) {
         a.mask[r * M + tid] = l.msk[tid];
-        if (ENV == EAMRL_ENV_CVRP) a.visited[r * M + tid] = l.vis[tid];
+        if (ENV == EAMRL_ENV_CVRP || PC) a.visited[r * M + tid] = l.vis[tid];
         if (SD) a.rem[r * M + tid] = l.dem[tid];
     }
     if (wv == fw && lane == 0) {
@@ -486,23 +511,12 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         a.done[r] = done ? 1 : 0;
         if (ENV == EAMRL_ENV_TSP) { a.first[r] = first; a.istep[r] = istep; }
         else a.used[r] = used;
+        if (PC) a.istep[r] = i0;          // launch_rollout_pad adds the batch's step count
         atomicMax(a.steps_out, t);
         if (!done) st_flags |= EAMRL_ST_STEP_OVERRUN;
         if (st_flags) atomicOr(a.status, st_flags);
     }
     if (MS) __syncthreads();      // the next start re-initialises the row state in LDS
-    }
-}
-
-__global__ void k_rollout_pad_cvrp_res(DecArgs a)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.R) return;
-    const int T = *a.steps_out;
-    if (T <= 0 || !a.done[r]) return;
-    if (a.cur[r] != 0 && a.action[r * a.t_max + (T - 1)] == 0) {   // see k_rollout_pad_cvrp
-        a.cur[r] = 0;
-        a.used[r] = 0.0f;
     }
 }
 
@@ -533,8 +547,7 @@ int launch_cp(const DecArgs& a, hipStream_t st)
         rc = launch_ms<ENV, CP, CR, false>(a, 1, 1, st);
     }
     if (rc) return rc;
-    if (ENV != EAMRL_ENV_TSP)
-        hipLaunchKernelGGL(k_rollout_pad_cvrp_res, dim3((unsigned)((a.R + 255) / 256)), dim3(256), 0, st, a);
+    launch_rollout_pad(ENV, a, st);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 
@@ -573,7 +586,8 @@ bool rollout_resident_supports(int env, const DecArgs& a)
 int launch_rollout_resident(int env, const DecArgs& a, hipStream_t st)
 {
     return env == EAMRL_ENV_TSP ? launch_env<EAMRL_ENV_TSP>(a, st)
-         : env == EAMRL_ENV_CVRP ? launch_env<EAMRL_ENV_CVRP>(a, st) : launch_env<EAMRL_ENV_SDVRP>(a, st);
+         : env == EAMRL_ENV_CVRP ? launch_env<EAMRL_ENV_CVRP>(a, st)
+         : env == EAMRL_ENV_SDVRP ? launch_env<EAMRL_ENV_SDVRP>(a, st) : launch_env<EAMRL_ENV_PCTSP>(a, st);
 }
 
 }  // namespace eamrl

@@ -114,6 +114,48 @@ class CVRPGenerator(Generator):
                           batch_size=batch_size)
 
 
+# Kool et al. (2019) expected tour lengths used to scale the PCTSP penalties (pctsp/generator.py:14)
+MAX_LENGTHS = {20: 2.0, 50: 3.0, 100: 4.0}
+
+
+class PCTSPGenerator(Generator):
+    """locs, depot, penalty ~ U[0, max_penalty), deterministic_prize ~ U[0, 4/num_loc), stochastic_prize
+    (pctsp/generator.py:17-148).  The draws come in the reference's order from torch's global generator."""
+
+    def __init__(self, num_loc: int = 20, min_loc: float = 0.0, max_loc: float = 1.0, loc_distribution="uniform",
+                 depot_distribution=None, penalty_factor: float = 3.0, prize_required: float = 1.0, **kwargs):
+        self.num_loc, self.min_loc, self.max_loc = num_loc, min_loc, max_loc
+        self.penalty_fctor, self.prize_required = penalty_factor, prize_required      # (sic: the reference's attribute name)
+        self.loc_sampler = kwargs.get("loc_sampler") or get_sampler("loc", loc_distribution, min_loc, max_loc, **kwargs)
+        self.depot_sampler = kwargs.get("depot_sampler") or (
+            get_sampler("depot", depot_distribution, min_loc, max_loc, **kwargs) if depot_distribution is not None else None)
+        self.deterministic_prize_sampler = get_sampler("deterministric_prize", "uniform", 0.0, 4.0 / self.num_loc)
+        self.stochastic_prize_sampler = get_sampler("stochastic_prize", "uniform", 0.0, 2.0)
+        self.max_penalty = kwargs.get("max_penalty", None)
+        if self.max_penalty is None:
+            self.max_penalty = MAX_LENGTHS.get(num_loc, None)
+        if self.max_penalty is None:
+            closest = min(MAX_LENGTHS, key=lambda x: abs(x - num_loc))
+            self.max_penalty = MAX_LENGTHS[closest]
+            log.warning("The max penalty for %d locations is not defined. Using the closest max penalty: %s with %d "
+                        "locations.", num_loc, self.max_penalty, closest)
+        self.max_penalty *= penalty_factor / self.num_loc
+        self.penalty_sampler = get_sampler("penalty", "uniform", 0.0, self.max_penalty)
+
+    def _generate(self, batch_size):
+        if self.depot_sampler is not None:
+            depot = self.depot_sampler.sample((*batch_size, 2))
+            locs = self.loc_sampler.sample((*batch_size, self.num_loc, 2))
+        else:
+            pts = self.loc_sampler.sample((*batch_size, self.num_loc + 1, 2))
+            depot, locs = pts[..., 0, :], pts[..., 1:, :]
+        penalty = self.penalty_sampler.sample((*batch_size, self.num_loc))
+        deterministic_prize = self.deterministic_prize_sampler.sample((*batch_size, self.num_loc))
+        stochastic_prize = self.stochastic_prize_sampler.sample((*batch_size, self.num_loc)) * deterministic_prize
+        return TensorDict({"locs": locs, "depot": depot, "penalty": penalty, "deterministic_prize": deterministic_prize,
+                           "stochastic_prize": stochastic_prize}, batch_size=batch_size)
+
+
 # --------------------------------------------------------------------------------------------------------
 class TensorDictDataset(torch.utils.data.Dataset):
     """List-of-dicts dataset with the reference's collate contract (rl4co/data/dataset.py:43-75)."""
@@ -221,13 +263,13 @@ class RL4COEnvBase:
 
     def get_num_starts(self, td):
         n = td["action_mask"].shape[-1]
-        return n - 1 if self.name in ("cvrp", "sdvrp") else n          # depot cannot be a start node (utils/ops.py:120-130)
+        return n - 1 if self.name in ("cvrp", "sdvrp", "pctsp") else n          # depot cannot be a start node (utils/ops.py:120-130)
 
     def select_start_nodes(self, td, num_starts):
         """POMO start nodes: flat row j = s*B + b starts at node s (+1 with a depot) (utils/ops.py:133-169)."""
         num_loc = getattr(self.generator, "num_loc", 0xFFFFFFFF)
         sel = torch.arange(num_starts, device=td.device).repeat_interleave(td.shape[0]) % num_loc
-        return sel + 1 if self.name in ("cvrp", "sdvrp") else sel
+        return sel + 1 if self.name in ("cvrp", "sdvrp", "pctsp") else sel
 
     def check_solution_validity(self, td, actions) -> None:
         raise NotImplementedError
@@ -474,12 +516,82 @@ class SDVRPEnv(CVRPEnv):
         assert bad[0] == 0, "All demand must be satisfied"
 
 
-ENV_REGISTRY = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv}
+class PCTSPEnv(RL4COEnvBase):
+    """Prize Collecting TSP (rl4co/envs/routing/pctsp/env.py:21-260): visit customers until the collected prize
+    reaches 1 (or everyone is visited), then return to the depot; reward = saved penalties - (length + all penalties)."""
+
+    name = "pctsp"
+    _stochastic = False
+
+    def __init__(self, generator: PCTSPGenerator = None, generator_params: dict = {}, **kwargs):
+        super().__init__(**kwargs)
+        self.generator = generator if generator is not None else PCTSPGenerator(**generator_params)
+
+    @property
+    def stochastic(self):
+        return self._stochastic
+
+    def _reset(self, td=None, batch_size=None):
+        dev = td.device
+        real_prize = td["stochastic_prize"] if self.stochastic else td["deterministic_prize"]
+        penalty = td["penalty"]
+        n = penalty.shape[-1]
+        zero = torch.zeros_like(penalty[..., :1])
+        visited = torch.zeros(*batch_size, n + 1, dtype=torch.bool, device=dev)
+        out = TensorDict({
+            "locs": torch.cat((td["depot"][..., None, :], td["locs"]), -2),
+            "current_node": torch.zeros(*batch_size, dtype=torch.int64, device=dev),
+            "expected_prize": td["deterministic_prize"],
+            "real_prize": torch.cat((zero, real_prize), -1),
+            "penalty": torch.cat((zero, penalty), -1),
+            "cur_total_prize": torch.zeros(*batch_size, dtype=torch.float32, device=dev),
+            "cur_total_penalty": penalty.sum(-1),          # all penalties while nothing is visited
+            "visited": visited,
+            "prize_required": torch.full((*batch_size,), self.generator.prize_required, dtype=torch.float32, device=dev),
+            "i": torch.zeros(*batch_size, dtype=torch.int64, device=dev),
+        }, batch_size=batch_size)
+        # reset-state mask in closed form (nothing visited, no prize yet): customers free, depot closed (env.py:156-163)
+        mask = torch.ones(*batch_size, n + 1, dtype=torch.bool, device=dev)
+        mask[..., 0] = not (n > 0)
+        out.set("action_mask", mask)
+        return out
+
+    def _step(self, td):
+        mask = td["action_mask"]
+        if not mask.is_contiguous():
+            mask = mask.contiguous()
+        done = _flat(td["done"], torch.bool)
+        ops.pctsp_step_mask_(td["visited"], _flat(td["cur_total_prize"], torch.float32),
+                             _flat(td["cur_total_penalty"], torch.float32), td["real_prize"].contiguous(),
+                             td["penalty"].contiguous(), _flat(td["current_node"], torch.int64),
+                             _flat(td["i"], torch.int64), td["action"].reshape(-1).contiguous(), mask, done)
+        td.update({"action_mask": mask, "done": done, "reward": torch.zeros_like(done)})
+        return td
+
+    def get_action_mask(self, td):
+        mask = torch.empty(td["visited"].shape, dtype=torch.bool, device=td["visited"].device)
+        ops.pctsp_step_mask_(td["visited"], _flat(td["cur_total_prize"], torch.float32), None, None, None, None, None, None,
+                             mask)
+        return mask
+
+    def _get_reward(self, td, actions):
+        if actions.size(-1) == 1:       # all tours return to the depot at once (env.py:168-171)
+            assert bool((actions == 0).all()), "If all length 1 tours, they should be zero"
+            return torch.zeros(actions.size(0), dtype=torch.float32, device=actions.device)
+        return ops.pctsp_reward(td["locs"].contiguous(), td["penalty"].contiguous(), actions.contiguous())
+
+    def check_solution_validity(self, td, actions) -> None:
+        bad = ops.check_solution("pctsp", actions.contiguous(), td["real_prize"].contiguous()).tolist()
+        assert bad[0] == 0, "Duplicates"
+        assert bad[1] == 0, "Total prize does not satisfy min total prize"
+
+
+ENV_REGISTRY = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv}
 
 
 def get_env(env_name: str, *args, **kwargs) -> RL4COEnvBase:
     cls = ENV_REGISTRY.get(env_name)
     if cls is None:
         raise ValueError(f"Unknown environment {env_name}. Available environments: {list(ENV_REGISTRY)} "
-                         "(only the TSP / CVRP / SDVRP rollout path is built for MI355X)")
+                         "(only the TSP / CVRP / SDVRP / PCTSP rollout path is built for MI355X)")
     return cls(*args, **kwargs)

@@ -8,11 +8,11 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ENV_CVRP, ENV_SDVRP, ENV_TSP, EVALUATE, GREEDY, NORM_BATCH_EVAL, NORM_INSTANCE, SAMPLE,  # noqa: F401
+from ._lib import (ENV_CVRP, ENV_PCTSP, ENV_SDVRP, ENV_TSP, EVALUATE, GREEDY, NORM_BATCH_EVAL, NORM_INSTANCE, SAMPLE,  # noqa: F401
                    ST_INFEASIBLE, ST_NAN_LOGITS, ST_STEP_OVERRUN)
 
 MODES = {"greedy": GREEDY, "sampling": SAMPLE, "evaluate": EVALUATE}
-ENVS = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP}
+ENVS = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP, "pctsp": ENV_PCTSP}
 
 
 def _need_gpu(t: torch.Tensor, name: str):
@@ -230,6 +230,48 @@ def sdvrp_step_mask_(rem, used, vcap, cur, action, mask, done=None):
     return mask
 
 
+def pctsp_step_mask_(visited, prize_tot, pen_tot, prize, penalty, cur, istep, action, mask, done=None):
+    """PCTSPEnv._step + get_action_mask in place (pctsp/env.py:64-97,156-163); action None: mask only."""
+    lib = _lib.load()
+    R, M = visited.shape
+    B = R if prize is None else prize.shape[0]
+    if visited.dtype not in (torch.bool, torch.uint8):
+        raise TypeError("visited must be bool or uint8")
+    _chk(_bytes(visited), "visited", torch.uint8, (R, M))
+    _chk(prize_tot, "cur_total_prize", torch.float32, (R,))
+    _chk(mask, "action_mask", torch.bool, (R, M))
+    if action is not None:
+        _chk(prize, "real_prize", torch.float32, (B, M))
+        _chk(cur, "current_node", torch.int64, (R,))
+        _chk(istep, "i", torch.int64, (R,))
+        _chk(action, "action", torch.int64, (R,))
+        _chk(done, "done", torch.bool, (R,))
+        if pen_tot is not None:
+            _chk(pen_tot, "cur_total_penalty", torch.float32, (R,))
+            _chk(penalty, "penalty", torch.float32, (B, M))
+    _lib.check(lib.eamrl_pctsp_step_mask(_ptr(_bytes(visited)), _ptr(prize_tot), _ptr(pen_tot), _ptr(prize), _ptr(penalty),
+                                         _ptr(cur), _ptr(istep), _ptr(action), _ptr(_bytes(mask)),
+                                         _ptr(_bytes(done)) if done is not None else None, R, B, M, _stream(mask)),
+               "eamrl_pctsp_step_mask")
+    return mask
+
+
+def pctsp_reward(locs, penalty, actions):
+    """PCTSPEnv._get_reward (pctsp/env.py:165-187): saved penalties - (tour length + all penalties)."""
+    lib = _lib.load()
+    _chk(locs, "locs", torch.float32)
+    B, M, _ = locs.shape
+    _chk(penalty, "penalty", torch.float32, (B, M))
+    _chk(actions, "actions", torch.int64)
+    R, T = actions.shape
+    if R % B:
+        raise ValueError("actions rows must be a multiple of the number of instances")
+    out = torch.empty(R, dtype=torch.float32, device=locs.device)
+    _lib.check(lib.eamrl_pctsp_reward(_ptr(locs), _ptr(penalty), _ptr(actions), _ptr(out), R, B, M, T, _stream(locs)),
+               "eamrl_pctsp_reward")
+    return out
+
+
 def tour_length_reward(locs, actions, with_depot):
     lib = _lib.load()
     _chk(locs, "locs", torch.float32)
@@ -265,6 +307,11 @@ def check_solution(env_name, actions, demand=None, vcap=None, num_loc=None):
         N, B = (T if num_loc is None else num_loc), R
         _lib.check(lib.eamrl_check_solution(ENV_TSP, _ptr(actions), None, None, R, B, N, T, _ptr(bad), _stream(actions)),
                    "eamrl_check_solution")
+    elif env_name == "pctsp":       # demand = real_prize [B, N+1]
+        _chk(demand, "real_prize", torch.float32)
+        B, M = demand.shape
+        _lib.check(lib.eamrl_check_solution(ENV_PCTSP, _ptr(actions), _ptr(demand), None, R, B, M - 1, T, _ptr(bad),
+                                            _stream(actions)), "eamrl_check_solution")
     else:
         _chk(demand, "demand", torch.float32)
         B, N = demand.shape
@@ -434,10 +481,10 @@ class RolloutState:
         self.mask = torch.ones(R, M, dtype=torch.bool, device=device)
         self.used = self.vcap = self.visited = self.rem = None
         self.demand = demand
-        if env_name in ("cvrp", "sdvrp"):
-            self.used = torch.zeros(R, dtype=torch.float32, device=device)
-            self.vcap = torch.ones(R, dtype=torch.float32, device=device)
-        if env_name == "cvrp":
+        if env_name in ("cvrp", "sdvrp", "pctsp"):
+            self.used = torch.zeros(R, dtype=torch.float32, device=device)     # pctsp: cur_total_prize
+            self.vcap = torch.ones(R, dtype=torch.float32, device=device)      # pctsp: prize_required
+        if env_name in ("cvrp", "pctsp"):
             self.visited = torch.zeros(R, M, dtype=torch.uint8, device=device)
         if env_name == "sdvrp":
             self.rem = torch.zeros(R, M, dtype=torch.float32, device=device)   # demand_with_depot
@@ -454,7 +501,8 @@ class RolloutState:
         s = _lib.State()
         s.first, s.cur, s.istep = _ptr(self.first), _ptr(self.cur), _ptr(self.istep)
         s.used, s.vcap, s.demand = _ptr(self.used), _ptr(self.vcap), _ptr(self.demand)
-        s.mask, s.visited, s.done = _ptr(_bytes(self.mask)), _ptr(self.visited), _ptr(_bytes(self.done))
+        s.mask, s.done = _ptr(_bytes(self.mask)), _ptr(_bytes(self.done))
+        s.visited = _ptr(None if self.visited is None else _bytes(self.visited))
         s.rem = _ptr(getattr(self, "rem", None))
         return s
 
@@ -475,6 +523,10 @@ def _validate_state(st: RolloutState, cache: DecodeCache):
         if st.env_name == "sdvrp":
             _chk(st.rem, "demand_with_depot", torch.float32, (R, M))
             _chk(cache.dyn, "dynamic embedding vectors", torch.float32, (3, cache.E))
+        elif st.env_name == "pctsp":
+            _chk(_bytes(st.visited), "visited", torch.uint8, (R, M))
+            _chk(st.demand, "real_prize", torch.float32, (cache.B, M))
+            _chk(st.istep, "i", torch.int64, (R,))
         else:
             _chk(st.visited, "visited", torch.uint8, (R, M))
             _chk(st.demand, "demand", torch.float32, (cache.B, M - 1))
@@ -512,7 +564,7 @@ def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, giv
     _validate_state(st, cache)
     R, M, dev = st.R, st.M, st.mask.device
     if t_max is None:
-        t_max = {"tsp": M, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1}[st.env_name]
+        t_max = {"tsp": M, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1, "pctsp": M + 1}[st.env_name]
     t_given = 0
     if noise is not None:
         _chk(noise, "noise", torch.float32)

@@ -54,6 +54,22 @@ class VRPInitEmbedding(nn.Module):
         return torch.cat((depot, cust), 1)
 
 
+class PCTSPInitEmbedding(nn.Module):
+    """x, y, expected prize, penalty per customer; depot embedded separately (nn/env_embeddings/init.py:227-257)."""
+
+    def __init__(self, embed_dim, linear_bias=True):
+        super().__init__()
+        self.init_embed = nn.Linear(4, embed_dim, linear_bias)
+        self.init_embed_depot = nn.Linear(2, embed_dim, linear_bias)
+
+    def forward(self, td):
+        locs = td["locs"]
+        depot = ops.linear(locs[:, :1, :].contiguous(), self.init_embed_depot.weight, self.init_embed_depot.bias)
+        feat = torch.cat((locs[:, 1:, :], td["expected_prize"][..., None], td["penalty"][..., 1:, None]), -1)
+        cust = ops.linear(feat, self.init_embed.weight, self.init_embed.bias)
+        return torch.cat((depot, cust), 1)
+
+
 class _Holder(nn.Module):
     """`.module` wrapper so that parameter names match the reference's SkipConnection(...)."""
 
@@ -156,8 +172,8 @@ class AttentionModelEncoder(nn.Module):
             raise NotImplementedError("moe_kwargs / sdpa_fn injection is outside the MI355X rollout path")
         self.env_name = env_name
         if init_embedding is None:
-            init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding,
-                              "sdvrp": VRPInitEmbedding}[env_name](embed_dim)
+            init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding, "sdvrp": VRPInitEmbedding,
+                              "pctsp": PCTSPInitEmbedding}[env_name](embed_dim)
         self.init_embedding = init_embedding
         self.net = GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden) \
             if net is None else net
@@ -287,6 +303,8 @@ def _env_step_(st: ops.RolloutState, action):
         ops.tsp_step_(st.mask, st.first, st.cur, st.istep, action, st.done)
     elif st.env_name == "cvrp":
         ops.cvrp_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, action, st.mask, st.done)
+    elif st.env_name == "pctsp":
+        ops.pctsp_step_mask_(st.visited, st.used, None, st.demand, None, st.cur, st.istep, action, st.mask, st.done)
     else:
         ops.sdvrp_step_mask_(st.rem, st.used, st.vcap, st.cur, action, st.mask, st.done)
 
@@ -294,7 +312,7 @@ def _env_step_(st: ops.RolloutState, action):
 def _max_decode_steps(env_name, M, npre=0):
     """TSP: one step per remaining node; CVRP: every customer visit is followed by at most one depot visit; SDVRP: as
     CVRP plus at most one split delivery per trip."""
-    return {"tsp": M - npre, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1}[env_name]
+    return {"tsp": M - npre, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1, "pctsp": M + 1}[env_name]
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -335,6 +353,12 @@ def state_from_td(env_name, td, num_starts: int = 0, copy: bool = True) -> ops.R
     if env_name == "tsp":
         st.first = rep(td["first_node"], torch.int64)
         st.istep = rep(td["i"], torch.int64)
+    elif env_name == "pctsp":       # used = collected prize, vcap = required prize, demand = prize per node (depot slot 0)
+        st.used = rep(td["cur_total_prize"], torch.float32)
+        st.vcap = rep(td["prize_required"], torch.float32)
+        st.demand = td["real_prize"].contiguous()
+        st.visited = rep(td["visited"], torch.bool)
+        st.istep = rep(td["i"], torch.int64)
     else:
         st.used = rep(td["used_capacity"], torch.float32)
         st.vcap = rep(td["vehicle_capacity"], torch.float32)
@@ -352,6 +376,10 @@ def state_to_td(env_name, st: ops.RolloutState, td, locs_rows=None):
     out = {"action_mask": st.mask, "done": st.done, "reward": torch.zeros_like(st.done)}
     if env_name == "tsp":
         out.update({"first_node": st.first, "current_node": st.cur, "i": st.istep.reshape(R, 1)})
+    elif env_name == "pctsp":
+        # cur_total_penalty is bookkeeping of env.step only (no decision reads it): the fused rollout does not carry it
+        out.update({"current_node": st.cur, "cur_total_prize": st.used, "prize_required": st.vcap, "visited": st.visited,
+                    "i": st.istep})
     else:
         out.update({"current_node": st.cur.reshape(R, 1), "used_capacity": st.used.reshape(R, 1),
                     "vehicle_capacity": st.vcap.reshape(R, 1)})
@@ -387,8 +415,9 @@ class AttentionModelPolicy(nn.Module):
             log.error("Found %d unused kwargs: %s", len(unused_kwargs), unused_kwargs)
         if isinstance(env_name, RL4COEnvBase):
             env_name = env_name.name
-        if env_name not in ("tsp", "cvrp", "sdvrp"):
-            raise NotImplementedError(f"env_name={env_name!r}: the MI355X rollout path covers 'tsp', 'cvrp' and 'sdvrp'")
+        if env_name not in ("tsp", "cvrp", "sdvrp", "pctsp"):
+            raise NotImplementedError(f"env_name={env_name!r}: the MI355X rollout path covers 'tsp', 'cvrp', 'sdvrp' "
+                                      "and 'pctsp'")
         if moe_kwargs not in (None, {"encoder": None, "decoder": None}) or any(
                 x is not None for x in (sdpa_fn, sdpa_fn_encoder, sdpa_fn_decoder, encoder_network)):
             raise NotImplementedError("MoE / sdpa_fn / encoder_network injection is outside the MI355X rollout path")
@@ -518,15 +547,20 @@ class AttentionModelPolicy(nn.Module):
         # x + 0 is exact in the lane tree), nor the log-likelihood sum, nor validity.
         actions_pad = torch.cat(pre_actions + [acts], 1) if pre_actions else acts
         logp_pad = torch.cat(pre_logps + [lps], 1) if pre_logps else lps
-        native_env = type(env).__name__ in ("TSPEnv", "CVRPEnv", "SDVRPEnv") and type(env).__module__ == RL4COEnvBase.__module__
+        native_env = type(env).__name__ in ("TSPEnv", "CVRPEnv", "SDVRPEnv", "PCTSPEnv") and type(env).__module__ == RL4COEnvBase.__module__
         fast = info is not None and native_env and not select_best
         reward_pad = ll_pad = bad = None
         if fast:
             locs = td["locs"].contiguous()
             if calc_reward:
-                reward_pad = ops.tour_length_reward(locs, actions_pad, with_depot=(self.env_name != "tsp"))
+                if self.env_name == "pctsp":        # depot padding: zero-length legs and zero penalties, exact
+                    reward_pad = ops.pctsp_reward(locs, td["penalty"].contiguous(), actions_pad)
+                else:
+                    reward_pad = ops.tour_length_reward(locs, actions_pad, with_depot=(self.env_name != "tsp"))
                 if env.check_solution and self.env_name != "sdvrp":   # sdvrp: replayed on the exact slice in _finish
                     bad = (ops.check_solution("tsp", actions_pad) if self.env_name == "tsp" else
+                           ops.check_solution("pctsp", actions_pad, td["real_prize"].contiguous())
+                           if self.env_name == "pctsp" else
                            ops.check_solution("cvrp", actions_pad, td["demand"].contiguous(), st.vcap))
             if return_sum_log_likelihood and "mask" not in td.keys():
                 ll_pad = ops.sum_logp(logp_pad)
@@ -572,6 +606,9 @@ class AttentionModelPolicy(nn.Module):
                         # node 0 is a real city in TSP, so zero padding cannot be checked in place: the (rare)
                         # short episode is re-checked on the exact slice
                         env.check_solution_validity(td_out, actions_out.contiguous())
+                    elif self.env_name == "pctsp":
+                        assert bad_counts[0] == 0, "Duplicates"
+                        assert bad_counts[1] == 0, "Total prize does not satisfy min total prize"
                     else:
                         assert bad_counts[0] == 0, "Invalid tour"
                         assert bad_counts[1] == 0, "Used more than capacity"

@@ -35,6 +35,7 @@ extern "C" {
 #define EAMRL_ENV_TSP 0
 #define EAMRL_ENV_CVRP 1
 #define EAMRL_ENV_SDVRP 2 /* split delivery: CVRP instances, customers may be served in several visits */
+#define EAMRL_ENV_PCTSP 3 /* prize collecting TSP: return to the depot once the collected prize reaches 1 */
 /* selection modes  [rl4co/utils/decoding.py:430-465] */
 #define EAMRL_GREEDY 0
 #define EAMRL_SAMPLE 1   /* argmax(p / noise), noise ~ Exp(1) supplied by the caller (== torch.multinomial) */
@@ -86,6 +87,15 @@ int eamrl_cvrp_step_mask(uint8_t* visited, float* used, const float* vcap, const
  * The vehicle delivers min(rem[action], vcap - used); a row is done when no remaining demand is > 0. */
 int eamrl_sdvrp_step_mask(float* rem, float* used, const float* vcap, int64_t* cur, const int64_t* action,
                           uint8_t* mask, uint8_t* done, int64_t R, int M, void* stream);
+
+/* PCTSPEnv._step + get_action_mask  [rl4co/envs/routing/pctsp/env.py:64-97,156-163].  In place.
+ * visited [R][M] u8, prize_tot [R] f32 (cur_total_prize), pen_tot [R] f32 (cur_total_penalty) or NULL, prize / penalty
+ * [B][M] f32 with a zero depot slot (penalty may be NULL with pen_tot), cur / istep [R] i64, mask [R][M] u8, done [R] u8.
+ * action == NULL: only the mask is recomputed.  A customer is feasible until visited and until the depot was visited;
+ * the depot is infeasible while prize_tot < 1 and a customer is unvisited; done = (istep > 0 and action == depot). */
+int eamrl_pctsp_step_mask(uint8_t* visited, float* prize_tot, float* pen_tot, const float* prize, const float* penalty,
+                          int64_t* cur, int64_t* istep, const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R,
+                          int64_t B, int M, void* stream);
 
 /* ---- one-shot encoder + cache ------------------------------------------------------------------- */
 
@@ -149,9 +159,9 @@ typedef struct eamrl_state {
     int64_t* first;    /* [R] TSP first_node */
     int64_t* cur;      /* [R] current_node */
     int64_t* istep;    /* [R] TSP i */
-    float* used;       /* [R] CVRP used_capacity */
-    const float* vcap; /* [R] CVRP vehicle_capacity */
-    const float* demand; /* [B][N] CVRP demand */
+    float* used;       /* [R] CVRP / SDVRP used_capacity; PCTSP cur_total_prize */
+    const float* vcap; /* [R] CVRP / SDVRP vehicle_capacity; PCTSP prize_required */
+    const float* demand; /* [B][N] CVRP demand; PCTSP: [B][M] real_prize with a zero depot slot */
     uint8_t* mask;     /* [R][M] action_mask (1 = feasible) */
     uint8_t* visited;  /* [R][M] CVRP visited */
     uint8_t* done;     /* [R] */
@@ -190,11 +200,18 @@ int eamrl_am_rollout(int env, const eamrl_cache* cache_host, const eamrl_state* 
 int eamrl_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R, int64_t B, int M, int T,
                       int with_depot, void* stream);
 
+/* PCTSPEnv._get_reward  [pctsp/env.py:165-187]: reward[r] = sum_t penalty[a_t] - (tour length from / to the depot +
+ * sum of all penalties).  locs [B][M][2], penalty [B][M] (zero depot slot), actions [R][T]. */
+int eamrl_pctsp_reward(const float* locs, const float* penalty, const int64_t* actions, float* reward, int64_t R, int64_t B,
+                       int M, int T, void* stream);
+
 /* out[r] = sum_t logp[r][t], sequential  (get_log_likelihood, utils/decoding.py:38-64) */
 int eamrl_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, void* stream);
 
 /* check_solution_validity on the device: bad[0] += invalid tours, bad[1] += over-capacity rows
  * [tsp/env.py:161-168; cvrp/env.py:157-185].  bad: device int32[2], caller zeroes.
+ * EAMRL_ENV_PCTSP [pctsp/env.py:189-205]: demand = real_prize [B][N+1], vcap unused; bad[0] += rows with a customer
+ * visited twice, bad[1] += rows that neither collect a total prize >= 1 - 1e-5 nor visit every customer.
  * EAMRL_ENV_SDVRP replays the deliveries [sdvrp/env.py:148-171]: bad[0] += rows with demand left at the end,
  * bad[1] += rows that visit the depot twice in a row while any entry of the replay's demand vector is nonzero. */
 int eamrl_check_solution(int env, const int64_t* actions, const float* demand, const float* vcap, int64_t R,

@@ -59,6 +59,11 @@ def make_td(env_name, locs, demand=None):
     env = ea.get_env(env_name, generator_params=dict(num_loc=locs.shape[1] - (env_name != "tsp")))
     if env_name == "tsp":
         td = ea.TensorDict({"locs": torch.from_numpy(locs)}, batch_size=[locs.shape[0]])
+    elif env_name == "pctsp":       # demand: the dict of prize tensors (tests/_util.py instance_of)
+        td = ea.TensorDict({"locs": torch.from_numpy(locs[:, 1:]), "depot": torch.from_numpy(locs[:, 0]),
+                            "deterministic_prize": torch.from_numpy(demand["expected_prize"]),
+                            "stochastic_prize": torch.from_numpy(demand["expected_prize"]),
+                            "penalty": torch.from_numpy(demand["penalty"][:, 1:])}, batch_size=[locs.shape[0]])
     else:
         td = ea.TensorDict({"locs": torch.from_numpy(locs[:, 1:]), "depot": torch.from_numpy(locs[:, 0]),
                             "demand": torch.from_numpy(demand)}, batch_size=[locs.shape[0]])
@@ -202,7 +207,8 @@ def test_encoder_and_cache_bit_exact(oracle, name):
 
 STEP_CASES = ["tsp20_greedy", "tsp100_greedy", "cvrp20_greedy", "cvrp100_greedy", "cvrp100_sampling",
               "tsp20_multistart_greedy", "cvrp20_multistart_greedy", "pomo_tsp20_multistart_sampling",
-              "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy"]
+              "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy",
+              "pctsp20_greedy", "pctsp20_sampling", "pctsp100_sampling", "pctsp20_multistart_greedy"]
 
 
 @pytest.mark.parametrize("name", STEP_CASES)
@@ -257,6 +263,10 @@ def test_decode_step_api_bit_exact_every_step(oracle, name):
         elif env_name == "cvrp":
             assert_bits_equal(st.visited, ost.visited, "visited")
             assert_bits_equal(st.used, ost.used, "used")
+        elif env_name == "pctsp":
+            assert_bits_equal(st.visited.to(torch.uint8), ost.visited, "visited")
+            assert_bits_equal(st.used, ost.used, "collected prize")
+            assert_bits_equal(st.istep, ost.istep, "i")
         else:
             assert_bits_equal(st.rem, ost.rem, "remaining demand")
             assert_bits_equal(st.used, ost.used, "used")
@@ -272,7 +282,8 @@ POLICY_CASES = ["tsp20_greedy", "tsp20_sampling", "tsp20_evaluate", "tsp20_multi
                 "tsp50_greedy", "cvrp50_sampling", "tsp200_greedy", "cvrp200_greedy", "pomo_cvrp20_multistart_greedy",
                 "cvrp20_sampling_temp", "tsp20_greedy_noclip",
                 "tsp20_sampling_topk5", "tsp20_sampling_topp", "cvrp20_sampling_topk_topp", "tsp100_greedy_topk",
-                "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy"]
+                "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy",
+                "pctsp20_greedy", "pctsp20_sampling", "pctsp50_greedy", "pctsp100_sampling", "pctsp20_multistart_greedy"]
 
 
 @pytest.mark.parametrize("stream_kernel", [0, 1])
@@ -323,7 +334,8 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
     assert_bits_equal(out["reward"], o["reward"], "reward vs oracle")
 
 
-@pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random"])
+@pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random",
+                                  "env_pctsp20_random"])
 def test_env_api_matches_reference_state_machine(name):
     """env.reset / env.step / env.get_reward through the RL4COEnvBase API against the reference's recorded states."""
     import eam_rl4co_amd as ea
@@ -345,6 +357,10 @@ def test_env_api_matches_reference_state_machine(name):
         if env_name == "tsp":
             assert_bits_equal(td["first_node"], fx["step_first_node"][:, step], "first")
             assert_bits_equal(td["i"], fx["step_i"][:, step], "i")
+        elif env_name == "pctsp":
+            for k in ("visited", "cur_total_prize", "cur_total_penalty", "i"):
+                assert_bits_equal(td[k], fx["step_" + k][:, step], k)
+            assert_bits_equal(env.get_action_mask(td), fx["step_action_mask"][:, step], "get_action_mask")
         else:
             if env_name == "cvrp":
                 assert_bits_equal(td["visited"], fx["step_visited"][:, step], "visited")
@@ -355,6 +371,14 @@ def test_env_api_matches_reference_state_machine(name):
     reward = env.get_reward(td, t(fx["step_action"]))
     np.testing.assert_allclose(reward.cpu().numpy(), fx["reward"], rtol=1e-6, atol=0)
     bad = fx["step_action"].copy()
+    if env_name == "pctsp":     # the reference's own asserts (pctsp/env.py:189-205)
+        bad[0, 1] = bad[0, 0]
+        with pytest.raises(AssertionError, match="Duplicates"):
+            env.get_reward(td, t(bad))
+        early = np.zeros_like(bad); early[:, 0] = fx["step_action"][:, 0]
+        with pytest.raises(AssertionError, match="Total prize does not satisfy min total prize"):
+            env.get_reward(td, t(early))
+        return
     if env_name == "sdvrp":     # the reference's own asserts (sdvrp/env.py:148-171)
         with pytest.raises(AssertionError, match="All demand must be satisfied"):
             env.get_reward(td, t(np.ascontiguousarray(bad[:, :5])))      # the tours stop early
@@ -380,7 +404,8 @@ def test_random_policy_rollout_helper_shapes():
 
 @pytest.mark.parametrize("env_name,N,B,mode", [("tsp", 100, 1024, "greedy"), ("cvrp", 100, 1024, "sampling"),
                                                 ("tsp", 20, 128, "greedy"), ("cvrp", 500, 16, "greedy"),
-                                                ("sdvrp", 100, 256, "sampling"), ("sdvrp", 200, 32, "greedy")])
+                                                ("sdvrp", 100, 256, "sampling"), ("sdvrp", 200, 32, "greedy"),
+                                                ("pctsp", 100, 256, "sampling"), ("pctsp", 200, 32, "greedy")])
 def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
     """BASELINE.json configs at full size (C2, C3, C1, C5 with a reduced batch so the CPU oracle finishes in
     seconds): tours bit-identical to the oracle, plus size-independent properties."""
@@ -392,7 +417,9 @@ def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
     td_cpu = env.reset(batch_size=[B])
     td = td_cpu.to(DEV)
     locs = td_cpu["locs"].numpy()
-    demand = td_cpu["demand"].numpy() if env_name != "tsp" else None
+    demand = td_cpu["demand"].numpy() if env_name in ("cvrp", "sdvrp") else None
+    if env_name == "pctsp":
+        demand = {k: td_cpu[k].numpy() for k in ("expected_prize", "real_prize", "penalty", "prize_required")}
     M = locs.shape[1]
     kw = {}
     noise = None
@@ -406,6 +433,17 @@ def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
     if env_name == "tsp":
         assert (np.sort(acts, 1) == np.arange(N)).all()
         pts = np.take_along_axis(locs, acts[..., None].repeat(2, -1), 1).astype(np.float64)
+    elif env_name == "pctsp":       # customers at most once; enough prize or everyone visited; reward by the definition
+        for b, row in enumerate(acts):
+            nz = row[row != 0]
+            assert len(set(nz)) == len(nz)
+            assert demand["real_prize"][b, nz].sum() >= 1 - 1e-5 or len(nz) == N
+        pts = np.take_along_axis(locs, acts[..., None].repeat(2, -1), 1).astype(np.float64)
+        pts = np.concatenate([locs[:, :1].astype(np.float64), pts], 1)
+        length = np.linalg.norm(np.roll(pts, -1, 1) - pts, axis=-1).sum(1)
+        pen = demand["penalty"].astype(np.float64)
+        want = np.take_along_axis(pen, acts, 1).sum(1) - (length + pen[:, 1:].sum(1))
+        np.testing.assert_allclose(out["reward"].cpu().numpy(), want, rtol=1e-5)
     else:
         if env_name == "cvrp":
             srt = np.sort(acts, 1)
@@ -415,8 +453,9 @@ def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
             assert float(pol._last_td["demand_with_depot"].abs().max()) == 0.0
         pts = np.take_along_axis(locs, acts[..., None].repeat(2, -1), 1).astype(np.float64)
         pts = np.concatenate([locs[:, :1].astype(np.float64), pts], 1)
-    length = np.linalg.norm(np.roll(pts, -1, 1) - pts, axis=-1).sum(1)
-    np.testing.assert_allclose(-out["reward"].cpu().numpy(), length, rtol=2e-6)
+    if env_name != "pctsp":
+        length = np.linalg.norm(np.roll(pts, -1, 1) - pts, axis=-1).sum(1)
+        np.testing.assert_allclose(-out["reward"].cpu().numpy(), length, rtol=2e-6)
     o = oracle.policy_rollout(golden_weights(cfg), env_name, locs, demand, decode_type=mode,
                               noise=None if noise is None else noise.numpy())
     T = o["actions"].shape[1]
