@@ -43,7 +43,10 @@ def encode_autograd(policy, td):
         h = F.linear(locs, ie.init_embed.weight, ie.init_embed.bias)
     else:
         depot = F.linear(locs[:, :1], ie.init_embed_depot.weight, ie.init_embed_depot.bias)
-        feat = torch.cat((locs[:, 1:], td["demand"][..., None]), -1)
+        if policy.env_name == "pctsp":
+            feat = torch.cat((locs[:, 1:], td["expected_prize"][..., None], td["penalty"][..., 1:, None]), -1)
+        else:
+            feat = torch.cat((locs[:, 1:], td["demand"][..., None]), -1)
         h = torch.cat((depot, F.linear(feat, ie.init_embed.weight, ie.init_embed.bias)), 1)
     training = policy.training
     for layer in enc.net.layers:
@@ -93,6 +96,31 @@ def _cvrp_states(actions, demand_rows, vcap, M):
         a = actions[:, t]
         d = demand_rows[ar, (a - 1).clamp(0, N - 1)]
         used = (used + d) * (a != 0).float()
+        visited = visited.clone()
+        visited[ar, a] = True
+        cur = a
+    return torch.stack(curs, 1), torch.stack(rems, 1), torch.stack(masks, 1)
+
+
+def _pctsp_states(actions, prize_rows, prize_required):
+    """-> cur [R,T], prize still to collect (clamped at 0) [R,T], mask [R,T,M] before each step
+    (pctsp/env.py:64-97,156-163; context.py:194-208).  prize_rows [R, M] with a zero depot slot."""
+    R, T = actions.shape
+    M = prize_rows.shape[1]
+    dev = actions.device
+    visited = torch.zeros(R, M, dtype=torch.bool, device=dev)
+    total = torch.zeros(R, dtype=torch.float32, device=dev)
+    cur = torch.zeros(R, dtype=torch.int64, device=dev)
+    curs, rems, masks = [], [], []
+    ar = torch.arange(R, device=dev)
+    for t in range(T):
+        blocked = visited[:, 1:] | visited[:, :1]
+        depot_blocked = (total < 1.0) & (~visited[:, 1:]).any(-1)
+        masks.append(~torch.cat((depot_blocked[:, None], blocked), 1))
+        curs.append(cur)
+        rems.append((prize_required - total).clamp(min=0))
+        a = actions[:, t]
+        total = total + prize_rows[ar, a]
         visited = visited.clone()
         visited[ar, a] = True
         cur = a
@@ -162,6 +190,9 @@ def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, tempe
             ctx_in = torch.cat((embr[ar, first], embr[ar, cur]), -1)                       # [Rc, T, 2E]
             if not multistart:   # step 0 uses the learned placeholder (context.py:118-131)
                 ctx_in = torch.cat((dec.context_embedding.W_placeholder.expand(Rc, 1, 2 * E), ctx_in[:, 1:]), 1)
+        elif policy.env_name == "pctsp":
+            cur, rem, mask = _pctsp_states(act, rep(td["real_prize"]), rep(td["prize_required"].reshape(-1)))
+            ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)                          # [Rc, T, E+1]
         elif policy.env_name == "cvrp":
             cur, rem, mask = _cvrp_states(act, rep(td["demand"]), rep(td["vehicle_capacity"].reshape(-1)), M)
             ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)                          # [Rc, T, E+1]

@@ -478,7 +478,10 @@ def policy_beam_search(sd, env_name, locs, demand=None, beam_width=None, select_
         cur_parent = parents[k][idx]
     actions_out = np.ascontiguousarray(np.stack(seq[::-1], 1))
     logp = np.ascontiguousarray(np.stack(seq_lp[::-1], 1))
-    reward = tour_length_reward(locs, actions_out, with_depot=(env_name != "tsp"))
+    if env_name == "pctsp":
+        reward = pctsp_reward(locs, demand["penalty"], actions_out)
+    else:
+        reward = tour_length_reward(locs, actions_out, with_depot=(env_name != "tsp"))
     if select_best:
         best = reward.reshape(BW, B).argmax(0)           # first maximum, as torch.max
         flat_idx = np.arange(B) + best * B

@@ -291,6 +291,7 @@ def pctsp():
     run_case("pctsp100_sampling", "pctsp", 100, 4, "sampling", keep_steps=first4, data_seed=75)
     run_case("pctsp20_multistart_greedy", "pctsp", 20, 3, "multistart_greedy", num_starts=20, keep_steps=first4, data_seed=74)
     run_env_case("env_pctsp20_random", "pctsp", 20, 8)
+    run_case("pctsp20_beam", "pctsp", 20, 3, "beam_search", keep_steps=first4, data_seed=76, decode_kw=dict(beam_width=6, select_best=True))
 
 
 def sdvrp():

@@ -178,7 +178,8 @@ def test_reference_lightning_checkpoint_loads(tmp_path):
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,cfg", [("tsp20_sampling", "am_tsp"), ("cvrp20_sampling", "am_cvrp"),
                                       ("pomo_tsp20_multistart_sampling", "pomo_tsp"), ("sdvrp20_sampling", "am_sdvrp"),
-                                      ("sdvrp20_multistart_greedy", "am_sdvrp")])
+                                      ("sdvrp20_multistart_greedy", "am_sdvrp"), ("pctsp20_sampling", "am_pctsp"),
+                                      ("pctsp20_multistart_greedy", "am_pctsp")])
 def test_reevaluation_matches_native_logp_and_reference(name, cfg):
     """evaluate_log_likelihood (autograd, all steps at once) == native per-step log-probs (atol 1e-4) == reference."""
     from eam_rl4co_amd.train import evaluate_log_likelihood
@@ -220,7 +221,7 @@ def test_reinforce_step_pomo_and_flat_allreduce():
     assert np.isfinite(first)
 
 
-@pytest.mark.parametrize("env_name", ["tsp", "cvrp", "sdvrp"])
+@pytest.mark.parametrize("env_name", ["tsp", "cvrp", "sdvrp", "pctsp"])
 def test_policy_call_leaves_the_callers_tensordict_untouched(env_name):
     """As in the reference, a rollout works on its own copy of the state: the same reset td can be rolled out twice
     (REINFORCE followed by a rollout baseline does exactly that) with identical results."""
@@ -241,7 +242,8 @@ def test_policy_call_leaves_the_callers_tensordict_untouched(env_name):
 # ---------------------------------------------------------------------------------------------------------
 # HIP graph replay of the whole rollout
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("env_name,mode", [("tsp", "greedy"), ("cvrp", "greedy"), ("cvrp", "sampling"), ("sdvrp", "greedy")])
+@pytest.mark.parametrize("env_name,mode", [("tsp", "greedy"), ("cvrp", "greedy"), ("cvrp", "sampling"), ("sdvrp", "greedy"),
+                                           ("pctsp", "greedy")])
 def test_graphed_rollout_equals_eager(env_name, mode):
     import eam_rl4co_amd as ea
 
@@ -494,7 +496,7 @@ def test_beam_topk_kernel(B, BW, M):
         np.testing.assert_array_equal(slp.cpu().numpy()[b::B], lp.reshape(BW, B, M)[order // M, b, order % M])
 
 
-@pytest.mark.parametrize("name", ["tsp20_beam", "tsp20_beam5_all", "cvrp20_beam", "tsp50_beam12_all", "sdvrp20_beam"])
+@pytest.mark.parametrize("name", ["tsp20_beam", "tsp20_beam5_all", "cvrp20_beam", "tsp50_beam12_all", "sdvrp20_beam", "pctsp20_beam"])
 def test_beam_search_reproduces_reference_tours(oracle, name):
     fx = golden(name)
     cfg = cfg_for(fx)

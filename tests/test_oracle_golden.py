@@ -275,7 +275,7 @@ def test_ea_cvrp_run_matches_reference(name):
                 assert load <= float(g["vehicle_capacity"]) + 1e-5
 
 
-@pytest.mark.parametrize("name", ["tsp20_beam", "tsp20_beam5_all", "cvrp20_beam", "tsp50_beam12_all", "sdvrp20_beam"])
+@pytest.mark.parametrize("name", ["tsp20_beam", "tsp20_beam5_all", "cvrp20_beam", "tsp50_beam12_all", "sdvrp20_beam", "pctsp20_beam"])
 def test_beam_search_matches_reference(oracle, name):
     """decode_type="beam_search" of the reference (beam_width = num_loc or given, with and without select_best)."""
     fx = golden(name)
