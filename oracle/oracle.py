@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ENV_TSP, ENV_CVRP, ENV_SDVRP, ENV_PCTSP = 0, 1, 2, 3
+ENV_TSP, ENV_CVRP, ENV_SDVRP, ENV_PCTSP, ENV_OP = 0, 1, 2, 3, 4
 GREEDY, SAMPLE, EVALUATE = 0, 1, 2
 MODES = {"greedy": GREEDY, "sampling": SAMPLE, "evaluate": EVALUATE}
 
@@ -179,6 +179,8 @@ def encode(sd, env_name, locs, demand=None, num_heads=8):
         depot = linear(locs[:, :1], sd[pre + "init_embed_depot.weight"], sd[pre + "init_embed_depot.bias"])
         if env_name == "pctsp":
             extra = [_f32(demand["expected_prize"])[..., None], _f32(demand["penalty"])[:, 1:, None]]
+        elif env_name == "op":        # (x, y, prize)  [nn/env_embeddings/init.py:260-286]
+            extra = [_f32(demand["prize"])[:, 1:, None]]
         else:
             extra = [_f32(demand)[..., None]]
         feat = np.concatenate([_f32(locs[:, 1:])] + extra, -1)
@@ -237,8 +239,12 @@ class State:
 
     def __init__(self, env_name, locs, demand=None, vehicle_capacity=1.0, num_starts=0):
         self.env_name = env_name
-        self.env = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP, "pctsp": ENV_PCTSP}[env_name]
+        self.env = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP, "pctsp": ENV_PCTSP, "op": ENV_OP}[env_name]
         self.rem = None
+        self.oplocs = None
+        op_maxlen = None
+        if env_name == "op":         # used = tour_length, vcap = max_length[:, 0] per row, demand = max_length [B, M]
+            op_maxlen, demand, vehicle_capacity = _f32(demand["max_length"]), _f32(demand["max_length"]), 0.0
         if env_name == "pctsp":      # used = cur_total_prize, vcap = prize_required, demand = real_prize (depot slot 0)
             demand, vehicle_capacity = demand["real_prize"], float(np.asarray(demand["prize_required"]).reshape(-1)[0])
         self.locs = _f32(locs)
@@ -255,6 +261,14 @@ class State:
             self.demand = None
             self.visited = None
             self.mask = np.ones((R, self.M), np.uint8)
+        elif env_name == "op":
+            self.demand = op_maxlen
+            self.oplocs = self.locs
+            self.vcap = np.ascontiguousarray(np.tile(op_maxlen[:, 0], S))
+            self.visited = np.zeros((R, self.M), np.uint8)
+            self.mask = np.empty((R, self.M), np.uint8)
+            lib().orc_op_mask(_p(self.visited), _p(self.used), _p(self.cur), _p(self.oplocs), _p(self.demand), _p(self.mask),
+                              C.c_long(R), C.c_long(self.Binst), C.c_int(self.M))
         elif env_name == "pctsp":
             self.demand = _f32(demand)
             self.visited = np.zeros((R, self.M), np.uint8)
@@ -280,6 +294,10 @@ class State:
         if self.env == ENV_TSP:
             lib().orc_tsp_step(_p(self.mask), _p(self.first), _p(self.cur), _p(self.istep), _p(a), _p(self.done),
                                C.c_long(self.R), C.c_int(self.M))
+        elif self.env == ENV_OP:
+            lib().orc_op_step(_p(self.visited), _p(self.used), None, None, _p(self.oplocs), _p(self.demand), _p(self.cur),
+                              _p(self.istep), _p(a), _p(self.mask), _p(self.done), C.c_long(self.R), C.c_long(self.Binst),
+                              C.c_int(self.M))
         elif self.env == ENV_PCTSP:
             lib().orc_pctsp_step(_p(self.visited), _p(self.used), None, _p(self.demand), None, _p(self.cur), _p(self.istep),
                                  _p(a), _p(self.mask), _p(self.done), C.c_long(self.R), C.c_long(self.Binst),
@@ -338,7 +356,8 @@ def rollout(st: State, cache, mode="greedy", noise=None, given=None, clip=10.0, 
         C.c_int(st.env), C.c_long(R), C.c_long(st.Binst), C.c_int(M), C.c_int(E), C.c_int(num_heads),
         _p(cache["K"]), _p(cache["V"]), _p(cache["Lp"]), _p(cache["Pa"]), _p(cache["Pb"]), _p(cache["cvec"]),
         _p(cache["gctx"]), _p(st.first), _p(st.cur), _p(st.istep), _p(st.used), _p(st.vcap), _p(st.demand),
-        _p(st.mask), _p(st.visited), _p(st.done), _p(st.rem), _p(cache.get("dyn")), C.c_int(MODES[mode]), _p(noise),
+        _p(st.mask), _p(st.visited), _p(st.done), _p(st.rem), _p(cache.get("dyn")), _p(st.oplocs), C.c_int(MODES[mode]),
+        _p(noise),
         _p(given), C.c_int(tg),
         C.c_float(clip), C.c_float(temp), C.c_int(int(top_k)), C.c_float(top_p), C.c_int(t_max), _p(actions), _p(logps))
     if T == -1:
@@ -366,6 +385,22 @@ def pctsp_reward(locs, penalty, actions):
     out = np.empty(R, np.float32)
     lib().orc_pctsp_reward(_p(locs), _p(penalty), _p(actions), _p(out), C.c_long(R), C.c_long(Binst), C.c_int(M), C.c_int(T))
     return out
+
+
+def op_reward(prize, actions):
+    prize, actions = _f32(prize), _i64(actions)
+    R, T = actions.shape
+    out = np.empty(R, np.float32)
+    lib().orc_op_reward(_p(prize), _p(actions), _p(out), C.c_long(R), C.c_long(prize.shape[0]), C.c_int(prize.shape[1]),
+                        C.c_int(T))
+    return out
+
+
+def check_op(actions, locs, max_length):
+    actions, locs, max_length = _i64(actions), _f32(locs), _f32(max_length)
+    lib().orc_check_op.restype = C.c_long
+    return int(lib().orc_check_op(_p(actions), _p(locs), _p(max_length), C.c_long(actions.shape[0]), C.c_long(locs.shape[0]),
+                                  C.c_int(locs.shape[1]), C.c_int(actions.shape[1])))
 
 
 def check_pctsp(actions, real_prize):
@@ -398,7 +433,7 @@ def check_cvrp(actions, demand, vcap):
 
 
 def policy_rollout(sd, env_name, locs, demand=None, decode_type="greedy", num_starts=0, noise=None, given=None,
-                   use_graph_context=True, clip=10.0, temp=1.0, num_heads=8, top_k=0, top_p=0.0):
+                   use_graph_context=True, clip=10.0, temp=1.0, num_heads=8, top_k=0, top_p=0.0, start_nodes=None):
     """ConstructivePolicy.forward restated on the oracle: encoder, cache, (multistart hook), loop, reward.
 
     locs for CVRP already include the depot at index 0 (post-reset layout).
@@ -415,6 +450,8 @@ def policy_rollout(sd, env_name, locs, demand=None, decode_type="greedy", num_st
         B = st.Binst
         nloc = st.M if env_name == "tsp" else st.M - 1          # depot cannot be a start node (utils/ops.py:120-130)
         start = (np.repeat(np.arange(num_starts), B) % nloc + (0 if env_name == "tsp" else 1)).astype(np.int64)
+        if start_nodes is not None:      # OP resamples its start nodes when some are infeasible (utils/ops.py:158-169)
+            start = _i64(start_nodes)
         if given is not None:
             start, given = _i64(given[:, 0]), np.ascontiguousarray(given[:, 1:])
         st.step(start)
@@ -425,6 +462,8 @@ def policy_rollout(sd, env_name, locs, demand=None, decode_type="greedy", num_st
     logp = np.concatenate(pre_lp + [lps], 1)
     if env_name == "pctsp":
         reward = pctsp_reward(locs, demand["penalty"], actions)
+    elif env_name == "op":
+        reward = op_reward(demand["prize"], actions)
     else:
         reward = tour_length_reward(locs, actions, with_depot=(env_name != "tsp"))
     return {"actions": actions, "logp_steps": logp, "log_likelihood": sum_logp(logp), "reward": reward,

@@ -36,6 +36,7 @@ import torch  # noqa: E402
 import goldweights  # noqa: E402
 import rl4co.utils.decoding as ref_decoding  # noqa: E402
 from rl4co.envs.routing.cvrp.env import CVRPEnv  # noqa: E402
+from rl4co.envs.routing.op.env import OPEnv  # noqa: E402
 from rl4co.envs.routing.pctsp.env import PCTSPEnv  # noqa: E402
 from rl4co.envs.routing.sdvrp.env import SDVRPEnv  # noqa: E402
 from rl4co.envs.routing.tsp.env import TSPEnv  # noqa: E402
@@ -104,6 +105,12 @@ class Recorder:
         torch.multinomial = self._mn
 
 
+def gen_params(env_name, num_loc):
+    """OPGenerator's defaults build Uniform(1.0, 1.0), which this torch rejects; prize_distribution="dist" skips that
+    sampler (it is unused: the prize comes from prize_type="dist", the distance to the depot)."""
+    return dict(num_loc=num_loc, prize_distribution="dist") if env_name == "op" else dict(num_loc=num_loc)
+
+
 def np_(t):
     return t.detach().cpu().numpy()
 
@@ -111,8 +118,8 @@ def np_(t):
 def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_starts=None,
              keep_steps=None, keep_embeds=False, data_seed=1234, sample_seed=4321, actions=None,
              td_init=None, decode_kw=None):
-    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv}[env_name]
-    env = Env(generator_params=dict(num_loc=num_loc), seed=data_seed)
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv}[env_name]
+    env = Env(generator_params=gen_params(env_name, num_loc), seed=data_seed)
     if td_init is None:
         torch.manual_seed(data_seed)
         td_init = env.reset(batch_size=[batch])
@@ -150,6 +157,9 @@ def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_st
     if env_name == "pctsp":
         for k in ("expected_prize", "real_prize", "penalty", "prize_required"):
             fx[k] = np_(td_init[k])
+    if env_name == "op":
+        for k in ("prize", "max_length"):
+            fx[k] = np_(td_init[k])
     if rec.noise:
         fx["noise"] = np.stack([np_(q) for q in rec.noise], 1)  # [rows, T, M] Exp(1) draws
     if policy_kw:
@@ -174,8 +184,8 @@ def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_st
 
 def run_env_case(name, env_name, num_loc, batch, data_seed=99, act_seed=7):
     """Env-only golden: random feasible policy, every state tensor after every step."""
-    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv}[env_name]
-    env = Env(generator_params=dict(num_loc=num_loc), seed=data_seed)
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv}[env_name]
+    env = Env(generator_params=gen_params(env_name, num_loc), seed=data_seed)
     torch.manual_seed(data_seed)
     gen = env.generator(batch_size=[batch])
     fx = {"torch_version": np.array(torch.__version__), "env_name": np.array(env_name),
@@ -188,7 +198,8 @@ def run_env_case(name, env_name, num_loc, batch, data_seed=99, act_seed=7):
     per = {k: [] for k in ("action", "action_mask", "done", "current_node")}
     extra = {"tsp": ("first_node", "i"), "cvrp": ("used_capacity", "visited"),
              "sdvrp": ("used_capacity", "demand_with_depot"),
-             "pctsp": ("cur_total_prize", "cur_total_penalty", "visited", "i")}[env_name]
+             "pctsp": ("cur_total_prize", "cur_total_penalty", "visited", "i"),
+             "op": ("tour_length", "current_total_prize", "visited", "i")}[env_name]
     for k in extra:
         per[k] = []
     while not td["done"].all():
@@ -278,6 +289,22 @@ def beam():
              decode_kw=dict(beam_width=12, select_best=False))
 
 
+def op():
+    """Seventh batch (python make_golden.py op): orienteering problem."""
+    import json
+    first4 = [0, 1, 2, 3]
+    sd = AttentionModelPolicy(env_name="op").state_dict()
+    with open(os.path.join(HERE, "state_dict_contract_op.json"), "w") as f:
+        json.dump({"am_op": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]}, f, indent=0)
+    run_case("op20_greedy", "op", 20, 4, "greedy", keep_embeds=True, data_seed=81)
+    run_case("op20_sampling", "op", 20, 4, "sampling", keep_steps=first4, data_seed=82)
+    run_case("op50_greedy", "op", 50, 4, "greedy", keep_steps=first4, data_seed=83)
+    run_case("op100_sampling", "op", 100, 4, "sampling", keep_steps=first4, data_seed=85)
+    run_case("op20_multistart_greedy", "op", 20, 3, "multistart_greedy", num_starts=20, keep_steps=first4, data_seed=84)
+    run_env_case("env_op20_random", "op", 20, 8)
+    run_env_case("env_op50_random", "op", 50, 4, data_seed=98)
+
+
 def pctsp():
     """Sixth batch (python make_golden.py pctsp): prize-collecting TSP."""
     import json
@@ -321,7 +348,9 @@ def filtering():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "pctsp":
+    if len(sys.argv) > 1 and sys.argv[1] == "op":
+        op()
+    elif len(sys.argv) > 1 and sys.argv[1] == "pctsp":
         pctsp()
     elif len(sys.argv) > 1 and sys.argv[1] == "sdvrp":
         sdvrp()

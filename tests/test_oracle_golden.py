@@ -26,6 +26,8 @@ POLICY_CASES = [
     "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy",
     # PCTSP (prize collecting): prize-gated depot, penalty reward
     "pctsp20_greedy", "pctsp20_sampling", "pctsp50_greedy", "pctsp100_sampling", "pctsp20_multistart_greedy",
+    # OP (orienteering): distance-dependent mask, prize reward
+    "op20_greedy", "op20_sampling", "op50_greedy", "op100_sampling", "op20_multistart_greedy",
 ]
 
 
@@ -40,7 +42,9 @@ def _run(orc, fx):
         sd, str(fx["env_name"]), fx["locs"], instance_of(fx), decode_type=decode_type, num_starts=ns,
         noise=fx.get("noise"), given=given, use_graph_context=bool(fx.get("policy_kw_use_graph_context", True)),
         clip=float(fx.get("decode_kw_tanh_clipping", 10.0)), temp=float(fx.get("decode_kw_temperature", 1.0)),
-        top_k=int(fx.get("decode_kw_top_k", 0)), top_p=float(fx.get("decode_kw_top_p", 0.0)))
+        top_k=int(fx.get("decode_kw_top_k", 0)), top_p=float(fx.get("decode_kw_top_p", 0.0)),
+        # OP may resample its start nodes at random (utils/ops.py:158-169): replay the recorded ones
+        start_nodes=fx["actions"][:, 0] if (str(fx["env_name"]) == "op" and ns > 1) else None)
 
 
 @pytest.mark.parametrize("name", POLICY_CASES)
@@ -56,7 +60,8 @@ def test_policy_rollout_matches_reference(oracle, name):
     np.testing.assert_allclose(out["log_likelihood"], fx["log_likelihood"], rtol=2e-6, atol=0)
 
 
-@pytest.mark.parametrize("name", ["tsp20_greedy", "cvrp20_greedy", "pomo_tsp20_multistart_sampling", "pctsp20_greedy"])
+@pytest.mark.parametrize("name", ["tsp20_greedy", "cvrp20_greedy", "pomo_tsp20_multistart_sampling", "pctsp20_greedy",
+                                  "op20_greedy"])
 def test_encoder_and_cache_match_reference(oracle, name):
     fx = golden(name)
     sd = golden_weights(cfg_for(fx))
@@ -106,12 +111,20 @@ def test_per_step_logits_logprobs_masks(oracle, name):
 
 
 @pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random",
-                                  "env_pctsp20_random"])
+                                  "env_pctsp20_random", "env_op20_random", "env_op50_random"])
 def test_env_state_machine_bit_exact(oracle, name):
     fx = golden(name)
     env = str(fx["env_name"])
     if env == "tsp":
         locs, demand = fx["gen_locs"], None
+    elif env == "op":
+        import torch
+        locs = np.concatenate([fx["gen_depot"][:, None], fx["gen_locs"]], 1)
+        tl, td_ = torch.from_numpy(locs), torch.from_numpy(fx["gen_depot"])
+        # the per-node arrival limit, with the reset's own torch expression (op/env.py:122-126)
+        ml = torch.from_numpy(fx["gen_max_length"])[..., None] - (td_[..., None, :] - tl).norm(p=2, dim=-1) - 1e-6
+        demand = {"prize": np.concatenate([np.zeros((locs.shape[0], 1), np.float32), fx["gen_prize"]], 1),
+                  "max_length": ml.numpy()}
     elif env == "pctsp":
         locs = np.concatenate([fx["gen_depot"][:, None], fx["gen_locs"]], 1)
         pad = lambda a: np.concatenate([np.zeros((a.shape[0], 1), np.float32), a], 1)
@@ -134,6 +147,10 @@ def test_env_state_machine_bit_exact(oracle, name):
         elif env == "sdvrp":
             assert np.array_equal(st.rem, fx["step_demand_with_depot"][:, t]), t       # exact: min / add / sub only
             assert np.array_equal(st.used, fx["step_used_capacity"][:, t].reshape(-1)), t
+        elif env == "op":
+            assert np.array_equal(st.visited.astype(bool), fx["step_visited"][:, t]), t
+            assert np.array_equal(st.used, fx["step_tour_length"][:, t]), t             # sqrtf(fmaf(dy,dy,dx*dx)) == torch
+            assert np.array_equal(st.istep, fx["step_i"][:, t]), t
         elif env == "pctsp":
             assert np.array_equal(st.visited.astype(bool), fx["step_visited"][:, t]), t
             assert np.array_equal(st.used, fx["step_cur_total_prize"][:, t]), t         # one fp32 add per step
@@ -144,11 +161,20 @@ def test_env_state_machine_bit_exact(oracle, name):
             assert np.array_equal(st.used, fx["step_used_capacity"][:, t].reshape(-1)), t
     if env == "pctsp":
         reward = oracle.pctsp_reward(locs, demand["penalty"], fx["step_action"])
+    elif env == "op":
+        reward = oracle.op_reward(demand["prize"], fx["step_action"])
     else:
         reward = oracle.tour_length_reward(locs, fx["step_action"], with_depot=(env != "tsp"))
     np.testing.assert_allclose(reward, fx["reward"], rtol=1e-6, atol=0)
     if env == "tsp":
         assert oracle.check_tsp(fx["step_action"]) == 0
+    elif env == "op":
+        assert oracle.check_op(fx["step_action"], locs, demand["max_length"]) == 0
+        twice = fx["step_action"].copy()
+        twice[:, 1] = twice[:, 0]
+        assert oracle.check_op(twice, locs, demand["max_length"]) % 1000000 == int((twice[:, 0] != 0).sum())
+        far = np.tile(np.arange(1, locs.shape[1], dtype=np.int64), (locs.shape[0], 1))      # everyone: far too long
+        assert oracle.check_op(far, locs, demand["max_length"]) // 1000000 == locs.shape[0]
     elif env == "pctsp":
         assert oracle.check_pctsp(fx["step_action"], demand["real_prize"]) == 0
         twice = fx["step_action"].copy()
