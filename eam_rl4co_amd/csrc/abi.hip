@@ -105,6 +105,38 @@ __attribute__((visibility("default"))) int eamrl_pctsp_step_mask(uint8_t* visite
                                  (hipStream_t)stream), "eamrl_pctsp_step_mask");
 }
 
+__attribute__((visibility("default"))) int eamrl_op_step_mask(uint8_t* visited, float* tour_len, float* prize_tot,
+                                                             const float* prize, const float* locs, const float* maxlen,
+                                                             int64_t* cur, int64_t* istep, const int64_t* action,
+                                                             uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int M,
+                                                             void* stream)
+{
+    REQUIRE(visited && tour_len && locs && maxlen && cur && mask, "eamrl_op_step_mask");
+    REQUIRE(!action || (istep && done), "eamrl_op_step_mask");
+    REQUIRE(!prize_tot || prize, "eamrl_op_step_mask");
+    REQUIRE(R >= 0 && B > 0 && M >= 2, "eamrl_op_step_mask");
+    if (R == 0) return 0;
+    return launched(launch_op(visited, tour_len, prize_tot, prize, locs, maxlen, cur, istep, action, mask, done, R, B, M,
+                              (hipStream_t)stream), "eamrl_op_step_mask");
+}
+
+__attribute__((visibility("default"))) int eamrl_op_reward(const float* prize, const int64_t* actions, float* reward,
+                                                          int64_t R, int64_t B, int M, int T, void* stream)
+{
+    REQUIRE(prize && actions && reward && R >= 0 && B > 0 && M >= 2 && T > 0, "eamrl_op_reward");
+    if (R == 0) return 0;
+    return launched(launch_op_reward(prize, actions, reward, R, B, M, T, (hipStream_t)stream), "eamrl_op_reward");
+}
+
+__attribute__((visibility("default"))) int eamrl_op_check_solution(const int64_t* actions, const float* locs,
+                                                                  const float* maxlen, int64_t R, int64_t B, int M, int T,
+                                                                  int32_t* bad, void* stream)
+{
+    REQUIRE(actions && locs && maxlen && bad && R >= 0 && B > 0 && M >= 2 && M <= 4096 && T > 0, "eamrl_op_check_solution");
+    if (R == 0) return 0;
+    return launched(launch_op_check(actions, locs, maxlen, R, B, M, T, bad, (hipStream_t)stream), "eamrl_op_check_solution");
+}
+
 __attribute__((visibility("default"))) int eamrl_pctsp_reward(const float* locs, const float* penalty, const int64_t* actions,
                                                              float* reward, int64_t R, int64_t B, int M, int T,
                                                              void* stream)
@@ -183,7 +215,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
                      uint32_t* status, DecArgs& a)
 {
     REQUIRE(c && s, what);
-    REQUIRE(env >= EAMRL_ENV_TSP && env <= EAMRL_ENV_PCTSP, what);
+    REQUIRE(env >= EAMRL_ENV_TSP && env <= EAMRL_ENV_OP, what);
     REQUIRE(mode == EAMRL_GREEDY || mode == EAMRL_SAMPLE || mode == EAMRL_EVALUATE, what);
     REQUIRE(c->K && c->V && c->Lp && c->Pa && c->cvec, what);
     REQUIRE(c->B > 0 && c->M > 0 && c->E > 0 && c->H > 0, what);
@@ -197,6 +229,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
     if (env == EAMRL_ENV_CVRP) REQUIRE(s->used && s->vcap && c->M >= 2, what);
     if (env == EAMRL_ENV_SDVRP) REQUIRE(s->used && s->vcap && s->rem && c->dyn && c->M >= 2, what);
     if (env == EAMRL_ENV_PCTSP) REQUIRE(s->used && s->vcap && c->M >= 2, what);
+    if (env == EAMRL_ENV_OP) REQUIRE(s->used && s->vcap && c->M >= 2, what);
     if (mode == EAMRL_SAMPLE) REQUIRE(noise != nullptr, what);
     if (mode == EAMRL_EVALUATE) REQUIRE(given != nullptr, what);
     a = DecArgs{};
@@ -204,7 +237,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
     a.ld = c->ld; a.B = c->B; a.M = c->M; a.E = c->E; a.H = c->H;
     a.first = s->first; a.cur = s->cur; a.istep = s->istep; a.used = s->used; a.vcap = s->vcap; a.demand = s->demand;
     a.mask = s->mask; a.visited = s->visited; a.done = s->done;
-    a.rem = s->rem; a.dyn = c->dyn;
+    a.rem = s->rem; a.dyn = c->dyn; a.locs = s->locs;
     a.R = R; a.mode = mode; a.noise = noise; a.given = given; a.clip = clip; a.temp = temp; a.top_k = top_k; a.top_p = top_p; a.status = status;
     return 0;
 }
@@ -226,6 +259,7 @@ __attribute__((visibility("default"))) int eamrl_am_decode_step(int env, const e
         REQUIRE(a.done, "eamrl_am_decode_step");
         if (env == EAMRL_ENV_CVRP) REQUIRE(a.visited && a.demand, "eamrl_am_decode_step");
         if (env == EAMRL_ENV_PCTSP) REQUIRE(a.visited && a.demand && a.istep, "eamrl_am_decode_step");
+        if (env == EAMRL_ENV_OP) REQUIRE(a.visited && a.demand && a.istep && a.locs, "eamrl_am_decode_step");
     }
     a.fuse_env = fuse_env_step;
     a.action = action; a.logp = logp; a.logprobs_all = logprobs_all; a.logits_raw = logits_raw;
@@ -246,6 +280,7 @@ __attribute__((visibility("default"))) int eamrl_am_rollout(int env, const eamrl
     REQUIRE(actions && logps && steps_out && a.done && t_max > 0, "eamrl_am_rollout");
     if (env == EAMRL_ENV_CVRP) REQUIRE(a.visited && a.demand, "eamrl_am_rollout");
     if (env == EAMRL_ENV_PCTSP) REQUIRE(a.visited && a.demand && a.istep, "eamrl_am_rollout");
+    if (env == EAMRL_ENV_OP) REQUIRE(a.visited && a.demand && a.istep && a.locs, "eamrl_am_rollout");
     if (mode == EAMRL_EVALUATE) REQUIRE(t_given > 0, "eamrl_am_rollout");
     a.fuse_env = 1; a.t_max = t_max; a.t_given = t_given;
     a.action = actions; a.logp = logps; a.steps_out = steps_out;

@@ -441,6 +441,28 @@ __device__ bool env_step_row(const DecArgs& a, const RowLds& l, uint8_t* vis, fl
         any_rem = __syncthreads_or(any_rem);
         if (tid == 0) l.msk[0] = !((s.cur == 0) && any_free);
         return any_rem == 0;
+    } else if (ENV == EAMRL_ENV_OP) {
+        // OPEnv._step + get_action_mask (op/env.py:69-102,149-165); a.demand = per-node arrival limit, s.used = tour length
+        const float* L = a.locs + (r % a.B) * (int64_t)M * 2;
+        const float* ml = a.demand + (r % a.B) * (int64_t)M;
+        const float cx = L[2 * act], cy = L[2 * act + 1];
+        {
+            const float dx = cx - L[2 * s.cur], dy = cy - L[2 * s.cur + 1];
+            s.used = s.used + __builtin_sqrtf(fma_(dy, dy, dx * dx));
+        }
+        const bool done = (act == 0) && (s.istep > 0);
+        s.cur = act;
+        s.istep += 1;
+        if (tid == 0) vis[act] = 1;
+        __syncthreads();
+        const int v0 = vis[0] != 0;
+        for (int n = 1 + tid; n < M; n += BLOCK) {
+            const float dx = L[2 * n] - cx, dy = L[2 * n + 1] - cy;
+            const int exceeds = (s.used + __builtin_sqrtf(fma_(dy, dy, dx * dx))) > ml[n];
+            l.msk[n] = !((vis[n] != 0) | v0 | exceeds);
+        }
+        if (tid == 0) l.msk[0] = 1;
+        return done;
     } else if (ENV == EAMRL_ENV_PCTSP) {
         // PCTSPEnv._step + get_action_mask (pctsp/env.py:64-97,156-163); a.demand = real_prize [B][M]
         const float* prize = a.demand + (r % a.B) * M;
@@ -507,7 +529,7 @@ __device__ __forceinline__ void load_row_state(const DecArgs& a, int64_t r, RowS
         s.vcap = 0.0f;
     } else {
         s.first = 0;
-        s.istep = (ENV == EAMRL_ENV_PCTSP) ? a.istep[r] : 1;
+        s.istep = (ENV == EAMRL_ENV_PCTSP || ENV == EAMRL_ENV_OP) ? a.istep[r] : 1;
         s.used = a.used[r];
         s.vcap = a.vcap[r];
     }
@@ -521,7 +543,7 @@ __device__ __forceinline__ void store_row_state(const DecArgs& a, const RowLds& 
     __syncthreads();
     for (int n = tid; n < a.M; n += BLOCK) {
         a.mask[r * a.M + n] = l.msk[n];
-        if (ENV == EAMRL_ENV_CVRP || ENV == EAMRL_ENV_PCTSP) a.visited[r * a.M + n] = vis[n];
+        if (ENV == EAMRL_ENV_CVRP || ENV == EAMRL_ENV_PCTSP || ENV == EAMRL_ENV_OP) a.visited[r * a.M + n] = vis[n];
         if (ENV == EAMRL_ENV_SDVRP) a.rem[r * a.M + n] = rem[n];
     }
     if (tid == 0) {
@@ -529,7 +551,7 @@ __device__ __forceinline__ void store_row_state(const DecArgs& a, const RowLds& 
         a.done[r] = done ? 1 : 0;
         if (ENV == EAMRL_ENV_TSP) { a.first[r] = s.first; a.istep[r] = s.istep; }
         else a.used[r] = s.used;
-        if (ENV == EAMRL_ENV_PCTSP) a.istep[r] = s.istep;
+        if (ENV == EAMRL_ENV_PCTSP || ENV == EAMRL_ENV_OP) a.istep[r] = s.istep;
     }
 }
 
@@ -541,7 +563,8 @@ __device__ __forceinline__ void load_row_lds(const DecArgs& a, const RowLds& l, 
     const int tid = threadIdx.x;
     for (int n = tid; n < a.M; n += BLOCK) {
         l.msk[n] = a.mask[r * a.M + n];
-        if ((ENV == EAMRL_ENV_CVRP || ENV == EAMRL_ENV_PCTSP) && want_vis) vis[n] = a.visited[r * a.M + n];
+        if ((ENV == EAMRL_ENV_CVRP || ENV == EAMRL_ENV_PCTSP || ENV == EAMRL_ENV_OP) && want_vis)
+            vis[n] = a.visited[r * a.M + n];
         if (ENV == EAMRL_ENV_SDVRP) rem[n] = a.rem[r * a.M + n];
     }
     if (ENV == EAMRL_ENV_SDVRP)
@@ -604,7 +627,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_stream(DecArgs a)
         done = env_step_row<ENV>(a, l, vis, rem, r, s, act);
         ++t;
     }
-    if (ENV == EAMRL_ENV_PCTSP) s.istep = i0;      // k_rollout_pad adds the batch's step count (see there)
+    if (ENV == EAMRL_ENV_PCTSP || ENV == EAMRL_ENV_OP) s.istep = i0;      // k_rollout_pad adds the batch's step count
     store_row_state<ENV>(a, l, vis, rem, r, s, done);
     if (tid == 0) {
         atomicMax(a.steps_out, t);
@@ -615,14 +638,14 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_stream(DecArgs a)
 // After the loop the reference keeps stepping finished CVRP rows with the depot until the slowest row
 // is done: rows whose last real action was a customer end at the depot with an
 // empty vehicle.  actions/logps are already right-padded with 0; this fixes the state tensors.
-// PCTSP: the reference keeps counting `i` for finished rows too, so every row ends at i0 + T; the rollout kernels store
-// i0 and this adds the batch's step count.
+// PCTSP / OP: the reference keeps counting `i` for finished rows too, so every row ends at i0 + T; the rollout kernels
+// store i0 and this adds the batch's step count.
 __global__ void k_rollout_pad(DecArgs a, int env)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.R) return;
     const int T = *a.steps_out;
-    if (env == EAMRL_ENV_PCTSP) { a.istep[r] += T; return; }
+    if (env == EAMRL_ENV_PCTSP || env == EAMRL_ENV_OP) { a.istep[r] += T; return; }
     if (T <= 0 || !a.done[r]) return;
     // A row that needed fewer than T steps never wrote column T-1 (host pre-zeroed = depot); stepping a
     // finished row with the depot makes (cur, used) = (0, 0) and leaves mask/visited unchanged.
@@ -650,11 +673,13 @@ static int launch_decode(int env, const DecArgs& a, bool rollout, hipStream_t st
     if (rollout)
         k = env == EAMRL_ENV_TSP ? k_rollout_stream<EAMRL_ENV_TSP>
           : env == EAMRL_ENV_CVRP ? k_rollout_stream<EAMRL_ENV_CVRP>
-          : env == EAMRL_ENV_SDVRP ? k_rollout_stream<EAMRL_ENV_SDVRP> : k_rollout_stream<EAMRL_ENV_PCTSP>;
+          : env == EAMRL_ENV_SDVRP ? k_rollout_stream<EAMRL_ENV_SDVRP>
+          : env == EAMRL_ENV_PCTSP ? k_rollout_stream<EAMRL_ENV_PCTSP> : k_rollout_stream<EAMRL_ENV_OP>;
     else
         k = env == EAMRL_ENV_TSP ? k_decode_step<EAMRL_ENV_TSP>
           : env == EAMRL_ENV_CVRP ? k_decode_step<EAMRL_ENV_CVRP>
-          : env == EAMRL_ENV_SDVRP ? k_decode_step<EAMRL_ENV_SDVRP> : k_decode_step<EAMRL_ENV_PCTSP>;
+          : env == EAMRL_ENV_SDVRP ? k_decode_step<EAMRL_ENV_SDVRP>
+          : env == EAMRL_ENV_PCTSP ? k_decode_step<EAMRL_ENV_PCTSP> : k_decode_step<EAMRL_ENV_OP>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)

@@ -182,6 +182,123 @@ __global__ __launch_bounds__(EB) void k_check_sdvrp(const int64_t* actions, cons
     if (twice) atomicAdd(&bad[1], 1);
 }
 
+// torch's norm(p=2, dim=-1) of a 2-vector on the CPU, bit for bit (OP): sqrtf(fmaf(dy, dy, dx * dx))
+__device__ __forceinline__ float dist2(float ax, float ay, float bx, float by)
+{
+    const float dx = ax - bx, dy = ay - by;
+    return __builtin_sqrtf(fma_(dy, dy, dx * dx));
+}
+
+// OP: one wavefront per row.  STEP = 0: mask only; STEP = 1: move (tour length += leg), mark visited, then mask.
+template <int STEP>
+__global__ __launch_bounds__(EB) void k_op_step_mask(uint8_t* visited, float* tour_len, float* prize_tot, const float* prize,
+                                                     const float* locs, const float* maxlen, int64_t* cur, int64_t* istep,
+                                                     const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R,
+                                                     int64_t B, int M)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* L = locs + (r % B) * (int64_t)M * 2;
+    const float* ml = maxlen + (r % B) * (int64_t)M;
+    uint8_t* vis = visited + r * M;
+    float tl = tour_len[r];
+    int64_t c = cur[r];
+    c = c < 0 ? 0 : (c > M - 1 ? M - 1 : c);
+    int64_t a = -1;
+    int v0 = vis[0] != 0;
+    if (STEP) {
+        a = action[r];
+        a = a < 0 ? 0 : (a > M - 1 ? M - 1 : a);     // an out-of-range action must not become an out-of-bounds access
+        tl = tl + dist2(L[2 * a], L[2 * a + 1], L[2 * c], L[2 * c + 1]);
+        c = a;
+        if (a == 0) v0 = 1;
+    }
+    const float cx = L[2 * c], cy = L[2 * c + 1];
+    for (int n = 1 + lane; n < M; n += 64) {
+        int v = vis[n] != 0;
+        if (STEP && n == a) { v = 1; vis[n] = 1; }
+        const int exceeds = (tl + dist2(L[2 * n], L[2 * n + 1], cx, cy)) > ml[n];
+        mask[r * M + n] = !(v | v0 | exceeds);
+    }
+    if (lane == 0) {
+        mask[r * M] = 1;                             // the depot can always be visited
+        if (STEP) {
+            if (a == 0) vis[0] = 1;
+            tour_len[r] = tl;
+            if (prize_tot) prize_tot[r] = prize_tot[r] + prize[(r % B) * M + a];
+            const int64_t i = istep[r];
+            done[r] = (a == 0 && i > 0) ? 1 : 0;
+            cur[r] = a;
+            istep[r] = i + 1;
+        }
+    }
+}
+
+// OPEnv._get_reward: lane tree over the steps of prize[a_t]
+__global__ __launch_bounds__(EB) void k_op_reward(const float* prize, const int64_t* actions, float* reward, int64_t R,
+                                                  int64_t B, int M, int T)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* pz = prize + (r % B) * (int64_t)M;
+    const int64_t* act = actions + r * T;
+    float total = 0.0f;
+    for (int b0 = 0; b0 < T; b0 += 64) {
+        const int t = b0 + lane;
+        int64_t a = t < T ? act[t] : 0;
+        a = a < 0 ? 0 : (a >= M ? M - 1 : a);
+        const float s = wave_tree_sum(t < T ? pz[a] : 0.0f);
+        total = (b0 == 0) ? s : total + s;
+    }
+    if (lane == 0) reward[r] = total;
+}
+
+// OPEnv.check_solution_validity (op/env.py:179-212): one wavefront per row
+__global__ __launch_bounds__(EB) void k_check_op(const int64_t* actions, const float* locs, const float* maxlen, int64_t R,
+                                                 int64_t B, int M, int T, int32_t* bad)
+{
+    __shared__ uint32_t seen_all[ROWS_PER_BLOCK][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wv;
+    if (r >= R) return;
+    uint32_t* seen = seen_all[wv];
+    for (int i = lane; i < 128; i += 64) seen[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t* act = actions + r * T;
+    const float* L = locs + (r % B) * (int64_t)M * 2;
+    int bad_lane = 0;
+    float length = 0.0f;
+    for (int b0 = 0; b0 < T; b0 += 64) {
+        const int t = b0 + lane;
+        float d = 0.0f;
+        if (t < T) {
+            int64_t a0 = act[t], a1 = act[(t + 1 == T) ? 0 : t + 1];
+            if (a0 < 0 || a0 >= M) { bad_lane = 1; a0 = 0; }
+            else if (a0 != 0) {
+                const uint32_t bit = 1u << (a0 & 31);
+                if (atomicOr(&seen[a0 >> 5], bit) & bit) bad_lane = 1;
+            }
+            a1 = a1 < 0 ? 0 : (a1 >= M ? M - 1 : a1);
+            d = dist2(L[2 * a1], L[2 * a1 + 1], L[2 * a0], L[2 * a0 + 1]);
+        }
+        const float s = wave_tree_sum(d);
+        length = (b0 == 0) ? s : length + s;
+    }
+    const bool invalid = __ballot(bad_lane != 0) != 0ull;
+    int ex = 0;
+    const float* ml = maxlen + (r % B) * (int64_t)M;
+    for (int n = lane; n < M; n += 64) {
+        const float lim = ((ml[n] + dist2(L[0], L[1], L[2 * n], L[2 * n + 1])) + 1e-6f) + 1e-5f;
+        ex |= !(length <= lim);
+    }
+    const bool over = __ballot(ex != 0) != 0ull;
+    if (lane != 0) return;
+    if (invalid) { atomicAdd(&bad[0], 1); return; }
+    if (over) atomicAdd(&bad[1], 1);
+}
+
 // PCTSP: one wavefront per row.  STEP = 0: mask only; STEP = 1: collect prize (and penalty), mark visited, then mask.
 // prize / penalty [B][M] with a zero depot slot; pen_tot / penalty may be null together.
 template <int STEP>
@@ -461,6 +578,33 @@ int launch_sdvrp(float* rem, float* used, const float* vcap, int64_t* cur, const
     else
         hipLaunchKernelGGL(k_sdvrp_step_mask<0>, dim3(row_blocks(R)), dim3(EB), 0, st, rem, used, vcap, cur, action, mask,
                            done, R, M);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_op(uint8_t* visited, float* tour_len, float* prize_tot, const float* prize, const float* locs, const float* maxlen,
+              int64_t* cur, int64_t* istep, const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int M,
+              hipStream_t st)
+{
+    if (action)
+        hipLaunchKernelGGL(k_op_step_mask<1>, dim3(row_blocks(R)), dim3(EB), 0, st, visited, tour_len, prize_tot, prize, locs,
+                           maxlen, cur, istep, action, mask, done, R, B, M);
+    else
+        hipLaunchKernelGGL(k_op_step_mask<0>, dim3(row_blocks(R)), dim3(EB), 0, st, visited, tour_len, prize_tot, prize, locs,
+                           maxlen, cur, istep, action, mask, done, R, B, M);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_op_reward(const float* prize, const int64_t* actions, float* reward, int64_t R, int64_t B, int M, int T,
+                     hipStream_t st)
+{
+    hipLaunchKernelGGL(k_op_reward, dim3(row_blocks(R)), dim3(EB), 0, st, prize, actions, reward, R, B, M, T);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_op_check(const int64_t* actions, const float* locs, const float* maxlen, int64_t R, int64_t B, int M, int T,
+                    int32_t* bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_op, dim3(row_blocks(R)), dim3(EB), 0, st, actions, locs, maxlen, R, B, M, T, bad);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 

@@ -41,8 +41,9 @@ __device__ unsigned long long g_stamps[8];
 #define STAMP(i) do { } while (0)
 #endif
 
-// TM: episode length bound (2M+1 steps for TSP / CVRP, 3M+1 for SDVRP); SDF: floats of the SDVRP-only arrays
-template <int CP, int TM, int SDF>
+// TM: episode length bound (2M+1 steps for TSP / CVRP, 3M+1 for SDVRP); SDF: floats of the SDVRP-only arrays;
+// XYF: node slots of the OP-only coordinate array
+template <int CP, int TM, int SDF, int XYF>
 struct ResLds {
     static constexpr int WROW = 4 * CP + 4;     // floats per head row of w (chunk-padded, +4 spreads banks)
     float q[RE];
@@ -56,6 +57,7 @@ struct ResLds {
     int16_t act_out[TM];                        // selected actions of the episode
     float dynv[3 * SDF];                        // SDVRP: dynamic-embedding vectors wk | wv | lw
     float partR[RH];                            // SDVRP: R_h = lane-tree sum of w * rem
+    float xy[2 * XYF];                          // OP: node coordinates
     int done;
     uint8_t msk[RNP];
     uint8_t vis[RNP];
@@ -71,14 +73,16 @@ struct ResLds {
 // over the register-resident, never modified K / V / Lp.
 constexpr int res_tmax(int env) { return (env == EAMRL_ENV_SDVRP ? 3 : 2) * RNP + 2; }
 constexpr int res_sdf(int env) { return env == EAMRL_ENV_SDVRP ? RE : 4; }
+constexpr int res_xyf(int env) { return env == EAMRL_ENV_OP ? RNP : 2; }
 
 template <int ENV, int CP, int CR, bool MS>
 __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, int G)
 {
     constexpr bool SD = ENV == EAMRL_ENV_SDVRP;
     constexpr bool PC = ENV == EAMRL_ENV_PCTSP;     // prize collecting: dem = real_prize, used = collected prize
+    constexpr bool OP = ENV == EAMRL_ENV_OP;        // orienteering: dem = arrival limit per node, used = tour length
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using L = ResLds<CP, res_tmax(ENV), res_sdf(ENV)>;
+    using L = ResLds<CP, res_tmax(ENV), res_sdf(ENV), res_xyf(ENV)>;
     L& l = *reinterpret_cast<L*>(smem);
     float* Plds = reinterpret_cast<float*>(smem + ((sizeof(L) + 15) & ~size_t(15)));
     constexpr int WROW = L::WROW;
@@ -154,8 +158,12 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
     // ---- state: mask / visited in LDS; the scalar row state lives in wavefront 0 -----------------------------------------
     if (tid < RNP) {
         l.msk[tid] = (tid < M) ? a.mask[r * M + tid] : 0;
-        l.vis[tid] = ((ENV == EAMRL_ENV_CVRP || PC) && tid < M) ? a.visited[r * M + tid] : 0;
-        if (PC) l.dem[tid] = (tid < M) ? a.demand[bi * M + tid] : 0.0f;
+        l.vis[tid] = ((ENV == EAMRL_ENV_CVRP || PC || OP) && tid < M) ? a.visited[r * M + tid] : 0;
+        if (PC || OP) l.dem[tid] = (tid < M) ? a.demand[bi * M + tid] : 0.0f;
+        if (OP) {
+            l.xy[2 * tid] = (tid < M) ? a.locs[(bi * M + tid) * 2] : 0.0f;
+            l.xy[2 * tid + 1] = (tid < M) ? a.locs[(bi * M + tid) * 2 + 1] : 0.0f;
+        }
         if (ENV == EAMRL_ENV_CVRP) l.dem[tid] = (tid < M - 1) ? a.demand[bi * (M - 1) + tid] : 0.0f;
         if (SD) l.dem[tid] = (tid < M) ? a.rem[r * M + tid] : 0.0f;
     }
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         cur = a.cur[r];
         if (ENV == EAMRL_ENV_TSP) { first = a.first[r]; istep = a.istep[r]; }
         else { used = a.used[r]; vcap = a.vcap[r]; }
-        if (PC) { istep = a.istep[r]; i0 = istep; }
+        if (PC || OP) { istep = a.istep[r]; i0 = istep; }
         // remaining feasible (TSP) / visited (CVRP; PCTSP: visited customers) node count, kept incrementally
         // (== the reference's mask.sum / visited.sum)
         const int c0 = (ENV == EAMRL_ENV_TSP) ? (in0 && l.msk[n0] != 0) : (in0 && l.vis[n0] != 0 && !(PC && n0 == 0));
@@ -403,6 +411,32 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                 if (lane == 0) { l.msk[sel] = 0; l.done = done; }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) l.q[lane + 64 * k] = (p1f[k] + Plds[cur * RE + lane + 64 * k]) + gq[k];
+            } else if (OP) {
+                // OPEnv._step + get_action_mask (op/env.py:69-102,149-165)
+                const float cx = l.xy[2 * sel], cy = l.xy[2 * sel + 1];
+                {
+                    const float dx = cx - l.xy[2 * cur], dy = cy - l.xy[2 * cur + 1];
+                    used = used + __builtin_sqrtf(fma_(dy, dy, dx * dx));
+                }
+                done = (sel == 0) && (istep > 0);
+                cur = sel;
+                istep += 1;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) { l.vis[sel] = 1; l.done = done; }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 2; ++k) l.q[lane + 64 * k] = fma_(cv[k], vcap - used, Plds[cur * RE + lane + 64 * k]) + gq[k];
+                const int v0 = l.vis[0] != 0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int nn = lane + 64 * k;
+                    if (nn >= 1 && nn < M) {
+                        const float dx = l.xy[2 * nn] - cx, dy = l.xy[2 * nn + 1] - cy;
+                        const int exceeds = (used + __builtin_sqrtf(fma_(dy, dy, dx * dx))) > l.dem[nn];
+                        l.msk[nn] = !((l.vis[nn] != 0) | v0 | exceeds);
+                    }
+                }
+                if (lane == 0) l.msk[0] = 1;
             } else if (PC) {
                 // PCTSPEnv._step + get_action_mask (pctsp/env.py:64-97,156-163)
                 used = used + l.dem[sel];
@@ -503,7 +537,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
     }
     if (tid < M) {
         a.mask[r * M + tid] = l.msk[tid];
-        if (ENV == EAMRL_ENV_CVRP || PC) a.visited[r * M + tid] = l.vis[tid];
+        if (ENV == EAMRL_ENV_CVRP || PC || OP) a.visited[r * M + tid] = l.vis[tid];
         if (SD) a.rem[r * M + tid] = l.dem[tid];
     }
     if (wv == fw && lane == 0) {
@@ -511,7 +545,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         a.done[r] = done ? 1 : 0;
         if (ENV == EAMRL_ENV_TSP) { a.first[r] = first; a.istep[r] = istep; }
         else a.used[r] = used;
-        if (PC) a.istep[r] = i0;          // launch_rollout_pad adds the batch's step count
+        if (PC || OP) a.istep[r] = i0;    // launch_rollout_pad adds the batch's step count
         atomicMax(a.steps_out, t);
         if (!done) st_flags |= EAMRL_ST_STEP_OVERRUN;
         if (st_flags) atomicOr(a.status, st_flags);
@@ -523,7 +557,8 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
 template <int ENV, int CP, int CR, bool MS>
 int launch_ms(const DecArgs& a, int S, int G, hipStream_t st)
 {
-    const size_t lds = ((sizeof(ResLds<CP, res_tmax(ENV), res_sdf(ENV)>) + 15) & ~size_t(15)) + (size_t)a.M * RE * sizeof(float);
+    const size_t lds = ((sizeof(ResLds<CP, res_tmax(ENV), res_sdf(ENV), res_xyf(ENV)>) + 15) & ~size_t(15)) +
+                       (size_t)a.M * RE * sizeof(float);
     auto k = k_rollout_resident<ENV, CP, CR, MS>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -587,7 +622,8 @@ int launch_rollout_resident(int env, const DecArgs& a, hipStream_t st)
 {
     return env == EAMRL_ENV_TSP ? launch_env<EAMRL_ENV_TSP>(a, st)
          : env == EAMRL_ENV_CVRP ? launch_env<EAMRL_ENV_CVRP>(a, st)
-         : env == EAMRL_ENV_SDVRP ? launch_env<EAMRL_ENV_SDVRP>(a, st) : launch_env<EAMRL_ENV_PCTSP>(a, st);
+         : env == EAMRL_ENV_SDVRP ? launch_env<EAMRL_ENV_SDVRP>(a, st)
+         : env == EAMRL_ENV_PCTSP ? launch_env<EAMRL_ENV_PCTSP>(a, st) : launch_env<EAMRL_ENV_OP>(a, st);
 }
 
 }  // namespace eamrl

@@ -156,6 +156,50 @@ class PCTSPGenerator(Generator):
                            "stochastic_prize": stochastic_prize}, batch_size=batch_size)
 
 
+class OPGenerator(Generator):
+    """locs, depot, prize (by default 1 + floor(99 * distance to depot / max distance), in hundredths), max_length
+    (op/generator.py:19-147).  Only prize_type in {"dist", "unif", "const"} with the uniform location sampler."""
+
+    def __init__(self, num_loc: int = 20, min_loc: float = 0.0, max_loc: float = 1.0, loc_distribution="uniform",
+                 depot_distribution=None, min_prize: float = 1.0, max_prize: float = 1.0, prize_distribution="uniform",
+                 prize_type: str = "dist", max_length=None, **kwargs):
+        self.num_loc, self.min_loc, self.max_loc = num_loc, min_loc, max_loc
+        self.min_prize, self.max_prize, self.prize_type = min_prize, max_prize, prize_type
+        self.loc_sampler = kwargs.get("loc_sampler") or get_sampler("loc", loc_distribution, min_loc, max_loc, **kwargs)
+        self.depot_sampler = kwargs.get("depot_sampler") or (
+            get_sampler("depot", depot_distribution, min_loc, max_loc, **kwargs) if depot_distribution is not None else None)
+        # the reference also builds a prize sampler here that _generate never reads (and whose default Uniform(1, 1)
+        # recent torch versions reject); it is not needed
+        self.max_length = max_length if max_length is not None else MAX_LENGTHS.get(num_loc, None)
+        if self.max_length is None:
+            closest = min(MAX_LENGTHS, key=lambda x: abs(x - num_loc))
+            self.max_length = MAX_LENGTHS[closest]
+            log.warning("The max length for %d locations is not defined. Using the closest max length: %s with %d "
+                        "locations.", num_loc, self.max_length, closest)
+
+    def _generate(self, batch_size):
+        if self.depot_sampler is not None:
+            depot = self.depot_sampler.sample((*batch_size, 2))
+            locs = self.loc_sampler.sample((*batch_size, self.num_loc, 2))
+        else:
+            pts = self.loc_sampler.sample((*batch_size, self.num_loc + 1, 2))
+            depot, locs = pts[..., 0, :], pts[..., 1:, :]
+        locs_with_depot = torch.cat((depot.unsqueeze(1), locs), dim=1)
+        if self.prize_type == "const":
+            prize = torch.ones(*batch_size, self.num_loc)
+        elif self.prize_type == "unif":
+            prize = (1 + torch.randint(0, 100, (*batch_size, self.num_loc)).float()) / 100
+        elif self.prize_type == "dist":
+            prize = (locs_with_depot[..., 0:1, :] - locs_with_depot[..., 1:, :]).norm(p=2, dim=-1)
+            prize = (1 + (prize / prize.max(dim=-1, keepdim=True)[0] * 99).int()).float() / 100
+        else:
+            raise ValueError(f"Invalid prize_type: {self.prize_type}")
+        max_length = self.max_length if isinstance(self.max_length, torch.Tensor) else torch.full((*batch_size,),
+                                                                                                 self.max_length)
+        return TensorDict({"locs": locs_with_depot[..., 1:, :], "depot": locs_with_depot[..., 0, :], "prize": prize,
+                           "max_length": max_length}, batch_size=batch_size)
+
+
 # --------------------------------------------------------------------------------------------------------
 class TensorDictDataset(torch.utils.data.Dataset):
     """List-of-dicts dataset with the reference's collate contract (rl4co/data/dataset.py:43-75)."""
@@ -263,13 +307,17 @@ class RL4COEnvBase:
 
     def get_num_starts(self, td):
         n = td["action_mask"].shape[-1]
-        return n - 1 if self.name in ("cvrp", "sdvrp", "pctsp") else n          # depot cannot be a start node (utils/ops.py:120-130)
+        return n - 1 if self.name in ("cvrp", "sdvrp", "pctsp", "op") else n          # depot cannot be a start node (utils/ops.py:120-130)
 
     def select_start_nodes(self, td, num_starts):
         """POMO start nodes: flat row j = s*B + b starts at node s (+1 with a depot) (utils/ops.py:133-169)."""
         num_loc = getattr(self.generator, "num_loc", 0xFFFFFFFF)
         sel = torch.arange(num_starts, device=td.device).repeat_interleave(td.shape[0]) % num_loc
-        return sel + 1 if self.name in ("cvrp", "sdvrp", "pctsp") else sel
+        if self.name == "op" and bool((td["action_mask"][..., 1:].float().sum(-1) < num_starts).any()):
+            # some customers are out of reach from the start: resample among the reachable ones (utils/ops.py:158-169)
+            sel = torch.multinomial(td["action_mask"][..., 1:].float(), num_starts, replacement=True) + 1
+            return sel.t().reshape(-1)                     # "b n -> (n b)"
+        return sel + 1 if self.name in ("cvrp", "sdvrp", "pctsp", "op") else sel
 
     def check_solution_validity(self, td, actions) -> None:
         raise NotImplementedError
@@ -586,12 +634,79 @@ class PCTSPEnv(RL4COEnvBase):
         assert bad[1] == 0, "Total prize does not satisfy min total prize"
 
 
-ENV_REGISTRY = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv}
+class OPEnv(RL4COEnvBase):
+    """Orienteering Problem (rl4co/envs/routing/op/env.py:24-267): collect as much prize as possible on a tour from and
+    to the depot no longer than max_length; a customer stays feasible while it can be reached AND the depot afterwards."""
+
+    name = "op"
+
+    def __init__(self, generator: OPGenerator = None, generator_params: dict = {}, prize_type: str = "dist", **kwargs):
+        super().__init__(**kwargs)
+        self.generator = generator if generator is not None else OPGenerator(**generator_params)
+        self.prize_type = prize_type
+        assert self.prize_type in ["dist", "unif", "const"], f"Invalid prize_type: {self.prize_type}"
+
+    def _reset(self, td=None, batch_size=None):
+        dev = td.device
+        locs = torch.cat((td["depot"][:, None, :], td["locs"]), -2)
+        # per-node arrival limit: max length minus the way back to the depot, minus an epsilon (env.py:122-126);
+        # instance preparation, evaluated with the reference's own torch expression
+        max_length = td["max_length"][..., None] - (td["depot"][..., None, :] - locs).norm(p=2, dim=-1) - 1e-6
+        out = TensorDict({
+            "locs": locs,
+            "prize": torch.nn.functional.pad(td["prize"], (1, 0), mode="constant", value=0),
+            "tour_length": torch.zeros(*batch_size, dtype=torch.float32, device=dev),
+            "max_length": max_length,
+            "current_node": torch.zeros(*batch_size, 1, dtype=torch.int64, device=dev),
+            "visited": torch.zeros(*batch_size, locs.shape[-2], dtype=torch.bool, device=dev),
+            "current_total_prize": torch.zeros(*batch_size, dtype=torch.float32, device=dev),
+            "i": torch.zeros(*batch_size, dtype=torch.int64, device=dev),
+        }, batch_size=batch_size)
+        # reset-state mask in closed form (at the depot, nothing visited, length 0)  (env.py:149-165)
+        exceeds = (locs - locs[..., 0:1, :]).norm(p=2, dim=-1) > max_length
+        mask = ~exceeds
+        mask[..., 0] = True
+        out.set("action_mask", mask)
+        return out
+
+    def _step(self, td):
+        mask = td["action_mask"]
+        if not mask.is_contiguous():
+            mask = mask.contiguous()
+        done = _flat(td["done"], torch.bool)
+        ops.op_step_mask_(td["visited"], _flat(td["tour_length"], torch.float32),
+                          _flat(td["current_total_prize"], torch.float32), td["prize"].contiguous(), td["locs"].contiguous(),
+                          td["max_length"].contiguous(), _flat(td["current_node"], torch.int64), _flat(td["i"], torch.int64),
+                          td["action"].reshape(-1).contiguous(), mask, done)
+        td.update({"action_mask": mask, "done": done, "reward": torch.zeros_like(done)})
+        return td
+
+    def get_action_mask(self, td):
+        mask = torch.empty(td["visited"].shape, dtype=torch.bool, device=td["visited"].device)
+        ops.op_step_mask_(td["visited"], _flat(td["tour_length"], torch.float32), None, None, td["locs"].contiguous(),
+                          td["max_length"].contiguous(), _flat(td["current_node"], torch.int64), None, None, mask)
+        return mask
+
+    def _get_reward(self, td, actions):
+        if actions.size(-1) == 1:       # all tours return to the depot at once (env.py:169-172)
+            assert bool((actions == 0).all()), "If all length 1 tours, they should be zero"
+            return torch.zeros(actions.size(0), dtype=torch.float32, device=actions.device)
+        return ops.op_reward(td["prize"].contiguous(), actions.contiguous())
+
+    def check_solution_validity(self, td, actions, add_distance_to_depot: bool = True) -> None:
+        if not add_distance_to_depot:
+            raise NotImplementedError("add_distance_to_depot=False is not built for MI355X")
+        bad = ops.op_check_solution(actions.contiguous(), td["locs"].contiguous(), td["max_length"].contiguous()).tolist()
+        assert bad[0] == 0, "Duplicates"
+        assert bad[1] == 0, "Max length exceeded"
+
+
+ENV_REGISTRY = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv}
 
 
 def get_env(env_name: str, *args, **kwargs) -> RL4COEnvBase:
     cls = ENV_REGISTRY.get(env_name)
     if cls is None:
         raise ValueError(f"Unknown environment {env_name}. Available environments: {list(ENV_REGISTRY)} "
-                         "(only the TSP / CVRP / SDVRP / PCTSP rollout path is built for MI355X)")
+                         "(only the TSP / CVRP / SDVRP / PCTSP / OP rollout path is built for MI355X)")
     return cls(*args, **kwargs)

@@ -8,11 +8,11 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ENV_CVRP, ENV_PCTSP, ENV_SDVRP, ENV_TSP, EVALUATE, GREEDY, NORM_BATCH_EVAL, NORM_INSTANCE, SAMPLE,  # noqa: F401
+from ._lib import (ENV_CVRP, ENV_OP, ENV_PCTSP, ENV_SDVRP, ENV_TSP, EVALUATE, GREEDY, NORM_BATCH_EVAL, NORM_INSTANCE, SAMPLE,  # noqa: F401
                    ST_INFEASIBLE, ST_NAN_LOGITS, ST_STEP_OVERRUN)
 
 MODES = {"greedy": GREEDY, "sampling": SAMPLE, "evaluate": EVALUATE}
-ENVS = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP, "pctsp": ENV_PCTSP}
+ENVS = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP, "pctsp": ENV_PCTSP, "op": ENV_OP}
 
 
 def _need_gpu(t: torch.Tensor, name: str):
@@ -256,6 +256,61 @@ def pctsp_step_mask_(visited, prize_tot, pen_tot, prize, penalty, cur, istep, ac
     return mask
 
 
+def op_step_mask_(visited, tour_len, prize_tot, prize, locs, maxlen, cur, istep, action, mask, done=None):
+    """OPEnv._step + get_action_mask in place (op/env.py:69-102,149-165); action None: mask only."""
+    lib = _lib.load()
+    R, M = visited.shape
+    _chk(locs, "locs", torch.float32)
+    B = locs.shape[0]
+    if tuple(locs.shape) != (B, M, 2) or R % B:
+        raise ValueError("op_step: locs must be [B, M, 2] with R a multiple of B")
+    _chk(_bytes(visited), "visited", torch.uint8, (R, M))
+    _chk(tour_len, "tour_length", torch.float32, (R,))
+    _chk(maxlen, "max_length", torch.float32, (B, M))
+    _chk(cur, "current_node", torch.int64, (R,))
+    _chk(mask, "action_mask", torch.bool, (R, M))
+    if action is not None:
+        _chk(istep, "i", torch.int64, (R,))
+        _chk(action, "action", torch.int64, (R,))
+        _chk(done, "done", torch.bool, (R,))
+        if prize_tot is not None:
+            _chk(prize_tot, "current_total_prize", torch.float32, (R,))
+            _chk(prize, "prize", torch.float32, (B, M))
+    _lib.check(lib.eamrl_op_step_mask(_ptr(_bytes(visited)), _ptr(tour_len), _ptr(prize_tot), _ptr(prize), _ptr(locs),
+                                      _ptr(maxlen), _ptr(cur), _ptr(istep), _ptr(action), _ptr(_bytes(mask)),
+                                      _ptr(_bytes(done)) if done is not None else None, R, B, M, _stream(mask)),
+               "eamrl_op_step_mask")
+    return mask
+
+
+def op_reward(prize, actions):
+    """OPEnv._get_reward (op/env.py:167-177): the collected prize."""
+    lib = _lib.load()
+    _chk(prize, "prize", torch.float32)
+    B, M = prize.shape
+    _chk(actions, "actions", torch.int64)
+    R, T = actions.shape
+    if R % B:
+        raise ValueError("actions rows must be a multiple of the number of instances")
+    out = torch.empty(R, dtype=torch.float32, device=prize.device)
+    _lib.check(lib.eamrl_op_reward(_ptr(prize), _ptr(actions), _ptr(out), R, B, M, T, _stream(prize)), "eamrl_op_reward")
+    return out
+
+
+def op_check_solution(actions, locs, maxlen):
+    """-> device int32[2]: (rows with a customer visited twice, rows longer than allowed)  (op/env.py:179-212)."""
+    lib = _lib.load()
+    _chk(actions, "actions", torch.int64)
+    _chk(locs, "locs", torch.float32)
+    B, M, _ = locs.shape
+    _chk(maxlen, "max_length", torch.float32, (B, M))
+    R, T = actions.shape
+    bad = torch.zeros(2, device=actions.device, dtype=torch.int32)
+    _lib.check(lib.eamrl_op_check_solution(_ptr(actions), _ptr(locs), _ptr(maxlen), R, B, M, T, _ptr(bad),
+                                           _stream(actions)), "eamrl_op_check_solution")
+    return bad
+
+
 def pctsp_reward(locs, penalty, actions):
     """PCTSPEnv._get_reward (pctsp/env.py:165-187): saved penalties - (tour length + all penalties)."""
     lib = _lib.load()
@@ -481,10 +536,11 @@ class RolloutState:
         self.mask = torch.ones(R, M, dtype=torch.bool, device=device)
         self.used = self.vcap = self.visited = self.rem = None
         self.demand = demand
-        if env_name in ("cvrp", "sdvrp", "pctsp"):
-            self.used = torch.zeros(R, dtype=torch.float32, device=device)     # pctsp: cur_total_prize
-            self.vcap = torch.ones(R, dtype=torch.float32, device=device)      # pctsp: prize_required
-        if env_name in ("cvrp", "pctsp"):
+        self.locs = None                                                       # op: node coordinates [B, M, 2]
+        if env_name in ("cvrp", "sdvrp", "pctsp", "op"):
+            self.used = torch.zeros(R, dtype=torch.float32, device=device)     # pctsp: cur_total_prize; op: tour_length
+            self.vcap = torch.ones(R, dtype=torch.float32, device=device)      # pctsp: prize_required; op: max_length[:, 0]
+        if env_name in ("cvrp", "pctsp", "op"):
             self.visited = torch.zeros(R, M, dtype=torch.uint8, device=device)
         if env_name == "sdvrp":
             self.rem = torch.zeros(R, M, dtype=torch.float32, device=device)   # demand_with_depot
@@ -504,6 +560,7 @@ class RolloutState:
         s.mask, s.done = _ptr(_bytes(self.mask)), _ptr(_bytes(self.done))
         s.visited = _ptr(None if self.visited is None else _bytes(self.visited))
         s.rem = _ptr(getattr(self, "rem", None))
+        s.locs = _ptr(getattr(self, "locs", None))
         return s
 
 
@@ -526,6 +583,11 @@ def _validate_state(st: RolloutState, cache: DecodeCache):
         elif st.env_name == "pctsp":
             _chk(_bytes(st.visited), "visited", torch.uint8, (R, M))
             _chk(st.demand, "real_prize", torch.float32, (cache.B, M))
+            _chk(st.istep, "i", torch.int64, (R,))
+        elif st.env_name == "op":
+            _chk(_bytes(st.visited), "visited", torch.uint8, (R, M))
+            _chk(st.demand, "max_length", torch.float32, (cache.B, M))
+            _chk(st.locs, "locs", torch.float32, (cache.B, M, 2))
             _chk(st.istep, "i", torch.int64, (R,))
         else:
             _chk(st.visited, "visited", torch.uint8, (R, M))
@@ -564,7 +626,7 @@ def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, giv
     _validate_state(st, cache)
     R, M, dev = st.R, st.M, st.mask.device
     if t_max is None:
-        t_max = {"tsp": M, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1, "pctsp": M + 1}[st.env_name]
+        t_max = {"tsp": M, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1, "pctsp": M + 1, "op": M + 1}[st.env_name]
     t_given = 0
     if noise is not None:
         _chk(noise, "noise", torch.float32)

@@ -70,6 +70,22 @@ class PCTSPInitEmbedding(nn.Module):
         return torch.cat((depot, cust), 1)
 
 
+class OPInitEmbedding(nn.Module):
+    """x, y, prize per customer; depot embedded separately (nn/env_embeddings/init.py:260-286)."""
+
+    def __init__(self, embed_dim, linear_bias=True):
+        super().__init__()
+        self.init_embed = nn.Linear(3, embed_dim, linear_bias)
+        self.init_embed_depot = nn.Linear(2, embed_dim, linear_bias)
+
+    def forward(self, td):
+        locs = td["locs"]
+        depot = ops.linear(locs[:, :1, :].contiguous(), self.init_embed_depot.weight, self.init_embed_depot.bias)
+        feat = torch.cat((locs[:, 1:, :], td["prize"][..., 1:, None]), -1)
+        cust = ops.linear(feat, self.init_embed.weight, self.init_embed.bias)
+        return torch.cat((depot, cust), 1)
+
+
 class _Holder(nn.Module):
     """`.module` wrapper so that parameter names match the reference's SkipConnection(...)."""
 
@@ -173,7 +189,7 @@ class AttentionModelEncoder(nn.Module):
         self.env_name = env_name
         if init_embedding is None:
             init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding, "sdvrp": VRPInitEmbedding,
-                              "pctsp": PCTSPInitEmbedding}[env_name](embed_dim)
+                              "pctsp": PCTSPInitEmbedding, "op": OPInitEmbedding}[env_name](embed_dim)
         self.init_embedding = init_embedding
         self.net = GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden) \
             if net is None else net
@@ -305,6 +321,8 @@ def _env_step_(st: ops.RolloutState, action):
         ops.cvrp_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, action, st.mask, st.done)
     elif st.env_name == "pctsp":
         ops.pctsp_step_mask_(st.visited, st.used, None, st.demand, None, st.cur, st.istep, action, st.mask, st.done)
+    elif st.env_name == "op":
+        ops.op_step_mask_(st.visited, st.used, None, None, st.locs, st.demand, st.cur, st.istep, action, st.mask, st.done)
     else:
         ops.sdvrp_step_mask_(st.rem, st.used, st.vcap, st.cur, action, st.mask, st.done)
 
@@ -312,7 +330,7 @@ def _env_step_(st: ops.RolloutState, action):
 def _max_decode_steps(env_name, M, npre=0):
     """TSP: one step per remaining node; CVRP: every customer visit is followed by at most one depot visit; SDVRP: as
     CVRP plus at most one split delivery per trip."""
-    return {"tsp": M - npre, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1, "pctsp": M + 1}[env_name]
+    return {"tsp": M - npre, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1, "pctsp": M + 1, "op": M + 1}[env_name]
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -349,9 +367,16 @@ def state_from_td(env_name, td, num_starts: int = 0, copy: bool = True) -> ops.R
     st.cur = rep(td["current_node"], torch.int64)
     done = td["done"] if "done" in td.keys() else torch.zeros(B, dtype=torch.bool, device=dev)
     st.done = rep(done, torch.bool)
-    st.first = st.istep = st.used = st.vcap = st.visited = st.demand = st.rem = None
+    st.first = st.istep = st.used = st.vcap = st.visited = st.demand = st.rem = st.locs = None
     if env_name == "tsp":
         st.first = rep(td["first_node"], torch.int64)
+        st.istep = rep(td["i"], torch.int64)
+    elif env_name == "op":          # used = tour length, vcap = the instance's max_length[:, 0], demand = arrival limits
+        st.used = rep(td["tour_length"], torch.float32)
+        st.vcap = rep(td["max_length"][..., 0], torch.float32)
+        st.demand = td["max_length"].contiguous()
+        st.locs = td["locs"].contiguous()
+        st.visited = rep(td["visited"], torch.bool)
         st.istep = rep(td["i"], torch.int64)
     elif env_name == "pctsp":       # used = collected prize, vcap = required prize, demand = prize per node (depot slot 0)
         st.used = rep(td["cur_total_prize"], torch.float32)
@@ -376,6 +401,9 @@ def state_to_td(env_name, st: ops.RolloutState, td, locs_rows=None):
     out = {"action_mask": st.mask, "done": st.done, "reward": torch.zeros_like(st.done)}
     if env_name == "tsp":
         out.update({"first_node": st.first, "current_node": st.cur, "i": st.istep.reshape(R, 1)})
+    elif env_name == "op":
+        # current_total_prize is bookkeeping of env.step only (the reward is recomputed from the actions)
+        out.update({"current_node": st.cur.reshape(R, 1), "tour_length": st.used, "visited": st.visited, "i": st.istep})
     elif env_name == "pctsp":
         # cur_total_penalty is bookkeeping of env.step only (no decision reads it): the fused rollout does not carry it
         out.update({"current_node": st.cur, "cur_total_prize": st.used, "prize_required": st.vcap, "visited": st.visited,
@@ -415,9 +443,9 @@ class AttentionModelPolicy(nn.Module):
             log.error("Found %d unused kwargs: %s", len(unused_kwargs), unused_kwargs)
         if isinstance(env_name, RL4COEnvBase):
             env_name = env_name.name
-        if env_name not in ("tsp", "cvrp", "sdvrp", "pctsp"):
-            raise NotImplementedError(f"env_name={env_name!r}: the MI355X rollout path covers 'tsp', 'cvrp', 'sdvrp' "
-                                      "and 'pctsp'")
+        if env_name not in ("tsp", "cvrp", "sdvrp", "pctsp", "op"):
+            raise NotImplementedError(f"env_name={env_name!r}: the MI355X rollout path covers 'tsp', 'cvrp', 'sdvrp', "
+                                      "'pctsp' and 'op'")
         if moe_kwargs not in (None, {"encoder": None, "decoder": None}) or any(
                 x is not None for x in (sdpa_fn, sdpa_fn_encoder, sdpa_fn_decoder, encoder_network)):
             raise NotImplementedError("MoE / sdpa_fn / encoder_network injection is outside the MI355X rollout path")
@@ -547,7 +575,7 @@ class AttentionModelPolicy(nn.Module):
         # x + 0 is exact in the lane tree), nor the log-likelihood sum, nor validity.
         actions_pad = torch.cat(pre_actions + [acts], 1) if pre_actions else acts
         logp_pad = torch.cat(pre_logps + [lps], 1) if pre_logps else lps
-        native_env = type(env).__name__ in ("TSPEnv", "CVRPEnv", "SDVRPEnv", "PCTSPEnv") and type(env).__module__ == RL4COEnvBase.__module__
+        native_env = type(env).__name__ in ("TSPEnv", "CVRPEnv", "SDVRPEnv", "PCTSPEnv", "OPEnv") and type(env).__module__ == RL4COEnvBase.__module__
         fast = info is not None and native_env and not select_best
         reward_pad = ll_pad = bad = None
         if fast:
@@ -555,12 +583,16 @@ class AttentionModelPolicy(nn.Module):
             if calc_reward:
                 if self.env_name == "pctsp":        # depot padding: zero-length legs and zero penalties, exact
                     reward_pad = ops.pctsp_reward(locs, td["penalty"].contiguous(), actions_pad)
+                elif self.env_name == "op":         # depot padding adds zero prizes
+                    reward_pad = ops.op_reward(td["prize"].contiguous(), actions_pad)
                 else:
                     reward_pad = ops.tour_length_reward(locs, actions_pad, with_depot=(self.env_name != "tsp"))
                 if env.check_solution and self.env_name != "sdvrp":   # sdvrp: replayed on the exact slice in _finish
                     bad = (ops.check_solution("tsp", actions_pad) if self.env_name == "tsp" else
                            ops.check_solution("pctsp", actions_pad, td["real_prize"].contiguous())
                            if self.env_name == "pctsp" else
+                           ops.op_check_solution(actions_pad, locs, td["max_length"].contiguous())
+                           if self.env_name == "op" else
                            ops.check_solution("cvrp", actions_pad, td["demand"].contiguous(), st.vcap))
             if return_sum_log_likelihood and "mask" not in td.keys():
                 ll_pad = ops.sum_logp(logp_pad)
@@ -609,6 +641,9 @@ class AttentionModelPolicy(nn.Module):
                     elif self.env_name == "pctsp":
                         assert bad_counts[0] == 0, "Duplicates"
                         assert bad_counts[1] == 0, "Total prize does not satisfy min total prize"
+                    elif self.env_name == "op":
+                        assert bad_counts[0] == 0, "Duplicates"
+                        assert bad_counts[1] == 0, "Max length exceeded"
                     else:
                         assert bad_counts[0] == 0, "Invalid tour"
                         assert bad_counts[1] == 0, "Used more than capacity"

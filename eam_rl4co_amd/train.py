@@ -45,6 +45,8 @@ def encode_autograd(policy, td):
         depot = F.linear(locs[:, :1], ie.init_embed_depot.weight, ie.init_embed_depot.bias)
         if policy.env_name == "pctsp":
             feat = torch.cat((locs[:, 1:], td["expected_prize"][..., None], td["penalty"][..., 1:, None]), -1)
+        elif policy.env_name == "op":
+            feat = torch.cat((locs[:, 1:], td["prize"][..., 1:, None]), -1)
         else:
             feat = torch.cat((locs[:, 1:], td["demand"][..., None]), -1)
         h = torch.cat((depot, F.linear(feat, ie.init_embed.weight, ie.init_embed.bias)), 1)
@@ -127,6 +129,33 @@ def _pctsp_states(actions, prize_rows, prize_required):
     return torch.stack(curs, 1), torch.stack(rems, 1), torch.stack(masks, 1)
 
 
+def _op_states(actions, locs_rows, maxlen_rows):
+    """-> cur [R,T], length still allowed to the depot's limit [R,T], mask [R,T,M] before each step
+    (op/env.py:69-102,149-165; context.py:211-223).  locs_rows [R,M,2], maxlen_rows [R,M]."""
+    R, T = actions.shape
+    M = locs_rows.shape[1]
+    dev = actions.device
+    visited = torch.zeros(R, M, dtype=torch.bool, device=dev)
+    length = torch.zeros(R, dtype=torch.float32, device=dev)
+    cur = torch.zeros(R, dtype=torch.int64, device=dev)
+    curs, rems, masks = [], [], []
+    ar = torch.arange(R, device=dev)
+    for t in range(T):
+        here = locs_rows[ar, cur]
+        exceeds = length[:, None] + (locs_rows - here[:, None, :]).norm(p=2, dim=-1) > maxlen_rows
+        m = ~(visited | visited[:, :1] | exceeds)
+        m[:, 0] = True
+        masks.append(m)
+        curs.append(cur)
+        rems.append(maxlen_rows[:, 0] - length)
+        a = actions[:, t]
+        length = length + (locs_rows[ar, a] - here).norm(p=2, dim=-1)
+        visited = visited.clone()
+        visited[ar, a] = True
+        cur = a
+    return torch.stack(curs, 1), torch.stack(rems, 1), torch.stack(masks, 1)
+
+
 def _sdvrp_states(actions, demand_rows, vcap, M):
     """-> cur [R,T], free capacity [R,T], mask [R,T,M] and remaining demand [R,T,M] before each step
     (sdvrp/env.py:58-92,137-146)."""
@@ -190,6 +219,9 @@ def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, tempe
             ctx_in = torch.cat((embr[ar, first], embr[ar, cur]), -1)                       # [Rc, T, 2E]
             if not multistart:   # step 0 uses the learned placeholder (context.py:118-131)
                 ctx_in = torch.cat((dec.context_embedding.W_placeholder.expand(Rc, 1, 2 * E), ctx_in[:, 1:]), 1)
+        elif policy.env_name == "op":
+            cur, rem, mask = _op_states(act, rep(td["locs"]), rep(td["max_length"]))
+            ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)                          # [Rc, T, E+1]
         elif policy.env_name == "pctsp":
             cur, rem, mask = _pctsp_states(act, rep(td["real_prize"]), rep(td["prize_required"].reshape(-1)))
             ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)                          # [Rc, T, E+1]

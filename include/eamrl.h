@@ -36,6 +36,7 @@ extern "C" {
 #define EAMRL_ENV_CVRP 1
 #define EAMRL_ENV_SDVRP 2 /* split delivery: CVRP instances, customers may be served in several visits */
 #define EAMRL_ENV_PCTSP 3 /* prize collecting TSP: return to the depot once the collected prize reaches 1 */
+#define EAMRL_ENV_OP 4    /* orienteering: collect prizes within a maximum tour length */
 /* selection modes  [rl4co/utils/decoding.py:430-465] */
 #define EAMRL_GREEDY 0
 #define EAMRL_SAMPLE 1   /* argmax(p / noise), noise ~ Exp(1) supplied by the caller (== torch.multinomial) */
@@ -96,6 +97,17 @@ int eamrl_sdvrp_step_mask(float* rem, float* used, const float* vcap, int64_t* c
 int eamrl_pctsp_step_mask(uint8_t* visited, float* prize_tot, float* pen_tot, const float* prize, const float* penalty,
                           int64_t* cur, int64_t* istep, const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R,
                           int64_t B, int M, void* stream);
+
+/* OPEnv._step + get_action_mask  [rl4co/envs/routing/op/env.py:69-102,149-165].  In place.
+ * visited [R][M] u8, tour_len [R] f32, prize_tot [R] f32 (current_total_prize) or NULL with prize [B][M] (zero depot
+ * slot), locs [B][M][2] f32 (depot first), maxlen [B][M] f32 (the reset state's per-node arrival limit: max_length -
+ * distance to the depot - 1e-6), cur / istep [R] i64, mask [R][M] u8, done [R] u8.  action == NULL: mask only.
+ * A customer is feasible until visited, until the depot was visited and while tour_len + distance(cur, n) <= maxlen[n];
+ * the depot is always feasible; done = (action == depot and istep > 0).  Distances are sqrtf(fmaf(dy, dy, dx*dx)),
+ * which is what torch's norm(p=2, dim=-1) computes for two components. */
+int eamrl_op_step_mask(uint8_t* visited, float* tour_len, float* prize_tot, const float* prize, const float* locs,
+                       const float* maxlen, int64_t* cur, int64_t* istep, const int64_t* action, uint8_t* mask,
+                       uint8_t* done, int64_t R, int64_t B, int M, void* stream);
 
 /* ---- one-shot encoder + cache ------------------------------------------------------------------- */
 
@@ -159,13 +171,14 @@ typedef struct eamrl_state {
     int64_t* first;    /* [R] TSP first_node */
     int64_t* cur;      /* [R] current_node */
     int64_t* istep;    /* [R] TSP i */
-    float* used;       /* [R] CVRP / SDVRP used_capacity; PCTSP cur_total_prize */
-    const float* vcap; /* [R] CVRP / SDVRP vehicle_capacity; PCTSP prize_required */
-    const float* demand; /* [B][N] CVRP demand; PCTSP: [B][M] real_prize with a zero depot slot */
+    float* used;       /* [R] CVRP / SDVRP used_capacity; PCTSP cur_total_prize; OP tour_length */
+    const float* vcap; /* [R] CVRP / SDVRP vehicle_capacity; PCTSP prize_required; OP max_length[:, 0] of the row's instance */
+    const float* demand; /* [B][N] CVRP demand; PCTSP: [B][M] real_prize with a zero depot slot; OP: [B][M] max_length */
     uint8_t* mask;     /* [R][M] action_mask (1 = feasible) */
     uint8_t* visited;  /* [R][M] CVRP visited */
     uint8_t* done;     /* [R] */
     float* rem;        /* [R][M] SDVRP demand_with_depot (remaining demand), else NULL */
+    const float* locs; /* [B][M][2] OP node coordinates (depot first), else NULL */
 } eamrl_state;
 
 /* One decode step for R rows = AttentionModelDecoder.forward + DecodingStrategy.step
@@ -204,6 +217,15 @@ int eamrl_tour_length(const float* locs, const int64_t* actions, float* reward, 
  * sum of all penalties).  locs [B][M][2], penalty [B][M] (zero depot slot), actions [R][T]. */
 int eamrl_pctsp_reward(const float* locs, const float* penalty, const int64_t* actions, float* reward, int64_t R, int64_t B,
                        int M, int T, void* stream);
+
+/* OPEnv._get_reward  [op/env.py:167-177]: reward[r] = sum_t prize[a_t] (lane tree over the steps).  prize [B][M]. */
+int eamrl_op_reward(const float* prize, const int64_t* actions, float* reward, int64_t R, int64_t B, int M, int T,
+                    void* stream);
+
+/* OPEnv.check_solution_validity  [op/env.py:179-212]: bad[0] += rows with a customer visited twice, bad[1] += rows whose
+ * closed length over the actions exceeds ((maxlen[n] + distance(depot, n)) + 1e-6) + 1e-5 for some node n. */
+int eamrl_op_check_solution(const int64_t* actions, const float* locs, const float* maxlen, int64_t R, int64_t B, int M,
+                            int T, int32_t* bad, void* stream);
 
 /* out[r] = sum_t logp[r][t], sequential  (get_log_likelihood, utils/decoding.py:38-64) */
 int eamrl_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, void* stream);

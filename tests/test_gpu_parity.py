@@ -59,6 +59,15 @@ def make_td(env_name, locs, demand=None):
     env = ea.get_env(env_name, generator_params=dict(num_loc=locs.shape[1] - (env_name != "tsp")))
     if env_name == "tsp":
         td = ea.TensorDict({"locs": torch.from_numpy(locs)}, batch_size=[locs.shape[0]])
+    elif env_name == "op":          # demand: {"prize" [B,M], "max_length" [B,M]} of the post-reset state
+        B = locs.shape[0]
+        # generator-style td; the per-node limits and prizes of the fixture replace what reset derives from them
+        td = ea.TensorDict({"locs": torch.from_numpy(locs[:, 1:]), "depot": torch.from_numpy(locs[:, 0]),
+                            "prize": torch.from_numpy(demand["prize"][:, 1:]),
+                            "max_length": torch.full((B,), float(env.generator.max_length))}, batch_size=[B])
+        td = env.reset(td)
+        assert np.array_equal(td["max_length"].numpy(), demand["max_length"])        # reset == the reference's reset
+        return env, td.to(DEV)
     elif env_name == "pctsp":       # demand: the dict of prize tensors (tests/_util.py instance_of)
         td = ea.TensorDict({"locs": torch.from_numpy(locs[:, 1:]), "depot": torch.from_numpy(locs[:, 0]),
                             "deterministic_prize": torch.from_numpy(demand["expected_prize"]),
@@ -208,7 +217,8 @@ def test_encoder_and_cache_bit_exact(oracle, name):
 STEP_CASES = ["tsp20_greedy", "tsp100_greedy", "cvrp20_greedy", "cvrp100_greedy", "cvrp100_sampling",
               "tsp20_multistart_greedy", "cvrp20_multistart_greedy", "pomo_tsp20_multistart_sampling",
               "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy",
-              "pctsp20_greedy", "pctsp20_sampling", "pctsp100_sampling", "pctsp20_multistart_greedy"]
+              "pctsp20_greedy", "pctsp20_sampling", "pctsp100_sampling", "pctsp20_multistart_greedy",
+              "op20_greedy", "op20_sampling", "op100_sampling", "op20_multistart_greedy"]
 
 
 @pytest.mark.parametrize("name", STEP_CASES)
@@ -263,9 +273,9 @@ def test_decode_step_api_bit_exact_every_step(oracle, name):
         elif env_name == "cvrp":
             assert_bits_equal(st.visited, ost.visited, "visited")
             assert_bits_equal(st.used, ost.used, "used")
-        elif env_name == "pctsp":
+        elif env_name in ("pctsp", "op"):
             assert_bits_equal(st.visited.to(torch.uint8), ost.visited, "visited")
-            assert_bits_equal(st.used, ost.used, "collected prize")
+            assert_bits_equal(st.used, ost.used, "collected prize / tour length")
             assert_bits_equal(st.istep, ost.istep, "i")
         else:
             assert_bits_equal(st.rem, ost.rem, "remaining demand")
@@ -283,7 +293,8 @@ POLICY_CASES = ["tsp20_greedy", "tsp20_sampling", "tsp20_evaluate", "tsp20_multi
                 "cvrp20_sampling_temp", "tsp20_greedy_noclip",
                 "tsp20_sampling_topk5", "tsp20_sampling_topp", "cvrp20_sampling_topk_topp", "tsp100_greedy_topk",
                 "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy",
-                "pctsp20_greedy", "pctsp20_sampling", "pctsp50_greedy", "pctsp100_sampling", "pctsp20_multistart_greedy"]
+                "pctsp20_greedy", "pctsp20_sampling", "pctsp50_greedy", "pctsp100_sampling", "pctsp20_multistart_greedy",
+                "op20_greedy", "op20_sampling", "op50_greedy", "op100_sampling", "op20_multistart_greedy"]
 
 
 @pytest.mark.parametrize("stream_kernel", [0, 1])
@@ -315,6 +326,11 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
             kw[k] = float(fx["decode_kw_" + k])
     if "decode_kw_top_k" in fx:
         kw["top_k"] = int(fx["decode_kw_top_k"])
+    okw = {}
+    if env_name == "op" and ns > 1:     # OP may resample its start nodes at random: replay the recorded ones
+        starts = t(np.ascontiguousarray(fx["actions"][:, 0]))
+        kw["select_start_nodes_fn"] = lambda td_, env_, n_: starts
+        okw["start_nodes"] = fx["actions"][:, 0]
     lib = _lib.load()
     lib.eamrl_debug_set(1, stream_kernel)
     try:
@@ -329,13 +345,13 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
                               noise=fx.get("noise"), given=fx["actions"] if "actions" in kw else None,
                               use_graph_context=pol.decoder.use_graph_context,
                               clip=kw.get("tanh_clipping", 10.0), temp=kw.get("temperature", 1.0),
-                              top_k=kw.get("top_k", 0), top_p=kw.get("top_p", 0.0))
+                              top_k=kw.get("top_k", 0), top_p=kw.get("top_p", 0.0), **okw)
     assert_bits_equal(out["log_likelihood"], o["logp_steps"], "per-step logp vs oracle")
     assert_bits_equal(out["reward"], o["reward"], "reward vs oracle")
 
 
 @pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random",
-                                  "env_pctsp20_random"])
+                                  "env_pctsp20_random", "env_op20_random", "env_op50_random"])
 def test_env_api_matches_reference_state_machine(name):
     """env.reset / env.step / env.get_reward through the RL4COEnvBase API against the reference's recorded states."""
     import eam_rl4co_amd as ea
@@ -357,6 +373,10 @@ def test_env_api_matches_reference_state_machine(name):
         if env_name == "tsp":
             assert_bits_equal(td["first_node"], fx["step_first_node"][:, step], "first")
             assert_bits_equal(td["i"], fx["step_i"][:, step], "i")
+        elif env_name == "op":
+            for k in ("visited", "tour_length", "current_total_prize", "i"):
+                assert_bits_equal(td[k], fx["step_" + k][:, step], k)
+            assert_bits_equal(env.get_action_mask(td), fx["step_action_mask"][:, step], "get_action_mask")
         elif env_name == "pctsp":
             for k in ("visited", "cur_total_prize", "cur_total_penalty", "i"):
                 assert_bits_equal(td[k], fx["step_" + k][:, step], k)
@@ -371,6 +391,15 @@ def test_env_api_matches_reference_state_machine(name):
     reward = env.get_reward(td, t(fx["step_action"]))
     np.testing.assert_allclose(reward.cpu().numpy(), fx["reward"], rtol=1e-6, atol=0)
     bad = fx["step_action"].copy()
+    if env_name == "op":        # the reference's own asserts (op/env.py:179-212)
+        rows = np.nonzero(bad[:, 1] != 0)[0]
+        bad[rows[0], 0] = bad[rows[0], 1]
+        with pytest.raises(AssertionError, match="Duplicates"):
+            env.get_reward(td, t(bad))
+        far = np.tile(np.arange(1, int(fx["num_loc"]) + 1, dtype=np.int64), (bad.shape[0], 1))
+        with pytest.raises(AssertionError, match="Max length exceeded"):
+            env.get_reward(td, t(far))
+        return
     if env_name == "pctsp":     # the reference's own asserts (pctsp/env.py:189-205)
         bad[0, 1] = bad[0, 0]
         with pytest.raises(AssertionError, match="Duplicates"):
@@ -405,7 +434,8 @@ def test_random_policy_rollout_helper_shapes():
 @pytest.mark.parametrize("env_name,N,B,mode", [("tsp", 100, 1024, "greedy"), ("cvrp", 100, 1024, "sampling"),
                                                 ("tsp", 20, 128, "greedy"), ("cvrp", 500, 16, "greedy"),
                                                 ("sdvrp", 100, 256, "sampling"), ("sdvrp", 200, 32, "greedy"),
-                                                ("pctsp", 100, 256, "sampling"), ("pctsp", 200, 32, "greedy")])
+                                                ("pctsp", 100, 256, "sampling"), ("pctsp", 200, 32, "greedy"),
+                                                ("op", 100, 256, "sampling"), ("op", 200, 32, "greedy")])
 def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
     """BASELINE.json configs at full size (C2, C3, C1, C5 with a reduced batch so the CPU oracle finishes in
     seconds): tours bit-identical to the oracle, plus size-independent properties."""
@@ -420,6 +450,8 @@ def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
     demand = td_cpu["demand"].numpy() if env_name in ("cvrp", "sdvrp") else None
     if env_name == "pctsp":
         demand = {k: td_cpu[k].numpy() for k in ("expected_prize", "real_prize", "penalty", "prize_required")}
+    if env_name == "op":
+        demand = {k: td_cpu[k].numpy() for k in ("prize", "max_length")}
     M = locs.shape[1]
     kw = {}
     noise = None
@@ -433,6 +465,15 @@ def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
     if env_name == "tsp":
         assert (np.sort(acts, 1) == np.arange(N)).all()
         pts = np.take_along_axis(locs, acts[..., None].repeat(2, -1), 1).astype(np.float64)
+    elif env_name == "op":          # customers at most once; the closed tour fits; reward = collected prize
+        for b, row in enumerate(acts):
+            nz = row[row != 0]
+            assert len(set(nz)) == len(nz)
+        pts = np.take_along_axis(locs, acts[..., None].repeat(2, -1), 1).astype(np.float64)
+        length = np.linalg.norm(np.roll(pts, -1, 1) - pts, axis=-1).sum(1)
+        assert (length <= float(env.generator.max_length) + 1e-4).all()
+        want = np.take_along_axis(demand["prize"].astype(np.float64), acts, 1).sum(1)
+        np.testing.assert_allclose(out["reward"].cpu().numpy(), want, rtol=1e-5)
     elif env_name == "pctsp":       # customers at most once; enough prize or everyone visited; reward by the definition
         for b, row in enumerate(acts):
             nz = row[row != 0]
@@ -453,7 +494,7 @@ def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
             assert float(pol._last_td["demand_with_depot"].abs().max()) == 0.0
         pts = np.take_along_axis(locs, acts[..., None].repeat(2, -1), 1).astype(np.float64)
         pts = np.concatenate([locs[:, :1].astype(np.float64), pts], 1)
-    if env_name != "pctsp":
+    if env_name not in ("pctsp", "op"):
         length = np.linalg.norm(np.roll(pts, -1, 1) - pts, axis=-1).sum(1)
         np.testing.assert_allclose(-out["reward"].cpu().numpy(), length, rtol=2e-6)
     o = oracle.policy_rollout(golden_weights(cfg), env_name, locs, demand, decode_type=mode,
