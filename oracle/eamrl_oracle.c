@@ -49,7 +49,7 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
-enum { ORC_ENV_TSP = 0, ORC_ENV_CVRP = 1, ORC_ENV_SDVRP = 2, ORC_ENV_PCTSP = 3, ORC_ENV_OP = 4 };
+enum { ORC_ENV_TSP = 0, ORC_ENV_CVRP = 1, ORC_ENV_SDVRP = 2, ORC_ENV_PCTSP = 3, ORC_ENV_OP = 4, ORC_ENV_CVRPTW = 5 };
 enum { ORC_GREEDY = 0, ORC_SAMPLE = 1, ORC_EVALUATE = 2 };
 #define ORC_NCHUNK 4 /* node chunks for the glimpse accumulation, column chunks for the logit dot */
 
@@ -437,6 +437,43 @@ ORC_API void orc_op_step(uint8_t* visited, float* tour_len, float* prize_tot, co
     orc_op_mask(visited, tour_len, cur, locs, maxlen, mask, R, Binst, M);
 }
 
+/* CVRPTWEnv.get_action_mask  [rl4co/envs/routing/cvrptw/env.py:103-116]: the CVRP mask AND "reachable before the time
+ * window closes".  tw [Binst][M][2] (start, end) as floats, time [R] = current_time. */
+ORC_API void orc_cvrptw_mask(const uint8_t* visited, const float* used, const float* vcap, const float* demand,
+                             const int64_t* cur, const float* time, const float* locs, const float* tw, uint8_t* mask,
+                             long R, long Binst, int N)
+{
+    const int M = N + 1;
+    orc_cvrp_mask(visited, used, vcap, demand, cur, mask, R, Binst, N);
+    for (long r = 0; r < R; ++r) {
+        const float* L = locs + (r % Binst) * (long)M * 2;
+        const float* W = tw + (r % Binst) * (long)M * 2;
+        for (int n = 0; n < M; ++n) {
+            const int in_time = (time[r] + dist2(L + 2 * cur[r], L + 2 * n)) <= W[2 * n + 1];
+            mask[r * M + n] = mask[r * M + n] && in_time;
+        }
+    }
+}
+
+/* CVRPTWEnv._step  [cvrptw/env.py:118-138]: time = (a != 0) * (max(time + dist(cur, a), tw_start[a]) + duration[a]),
+ * then CVRPEnv._step and the mask above.  dur [Binst][M]. */
+ORC_API void orc_cvrptw_step(uint8_t* visited, float* used, const float* vcap, const float* demand, int64_t* cur,
+                             float* time, const float* locs, const float* tw, const float* dur, const int64_t* action,
+                             uint8_t* mask, uint8_t* done, long R, long Binst, int N)
+{
+    const int M = N + 1;
+    for (long r = 0; r < R; ++r) {
+        const int64_t a = action[r];
+        const float* L = locs + (r % Binst) * (long)M * 2;
+        const float* W = tw + (r % Binst) * (long)M * 2;
+        const float arrive = time[r] + dist2(L + 2 * cur[r], L + 2 * a);
+        const float start = arrive > W[2 * a] ? arrive : W[2 * a];                 /* torch.max */
+        time[r] = (a != 0 ? 1.0f : 0.0f) * (start + dur[(r % Binst) * (long)M + a]);
+    }
+    orc_cvrp_step(visited, used, vcap, demand, cur, action, mask, done, R, Binst, N);
+    orc_cvrptw_mask(visited, used, vcap, demand, cur, time, locs, tw, mask, R, Binst, N);
+}
+
 /* PCTSPEnv.get_action_mask  [rl4co/envs/routing/pctsp/env.py:156-163].  visited [R][M], prize_tot [R] (cur_total_prize):
  * a customer is feasible until visited and until the depot has been visited; the depot is infeasible while the collected
  * prize is below 1 and an unvisited customer remains. */
@@ -490,7 +527,7 @@ typedef struct {
     float top_p;        /* process_logits nucleus filtering (0 or >= 1 = off)            utils/decoding.py:118-136 */
 } orc_dec_t;
 
-static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, int64_t istep, float remaining,
+static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, int64_t istep, float remaining, float now,
                       const float* rem, const uint8_t* mask, int mode, const float* noise, int64_t given,
                       int64_t* out_action, float* out_logp, float* out_logits, float* out_logprobs, float* scratch)
 {
@@ -514,6 +551,8 @@ static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, in
             else ctx = c->Pa[(bi * M + first) * (long)E + e] + c->Pb[(bi * M + cur) * (long)E + e];
         } else {   /* CVRP and SDVRP: VRPContext */
             ctx = fmaf(c->cvec[e], remaining, c->Pa[(bi * M + cur) * (long)E + e]);
+            /* VRPTWContext: one more state column, the current time (context.py:160-176); cvec = [2][E] */
+            if (c->env == ORC_ENV_CVRPTW) ctx = fmaf(c->cvec[E + e], now, ctx);
         }
         q[e] = ctx + g;
     }
@@ -663,7 +702,7 @@ ORC_API int orc_decode_step(int env, long R, long Binst, int M, int E, int H,
                             const float* Pa, const float* Pb, const float* cvec, const float* gctx,
                             const int64_t* first, const int64_t* cur, const int64_t* istep,
                             const float* used, const float* vcap, const uint8_t* mask,
-                            const float* rem, const float* dyn,
+                            const float* rem, const float* dyn, const float* time,
                             int mode, const float* noise, const int64_t* given, float clip, float temp,
                             int top_k, float top_p,
                             int64_t* out_action, float* out_logp, float* out_logits, float* out_logprobs)
@@ -678,7 +717,7 @@ ORC_API int orc_decode_step(int env, long R, long Binst, int M, int E, int H,
             float remaining = (env != ORC_ENV_TSP) ? (vcap[r] - used[r]) : 0.0f;
             /* PCTSPContext: clamp(prize_required - cur_total_prize, min=0)   nn/env_embeddings/context.py:194-208 */
             if (env == ORC_ENV_PCTSP && remaining < 0.0f) remaining = 0.0f;
-            int st = decode_row(&c, r, first ? first[r] : 0, cur[r], istep ? istep[r] : 1, remaining,
+            int st = decode_row(&c, r, first ? first[r] : 0, cur[r], istep ? istep[r] : 1, remaining, time ? time[r] : 0.0f,
                                 rem ? rem + r * (long)M : NULL, mask + r * (long)M, mode, noise ? noise + r * (long)M : NULL,
                                 given ? given[r] : 0, out_action + r, out_logp + r,
                                 out_logits ? out_logits + r * (long)M : NULL,
@@ -786,6 +825,35 @@ ORC_API long orc_check_op(const int64_t* actions, const float* locs, const float
     return dup + 1000000 * over;
 }
 
+/* The time-window replay of CVRPTWEnv.check_solution_validity  [cvrptw/env.py:203-227]: arrival times are truncated to
+ * integers there ((curr_time + dist).int()), service starts at max(arrival, window start) and must not be after the
+ * window end; the depot resets the clock.  Returns the number of rows that miss a deadline. */
+ORC_API long orc_check_cvrptw_time(const int64_t* actions, const float* locs, const float* tw, const float* dur,
+                                   long R, long Binst, int M, int T)
+{
+    long late = 0;
+    for (long r = 0; r < R; ++r) {
+        const float* L = locs + (r % Binst) * (long)M * 2;
+        const float* W = tw + (r % Binst) * (long)M * 2;
+        float curr = 0.0f;
+        int64_t node = 0;
+        int bad = 0;
+        for (int t = 0; t < T; ++t) {
+            int64_t nx = actions[r * T + t];
+            if (nx < 0 || nx >= M) { bad = 1; break; }
+            int ct = (int)(curr + dist2(L + 2 * node, L + 2 * nx));
+            const int ws = (int)W[2 * nx];
+            if (ws > ct) ct = ws;
+            if ((float)ct > W[2 * nx + 1]) bad = 1;
+            curr = (float)ct + dur[(r % Binst) * (long)M + nx];
+            node = nx;
+            if (nx == 0) curr = 0.0f;
+        }
+        late += bad;
+    }
+    return late;
+}
+
 /* PCTSPEnv.check_solution_validity  [pctsp/env.py:189-205].  Returns rows with a customer visited twice (or an id out of
  * range) + 1000000 * rows that neither collect a total prize >= 1 - 1e-5 nor visit every customer. */
 ORC_API long orc_check_pctsp(const int64_t* actions, const float* prize, long R, long Binst, int M, int T)
@@ -883,7 +951,8 @@ ORC_API int orc_rollout(int env, long R, long Binst, int M, int E, int H,
                         int64_t* first, int64_t* cur, int64_t* istep,
                         float* used, const float* vcap, const float* demand,
                         uint8_t* mask, uint8_t* visited, uint8_t* done, float* rem, const float* dyn,
-                        const float* locs,   /* OP only: [Binst][M][2]; `demand` is then the arrival limit [Binst][M] */
+                        const float* locs,   /* OP, CVRPTW: [Binst][M][2]; OP: `demand` is then the arrival limit [Binst][M] */
+                        const float* tw, const float* dur, float* time,   /* CVRPTW: [Binst][M][2], [Binst][M], [R] */
                         int mode, const float* noise, const int64_t* given, int Tgiven,
                         float clip, float temp, int top_k, float top_p, int Tmax,
                         int64_t* actions, float* logps)
@@ -900,12 +969,14 @@ ORC_API int orc_rollout(int env, long R, long Binst, int M, int E, int H,
         if (noise) for (long r = 0; r < R; ++r) memcpy(nz + r * M, noise + (r * (long)Tmax + t) * M, sizeof(float) * M);
         if (given) for (long r = 0; r < R; ++r) gv[r] = (t < Tgiven) ? given[r * (long)Tgiven + t] : 0;
         status = orc_decode_step(env, R, Binst, M, E, H, K, V, Lp, Pa, Pb, cvec, gctx, first, cur, istep,
-                                 used, vcap, mask, rem, dyn, mode, nz, gv, clip, temp, top_k, top_p, a, lp, NULL, NULL);
+                                 used, vcap, mask, rem, dyn, time, mode, nz, gv, clip, temp, top_k, top_p, a, lp, NULL, NULL);
         if (status != 0) break;
         for (long r = 0; r < R; ++r) { actions[r * (long)Tmax + t] = a[r]; logps[r * (long)Tmax + t] = lp[r]; }
         if (env == ORC_ENV_TSP) orc_tsp_step(mask, first, cur, istep, a, done, R, M);
         else if (env == ORC_ENV_CVRP) orc_cvrp_step(visited, used, vcap, demand, cur, a, mask, done, R, Binst, M - 1);
         else if (env == ORC_ENV_PCTSP) orc_pctsp_step(visited, used, NULL, demand, NULL, cur, istep, a, mask, done, R, Binst, M);
+        else if (env == ORC_ENV_CVRPTW)
+            orc_cvrptw_step(visited, used, vcap, demand, cur, time, locs, tw, dur, a, mask, done, R, Binst, M - 1);
         else if (env == ORC_ENV_OP) orc_op_step(visited, used, NULL, NULL, locs, demand, cur, istep, a, mask, done, R, Binst, M);
         else orc_sdvrp_step(rem, used, vcap, cur, a, mask, done, R, M);
         ++t;

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ENV_TSP, ENV_CVRP, ENV_SDVRP, ENV_PCTSP, ENV_OP = 0, 1, 2, 3, 4
+ENV_TSP, ENV_CVRP, ENV_SDVRP, ENV_PCTSP, ENV_OP, ENV_CVRPTW = 0, 1, 2, 3, 4, 5
 GREEDY, SAMPLE, EVALUATE = 0, 1, 2
 MODES = {"greedy": GREEDY, "sampling": SAMPLE, "evaluate": EVALUATE}
 
@@ -181,6 +181,9 @@ def encode(sd, env_name, locs, demand=None, num_heads=8):
             extra = [_f32(demand["expected_prize"])[..., None], _f32(demand["penalty"])[:, 1:, None]]
         elif env_name == "op":        # (x, y, prize)  [nn/env_embeddings/init.py:260-286]
             extra = [_f32(demand["prize"])[:, 1:, None]]
+        elif env_name == "cvrptw":    # (x, y, demand, window start, window end, service time)  [init.py:141-157]
+            extra = [_f32(demand["demand"])[..., None], _f32(demand["time_windows"])[:, 1:, :],
+                     _f32(demand["durations"])[:, 1:, None]]
         else:
             extra = [_f32(demand)[..., None]]
         feat = np.concatenate([_f32(locs[:, 1:])] + extra, -1)
@@ -222,7 +225,8 @@ def precompute(sd, env_name, emb, use_graph_context=True):
     else:
         out["Pa"] = linear(emb, np.ascontiguousarray(Wctx[:, :E]))
         out["Pb"] = None
-        out["cvec"] = np.ascontiguousarray(Wctx[:, E])
+        # state columns of project_context: capacity (and, CVRPTW, the current time) -> [E] or [2, E]
+        out["cvec"] = np.ascontiguousarray(Wctx[:, E:].T.reshape(-1)) if env_name == "cvrptw" else np.ascontiguousarray(Wctx[:, E])
     out["gctx"] = linear(mean_nodes(emb), sd["decoder.project_fixed_context.weight"]) if use_graph_context else None
     if env_name == "sdvrp":      # SDVRPDynamicEmbedding: Linear(1, 3E, bias=False); the logit part folded like Lp
         w = _f32(sd["decoder.dynamic_embedding.projection.weight"]).reshape(3, E)
@@ -239,9 +243,14 @@ class State:
 
     def __init__(self, env_name, locs, demand=None, vehicle_capacity=1.0, num_starts=0):
         self.env_name = env_name
-        self.env = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP, "pctsp": ENV_PCTSP, "op": ENV_OP}[env_name]
+        self.env = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP, "pctsp": ENV_PCTSP, "op": ENV_OP,
+                    "cvrptw": ENV_CVRPTW}[env_name]
         self.rem = None
-        self.oplocs = None
+        self.oplocs = self.tw = self.dur = self.time = None
+        if env_name == "cvrptw":     # CVRP state + clock; time windows as floats (exact: they are small integers)
+            self.tw = _f32(demand["time_windows"])
+            self.dur = _f32(demand["durations"])
+            demand = demand["demand"]
         op_maxlen = None
         if env_name == "op":         # used = tour_length, vcap = max_length[:, 0] per row, demand = max_length [B, M]
             op_maxlen, demand, vehicle_capacity = _f32(demand["max_length"]), _f32(demand["max_length"]), 0.0
@@ -282,6 +291,15 @@ class State:
             self.mask = np.empty((R, self.M), np.uint8)
             lib().orc_sdvrp_mask(_p(self.rem), _p(self.used), _p(self.vcap), _p(self.cur), _p(self.mask), C.c_long(R),
                                  C.c_int(self.M))
+        elif env_name == "cvrptw":
+            self.demand = _f32(demand)
+            self.oplocs = self.locs
+            self.time = np.zeros(R, np.float32)
+            self.visited = np.zeros((R, self.M), np.uint8)
+            self.mask = np.empty((R, self.M), np.uint8)
+            lib().orc_cvrptw_mask(_p(self.visited), _p(self.used), _p(self.vcap), _p(self.demand), _p(self.cur),
+                                  _p(self.time), _p(self.oplocs), _p(self.tw), _p(self.mask), C.c_long(R),
+                                  C.c_long(self.Binst), C.c_int(self.M - 1))
         else:
             self.demand = _f32(demand)
             self.visited = np.zeros((R, self.M), np.uint8)
@@ -294,6 +312,10 @@ class State:
         if self.env == ENV_TSP:
             lib().orc_tsp_step(_p(self.mask), _p(self.first), _p(self.cur), _p(self.istep), _p(a), _p(self.done),
                                C.c_long(self.R), C.c_int(self.M))
+        elif self.env == ENV_CVRPTW:
+            lib().orc_cvrptw_step(_p(self.visited), _p(self.used), _p(self.vcap), _p(self.demand), _p(self.cur),
+                                  _p(self.time), _p(self.oplocs), _p(self.tw), _p(self.dur), _p(a), _p(self.mask),
+                                  _p(self.done), C.c_long(self.R), C.c_long(self.Binst), C.c_int(self.M - 1))
         elif self.env == ENV_OP:
             lib().orc_op_step(_p(self.visited), _p(self.used), None, None, _p(self.oplocs), _p(self.demand), _p(self.cur),
                               _p(self.istep), _p(a), _p(self.mask), _p(self.done), C.c_long(self.R), C.c_long(self.Binst),
@@ -325,7 +347,7 @@ def decode_step(st: State, cache, mode="greedy", noise=None, given=None, clip=10
         C.c_int(st.env), C.c_long(R), C.c_long(st.Binst), C.c_int(M), C.c_int(E), C.c_int(num_heads),
         _p(cache["K"]), _p(cache["V"]), _p(cache["Lp"]), _p(cache["Pa"]), _p(cache["Pb"]), _p(cache["cvec"]),
         _p(cache["gctx"]), _p(st.first), _p(st.cur), _p(st.istep), _p(st.used), _p(st.vcap), _p(st.mask),
-        _p(st.rem), _p(cache.get("dyn")),
+        _p(st.rem), _p(cache.get("dyn")), _p(st.time),
         C.c_int(MODES[mode]), _p(nz), _p(gv), C.c_float(clip), C.c_float(temp), C.c_int(int(top_k)), C.c_float(top_p),
         _p(act), _p(lp), _p(logits), _p(logprobs))
     if rc == -1:
@@ -356,8 +378,8 @@ def rollout(st: State, cache, mode="greedy", noise=None, given=None, clip=10.0, 
         C.c_int(st.env), C.c_long(R), C.c_long(st.Binst), C.c_int(M), C.c_int(E), C.c_int(num_heads),
         _p(cache["K"]), _p(cache["V"]), _p(cache["Lp"]), _p(cache["Pa"]), _p(cache["Pb"]), _p(cache["cvec"]),
         _p(cache["gctx"]), _p(st.first), _p(st.cur), _p(st.istep), _p(st.used), _p(st.vcap), _p(st.demand),
-        _p(st.mask), _p(st.visited), _p(st.done), _p(st.rem), _p(cache.get("dyn")), _p(st.oplocs), C.c_int(MODES[mode]),
-        _p(noise),
+        _p(st.mask), _p(st.visited), _p(st.done), _p(st.rem), _p(cache.get("dyn")), _p(st.oplocs), _p(st.tw), _p(st.dur),
+        _p(st.time), C.c_int(MODES[mode]), _p(noise),
         _p(given), C.c_int(tg),
         C.c_float(clip), C.c_float(temp), C.c_int(int(top_k)), C.c_float(top_p), C.c_int(t_max), _p(actions), _p(logps))
     if T == -1:
@@ -401,6 +423,13 @@ def check_op(actions, locs, max_length):
     lib().orc_check_op.restype = C.c_long
     return int(lib().orc_check_op(_p(actions), _p(locs), _p(max_length), C.c_long(actions.shape[0]), C.c_long(locs.shape[0]),
                                   C.c_int(locs.shape[1]), C.c_int(actions.shape[1])))
+
+
+def check_cvrptw_time(actions, locs, time_windows, durations):
+    actions, locs, tw, dur = _i64(actions), _f32(locs), _f32(time_windows), _f32(durations)
+    lib().orc_check_cvrptw_time.restype = C.c_long
+    return int(lib().orc_check_cvrptw_time(_p(actions), _p(locs), _p(tw), _p(dur), C.c_long(actions.shape[0]),
+                                           C.c_long(locs.shape[0]), C.c_int(locs.shape[1]), C.c_int(actions.shape[1])))
 
 
 def check_pctsp(actions, real_prize):
@@ -500,7 +529,7 @@ def policy_beam_search(sd, env_name, locs, demand=None, beam_width=None, select_
                 node[k * B + b], beam[k * B + b], new_parent[k * B + b] = c % M, c // M, flat[b, c]
         idx = inst + beam * B
         slp = logprobs[idx, node]
-        for name in ("first", "cur", "istep", "done", "mask", "used", "visited", "rem"):
+        for name in ("first", "cur", "istep", "done", "mask", "used", "visited", "rem", "time"):
             v = getattr(st, name)
             if v is not None:
                 setattr(st, name, np.ascontiguousarray(v[idx]))

@@ -10,7 +10,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 with open(os.path.join(GOLDEN, "state_dict_contract.json")) as _f:
     CONTRACT = json.load(_f)
-for _name in ("state_dict_contract_sdvrp.json", "state_dict_contract_pctsp.json", "state_dict_contract_op.json"):      # the sibling envs
+for _name in ("state_dict_contract_sdvrp.json", "state_dict_contract_pctsp.json", "state_dict_contract_op.json",
+              "state_dict_contract_cvrptw.json"):      # the sibling envs
     with open(os.path.join(GOLDEN, _name)) as _f:
         CONTRACT.update(json.load(_f))
 
@@ -44,4 +45,6 @@ def instance_of(fx):
         return {k: fx[k] for k in ("expected_prize", "real_prize", "penalty", "prize_required")}
     if str(fx["env_name"]) == "op":
         return {k: fx[k] for k in ("prize", "max_length")}
+    if str(fx["env_name"]) == "cvrptw":
+        return {k: fx[k] for k in ("demand", "time_windows", "durations")}
     return fx.get("demand")

@@ -36,6 +36,7 @@ import torch  # noqa: E402
 import goldweights  # noqa: E402
 import rl4co.utils.decoding as ref_decoding  # noqa: E402
 from rl4co.envs.routing.cvrp.env import CVRPEnv  # noqa: E402
+from rl4co.envs.routing.cvrptw.env import CVRPTWEnv  # noqa: E402
 from rl4co.envs.routing.op.env import OPEnv  # noqa: E402
 from rl4co.envs.routing.pctsp.env import PCTSPEnv  # noqa: E402
 from rl4co.envs.routing.sdvrp.env import SDVRPEnv  # noqa: E402
@@ -118,7 +119,7 @@ def np_(t):
 def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_starts=None,
              keep_steps=None, keep_embeds=False, data_seed=1234, sample_seed=4321, actions=None,
              td_init=None, decode_kw=None):
-    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv}[env_name]
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv, "cvrptw": CVRPTWEnv}[env_name]
     env = Env(generator_params=gen_params(env_name, num_loc), seed=data_seed)
     if td_init is None:
         torch.manual_seed(data_seed)
@@ -151,9 +152,12 @@ def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_st
         "step_mask": np.stack([np_(rec.masks[s]) for s in steps], 1),
         "n_decoder_steps": np.array(T, dtype=np.int64),
     }
-    if env_name in ("cvrp", "sdvrp"):
+    if env_name in ("cvrp", "sdvrp", "cvrptw"):
         fx["demand"] = np_(td_init["demand"])
         fx["vehicle_capacity"] = np_(td_init["vehicle_capacity"])
+    if env_name == "cvrptw":
+        for k in ("durations", "time_windows"):
+            fx[k] = np_(td_init[k])
     if env_name == "pctsp":
         for k in ("expected_prize", "real_prize", "penalty", "prize_required"):
             fx[k] = np_(td_init[k])
@@ -184,7 +188,7 @@ def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_st
 
 def run_env_case(name, env_name, num_loc, batch, data_seed=99, act_seed=7):
     """Env-only golden: random feasible policy, every state tensor after every step."""
-    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv}[env_name]
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv, "cvrptw": CVRPTWEnv}[env_name]
     env = Env(generator_params=gen_params(env_name, num_loc), seed=data_seed)
     torch.manual_seed(data_seed)
     gen = env.generator(batch_size=[batch])
@@ -199,7 +203,8 @@ def run_env_case(name, env_name, num_loc, batch, data_seed=99, act_seed=7):
     extra = {"tsp": ("first_node", "i"), "cvrp": ("used_capacity", "visited"),
              "sdvrp": ("used_capacity", "demand_with_depot"),
              "pctsp": ("cur_total_prize", "cur_total_penalty", "visited", "i"),
-             "op": ("tour_length", "current_total_prize", "visited", "i")}[env_name]
+             "op": ("tour_length", "current_total_prize", "visited", "i"),
+             "cvrptw": ("used_capacity", "visited", "current_time")}[env_name]
     for k in extra:
         per[k] = []
     while not td["done"].all():
@@ -289,6 +294,22 @@ def beam():
              decode_kw=dict(beam_width=12, select_best=False))
 
 
+def cvrptw():
+    """Eighth batch (python make_golden.py cvrptw): CVRP with time windows."""
+    import json
+    first4 = [0, 1, 2, 3]
+    sd = AttentionModelPolicy(env_name="cvrptw").state_dict()
+    with open(os.path.join(HERE, "state_dict_contract_cvrptw.json"), "w") as f:
+        json.dump({"am_cvrptw": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]}, f, indent=0)
+    run_case("cvrptw20_greedy", "cvrptw", 20, 4, "greedy", keep_embeds=True, data_seed=91)
+    run_case("cvrptw20_sampling", "cvrptw", 20, 4, "sampling", keep_steps=first4, data_seed=92)
+    run_case("cvrptw50_greedy", "cvrptw", 50, 4, "greedy", keep_steps=first4, data_seed=93)
+    run_case("cvrptw100_sampling", "cvrptw", 100, 4, "sampling", keep_steps=first4, data_seed=95)
+    run_case("cvrptw20_multistart_greedy", "cvrptw", 20, 3, "multistart_greedy", num_starts=20, keep_steps=first4, data_seed=94)
+    run_env_case("env_cvrptw20_random", "cvrptw", 20, 8)
+    run_env_case("env_cvrptw50_random", "cvrptw", 50, 4, data_seed=97)
+
+
 def op():
     """Seventh batch (python make_golden.py op): orienteering problem."""
     import json
@@ -348,7 +369,9 @@ def filtering():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "op":
+    if len(sys.argv) > 1 and sys.argv[1] == "cvrptw":
+        cvrptw()
+    elif len(sys.argv) > 1 and sys.argv[1] == "op":
         op()
     elif len(sys.argv) > 1 and sys.argv[1] == "pctsp":
         pctsp()
