@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # EAMRL_HIP_LIB: development override (instrumented builds made by tools/); the default is the in-tree library
 LIB_PATH = os.environ.get("EAMRL_HIP_LIB") or os.path.join(_PKG, "lib", "libeamrl_hip.so")
 
-ENV_TSP, ENV_CVRP, ENV_SDVRP, ENV_PCTSP, ENV_OP = 0, 1, 2, 3, 4
+ENV_TSP, ENV_CVRP, ENV_SDVRP, ENV_PCTSP, ENV_OP, ENV_CVRPTW = 0, 1, 2, 3, 4, 5
 GREEDY, SAMPLE, EVALUATE = 0, 1, 2
 NORM_BATCH_EVAL, NORM_INSTANCE = 0, 1
 ST_NAN_LOGITS, ST_INFEASIBLE, ST_STEP_OVERRUN = 1, 2, 4
@@ -27,7 +27,8 @@ class Cache(C.Structure):
 class State(C.Structure):
     """struct eamrl_state"""
     _fields_ = [("first", _vp), ("cur", _vp), ("istep", _vp), ("used", _vp), ("vcap", _vp), ("demand", _vp),
-                ("mask", _vp), ("visited", _vp), ("done", _vp), ("rem", _vp), ("locs", _vp)]
+                ("mask", _vp), ("visited", _vp), ("done", _vp), ("rem", _vp), ("locs", _vp),
+                ("time", _vp), ("tw", _vp), ("dur", _vp)]
 
 
 # name -> argtypes (all return int unless listed in _RESTYPES); mirrors include/eamrl.h one to one
@@ -39,6 +40,8 @@ PROTOTYPES = {
     "eamrl_cvrp_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "eamrl_cvrp_step_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "eamrl_sdvrp_step_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "eamrl_cvrptw_step_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "eamrl_cvrptw_check_time": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp],
     "eamrl_op_step_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "eamrl_op_reward": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "eamrl_op_check_solution": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp],

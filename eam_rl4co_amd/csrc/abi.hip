@@ -105,6 +105,30 @@ __attribute__((visibility("default"))) int eamrl_pctsp_step_mask(uint8_t* visite
                                  (hipStream_t)stream), "eamrl_pctsp_step_mask");
 }
 
+__attribute__((visibility("default"))) int eamrl_cvrptw_step_mask(uint8_t* visited, float* used, const float* vcap,
+                                                                 const float* demand, int64_t* cur, float* time,
+                                                                 const float* locs, const float* tw, const float* dur,
+                                                                 const int64_t* action, uint8_t* mask, uint8_t* done,
+                                                                 int64_t R, int64_t B, int N, void* stream)
+{
+    REQUIRE(visited && used && vcap && demand && cur && time && locs && tw && mask, "eamrl_cvrptw_step_mask");
+    REQUIRE(!action || (dur && done), "eamrl_cvrptw_step_mask");
+    REQUIRE(R >= 0 && B > 0 && N > 0, "eamrl_cvrptw_step_mask");
+    if (R == 0) return 0;
+    return launched(launch_cvrptw(visited, used, vcap, demand, cur, time, locs, tw, dur, action, mask, done, R, B, N,
+                                  (hipStream_t)stream), "eamrl_cvrptw_step_mask");
+}
+
+__attribute__((visibility("default"))) int eamrl_cvrptw_check_time(const int64_t* actions, const float* locs, const float* tw,
+                                                                  const float* dur, int64_t R, int64_t B, int M, int T,
+                                                                  int32_t* bad, void* stream)
+{
+    REQUIRE(actions && locs && tw && dur && bad && R >= 0 && B > 0 && M >= 2 && T > 0, "eamrl_cvrptw_check_time");
+    if (R == 0) return 0;
+    return launched(launch_cvrptw_check(actions, locs, tw, dur, R, B, M, T, bad, (hipStream_t)stream),
+                    "eamrl_cvrptw_check_time");
+}
+
 __attribute__((visibility("default"))) int eamrl_op_step_mask(uint8_t* visited, float* tour_len, float* prize_tot,
                                                              const float* prize, const float* locs, const float* maxlen,
                                                              int64_t* cur, int64_t* istep, const int64_t* action,
@@ -215,7 +239,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
                      uint32_t* status, DecArgs& a)
 {
     REQUIRE(c && s, what);
-    REQUIRE(env >= EAMRL_ENV_TSP && env <= EAMRL_ENV_OP, what);
+    REQUIRE(env >= EAMRL_ENV_TSP && env <= EAMRL_ENV_CVRPTW, what);
     REQUIRE(mode == EAMRL_GREEDY || mode == EAMRL_SAMPLE || mode == EAMRL_EVALUATE, what);
     REQUIRE(c->K && c->V && c->Lp && c->Pa && c->cvec, what);
     REQUIRE(c->B > 0 && c->M > 0 && c->E > 0 && c->H > 0, what);
@@ -230,6 +254,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
     if (env == EAMRL_ENV_SDVRP) REQUIRE(s->used && s->vcap && s->rem && c->dyn && c->M >= 2, what);
     if (env == EAMRL_ENV_PCTSP) REQUIRE(s->used && s->vcap && c->M >= 2, what);
     if (env == EAMRL_ENV_OP) REQUIRE(s->used && s->vcap && c->M >= 2, what);
+    if (env == EAMRL_ENV_CVRPTW) REQUIRE(s->used && s->vcap && s->time && c->M >= 2, what);
     if (mode == EAMRL_SAMPLE) REQUIRE(noise != nullptr, what);
     if (mode == EAMRL_EVALUATE) REQUIRE(given != nullptr, what);
     a = DecArgs{};
@@ -237,7 +262,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
     a.ld = c->ld; a.B = c->B; a.M = c->M; a.E = c->E; a.H = c->H;
     a.first = s->first; a.cur = s->cur; a.istep = s->istep; a.used = s->used; a.vcap = s->vcap; a.demand = s->demand;
     a.mask = s->mask; a.visited = s->visited; a.done = s->done;
-    a.rem = s->rem; a.dyn = c->dyn; a.locs = s->locs;
+    a.rem = s->rem; a.dyn = c->dyn; a.locs = s->locs; a.time = s->time; a.tw = s->tw; a.dur = s->dur;
     a.R = R; a.mode = mode; a.noise = noise; a.given = given; a.clip = clip; a.temp = temp; a.top_k = top_k; a.top_p = top_p; a.status = status;
     return 0;
 }
@@ -260,6 +285,7 @@ __attribute__((visibility("default"))) int eamrl_am_decode_step(int env, const e
         if (env == EAMRL_ENV_CVRP) REQUIRE(a.visited && a.demand, "eamrl_am_decode_step");
         if (env == EAMRL_ENV_PCTSP) REQUIRE(a.visited && a.demand && a.istep, "eamrl_am_decode_step");
         if (env == EAMRL_ENV_OP) REQUIRE(a.visited && a.demand && a.istep && a.locs, "eamrl_am_decode_step");
+        if (env == EAMRL_ENV_CVRPTW) REQUIRE(a.visited && a.demand && a.locs && a.tw && a.dur, "eamrl_am_decode_step");
     }
     a.fuse_env = fuse_env_step;
     a.action = action; a.logp = logp; a.logprobs_all = logprobs_all; a.logits_raw = logits_raw;
@@ -281,6 +307,7 @@ __attribute__((visibility("default"))) int eamrl_am_rollout(int env, const eamrl
     if (env == EAMRL_ENV_CVRP) REQUIRE(a.visited && a.demand, "eamrl_am_rollout");
     if (env == EAMRL_ENV_PCTSP) REQUIRE(a.visited && a.demand && a.istep, "eamrl_am_rollout");
     if (env == EAMRL_ENV_OP) REQUIRE(a.visited && a.demand && a.istep && a.locs, "eamrl_am_rollout");
+    if (env == EAMRL_ENV_CVRPTW) REQUIRE(a.visited && a.demand && a.locs && a.tw && a.dur, "eamrl_am_rollout");
     if (mode == EAMRL_EVALUATE) REQUIRE(t_given > 0, "eamrl_am_rollout");
     a.fuse_env = 1; a.t_max = t_max; a.t_given = t_given;
     a.action = actions; a.logp = logps; a.steps_out = steps_out;

@@ -15,7 +15,8 @@ struct DecArgs {
     int64_t* first; int64_t* cur; int64_t* istep; float* used; const float* vcap; const float* demand;
     uint8_t* mask; uint8_t* visited; uint8_t* done;
     float* rem; const float* dyn;      // SDVRP: remaining demand [R][M], dynamic-embedding vectors [3][E]
-    const float* locs;                 // OP: node coordinates [B][M][2]
+    const float* locs;                 // OP, CVRPTW: node coordinates [B][M][2]
+    float* time; const float* tw; const float* dur;   // CVRPTW: clock [R], windows [B][M][2], service times [B][M]
     // call
     int64_t R; int mode; const float* noise; const int64_t* given; int t_given;
     float clip, temp; int fuse_env; int t_max;

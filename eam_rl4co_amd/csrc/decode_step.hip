@@ -24,6 +24,7 @@ constexpr int NWAVE = BLOCK / EAMRL_WAVE;
 struct RowState {
     int64_t first, cur, istep;
     float used, vcap;
+    float now;          // CVRPTW: current_time
 };
 
 // block-wide max over values already reduced per thread; result broadcast to all threads
@@ -78,6 +79,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             float state = s.vcap - s.used;
             if (ENV == EAMRL_ENV_PCTSP) state = state < 0.0f ? 0.0f : state;
             ctx = fma_(a.cvec[e], state, a.Pa[(bi * M + s.cur) * ld + e]);
+            if (ENV == EAMRL_ENV_CVRPTW) ctx = fma_(a.cvec[E + e], s.now, ctx);      // VRPTWContext: + current time column
         }
         l.q[e] = ctx + g;
     }
@@ -491,10 +493,21 @@ __device__ bool env_step_row(const DecArgs& a, const RowLds& l, uint8_t* vis, fl
         int any = 0;
         for (int n = tid; n < M; n += BLOCK) any |= l.msk[n];
         return __syncthreads_or(any) == 0;
-    } else {
+    } else {      // CVRP, and CVRPTW = CVRP + clock (cvrptw/env.py:103-138)
+        constexpr bool TW = ENV == EAMRL_ENV_CVRPTW;
         const int N = M - 1;
         const int64_t bi = r % a.B;
         const float* dem = a.demand + bi * N;
+        const float* L = TW ? a.locs + bi * (int64_t)M * 2 : nullptr;
+        const float* W = TW ? a.tw + bi * (int64_t)M * 2 : nullptr;
+        float cx = 0.0f, cy = 0.0f;
+        if (TW) {
+            cx = L[2 * act]; cy = L[2 * act + 1];
+            const float dx = L[2 * s.cur] - cx, dy = L[2 * s.cur + 1] - cy;
+            const float arrive = s.now + __builtin_sqrtf(fma_(dy, dy, dx * dx));
+            const float start = arrive > W[2 * act] ? arrive : W[2 * act];
+            s.now = (act != 0 ? 1.0f : 0.0f) * (start + a.dur[bi * (int64_t)M + act]);
+        }
         int64_t di = act - 1;
         di = di < 0 ? 0 : (di > N - 1 ? N - 1 : di);
         s.used = (s.used + dem[di]) * (act != 0 ? 1.0f : 0.0f);
@@ -507,13 +520,25 @@ __device__ bool env_step_row(const DecArgs& a, const RowLds& l, uint8_t* vis, fl
             const int v = vis[j + 1] != 0;
             const float load = dem[j] + s.used;
             const int blocked = v | (load > lim);
-            l.msk[j + 1] = !blocked;
-            any_free |= !blocked;
+            int ok = !blocked;
+            if (TW) {       // reachable before the window closes
+                const float dx = cx - L[2 * (j + 1)], dy = cy - L[2 * (j + 1) + 1];
+                ok &= (s.now + __builtin_sqrtf(fma_(dy, dy, dx * dx))) <= W[2 * (j + 1) + 1];
+            }
+            l.msk[j + 1] = ok;
+            any_free |= !blocked;        // the depot rule looks at the CVRP mask only
             all_vis &= v;
         }
         any_free = __syncthreads_or(any_free);
         all_vis = __syncthreads_and(all_vis);
-        if (tid == 0) l.msk[0] = !((s.cur == 0) && any_free);
+        if (tid == 0) {
+            int ok0 = !((s.cur == 0) && any_free);
+            if (TW) {
+                const float dx = cx - L[0], dy = cy - L[1];
+                ok0 &= (s.now + __builtin_sqrtf(fma_(dy, dy, dx * dx))) <= W[1];
+            }
+            l.msk[0] = ok0;
+        }
         return all_vis != 0;
     }
 }
@@ -533,6 +558,7 @@ __device__ __forceinline__ void load_row_state(const DecArgs& a, int64_t r, RowS
         s.used = a.used[r];
         s.vcap = a.vcap[r];
     }
+    s.now = (ENV == EAMRL_ENV_CVRPTW) ? a.time[r] : 0.0f;
 }
 
 template <int ENV>
@@ -543,7 +569,8 @@ __device__ __forceinline__ void store_row_state(const DecArgs& a, const RowLds& 
     __syncthreads();
     for (int n = tid; n < a.M; n += BLOCK) {
         a.mask[r * a.M + n] = l.msk[n];
-        if (ENV == EAMRL_ENV_CVRP || ENV == EAMRL_ENV_PCTSP || ENV == EAMRL_ENV_OP) a.visited[r * a.M + n] = vis[n];
+        if (ENV == EAMRL_ENV_CVRP || ENV == EAMRL_ENV_PCTSP || ENV == EAMRL_ENV_OP || ENV == EAMRL_ENV_CVRPTW)
+            a.visited[r * a.M + n] = vis[n];
         if (ENV == EAMRL_ENV_SDVRP) a.rem[r * a.M + n] = rem[n];
     }
     if (tid == 0) {
@@ -552,6 +579,7 @@ __device__ __forceinline__ void store_row_state(const DecArgs& a, const RowLds& 
         if (ENV == EAMRL_ENV_TSP) { a.first[r] = s.first; a.istep[r] = s.istep; }
         else a.used[r] = s.used;
         if (ENV == EAMRL_ENV_PCTSP || ENV == EAMRL_ENV_OP) a.istep[r] = s.istep;
+        if (ENV == EAMRL_ENV_CVRPTW) a.time[r] = s.now;
     }
 }
 
@@ -563,7 +591,7 @@ __device__ __forceinline__ void load_row_lds(const DecArgs& a, const RowLds& l, 
     const int tid = threadIdx.x;
     for (int n = tid; n < a.M; n += BLOCK) {
         l.msk[n] = a.mask[r * a.M + n];
-        if ((ENV == EAMRL_ENV_CVRP || ENV == EAMRL_ENV_PCTSP || ENV == EAMRL_ENV_OP) && want_vis)
+        if ((ENV == EAMRL_ENV_CVRP || ENV == EAMRL_ENV_PCTSP || ENV == EAMRL_ENV_OP || ENV == EAMRL_ENV_CVRPTW) && want_vis)
             vis[n] = a.visited[r * a.M + n];
         if (ENV == EAMRL_ENV_SDVRP) rem[n] = a.rem[r * a.M + n];
     }
@@ -652,6 +680,7 @@ __global__ void k_rollout_pad(DecArgs a, int env)
     if (a.cur[r] != 0 && a.action[r * a.t_max + (T - 1)] == 0) {
         a.cur[r] = 0;
         a.used[r] = 0.0f;
+        if (env == EAMRL_ENV_CVRPTW) a.time[r] = 0.0f;       // the depot resets the clock
     }
 }
 
@@ -674,12 +703,14 @@ static int launch_decode(int env, const DecArgs& a, bool rollout, hipStream_t st
         k = env == EAMRL_ENV_TSP ? k_rollout_stream<EAMRL_ENV_TSP>
           : env == EAMRL_ENV_CVRP ? k_rollout_stream<EAMRL_ENV_CVRP>
           : env == EAMRL_ENV_SDVRP ? k_rollout_stream<EAMRL_ENV_SDVRP>
-          : env == EAMRL_ENV_PCTSP ? k_rollout_stream<EAMRL_ENV_PCTSP> : k_rollout_stream<EAMRL_ENV_OP>;
+          : env == EAMRL_ENV_PCTSP ? k_rollout_stream<EAMRL_ENV_PCTSP>
+          : env == EAMRL_ENV_OP ? k_rollout_stream<EAMRL_ENV_OP> : k_rollout_stream<EAMRL_ENV_CVRPTW>;
     else
         k = env == EAMRL_ENV_TSP ? k_decode_step<EAMRL_ENV_TSP>
           : env == EAMRL_ENV_CVRP ? k_decode_step<EAMRL_ENV_CVRP>
           : env == EAMRL_ENV_SDVRP ? k_decode_step<EAMRL_ENV_SDVRP>
-          : env == EAMRL_ENV_PCTSP ? k_decode_step<EAMRL_ENV_PCTSP> : k_decode_step<EAMRL_ENV_OP>;
+          : env == EAMRL_ENV_PCTSP ? k_decode_step<EAMRL_ENV_PCTSP>
+          : env == EAMRL_ENV_OP ? k_decode_step<EAMRL_ENV_OP> : k_decode_step<EAMRL_ENV_CVRPTW>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)

@@ -235,6 +235,89 @@ __global__ __launch_bounds__(EB) void k_op_step_mask(uint8_t* visited, float* to
     }
 }
 
+// CVRPTW: CVRP transition and mask plus the clock (cvrptw/env.py:103-138).  One wavefront per row.
+template <int STEP>
+__global__ __launch_bounds__(EB) void k_cvrptw_step_mask(uint8_t* visited, float* used, const float* vcap,
+                                                         const float* demand, int64_t* cur, float* time, const float* locs,
+                                                         const float* tw, const float* dur, const int64_t* action,
+                                                         uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int M = N + 1;
+    const float* dem = demand + (r % B) * N;
+    const float* L = locs + (r % B) * (int64_t)M * 2;
+    const float* W = tw + (r % B) * (int64_t)M * 2;
+    uint8_t* vis = visited + r * M;
+    float u = used[r], now = time[r];
+    int64_t c = cur[r];
+    c = c < 0 ? 0 : (c > M - 1 ? M - 1 : c);
+    int64_t a = -1;
+    if (STEP) {
+        a = action[r];
+        a = a < 0 ? 0 : (a > M - 1 ? M - 1 : a);     // an out-of-range action must not become an out-of-bounds access
+        const float arrive = now + dist2(L[2 * c], L[2 * c + 1], L[2 * a], L[2 * a + 1]);
+        const float start = arrive > W[2 * a] ? arrive : W[2 * a];
+        now = (a != 0 ? 1.0f : 0.0f) * (start + dur[(r % B) * (int64_t)M + a]);
+        int64_t di = a - 1;
+        di = di < 0 ? 0 : (di > N - 1 ? N - 1 : di);
+        u = (u + dem[di]) * (a != 0 ? 1.0f : 0.0f);
+        c = a;
+    }
+    const float cx = L[2 * c], cy = L[2 * c + 1];
+    const float lim = vcap[r] + 1e-5f;
+    int any_free = 0, all_vis = 1;
+    for (int j = lane; j < N; j += 64) {
+        int v = vis[j + 1] != 0;
+        if (STEP && j + 1 == a) { v = 1; vis[j + 1] = 1; }
+        const int blocked = v | ((dem[j] + u) > lim);
+        const int in_time = (now + dist2(cx, cy, L[2 * (j + 1)], L[2 * (j + 1) + 1])) <= W[2 * (j + 1) + 1];
+        mask[r * M + 1 + j] = (!blocked) & in_time;
+        any_free |= !blocked;                        // the depot rule looks at the CVRP mask only
+        all_vis &= v;
+    }
+    const bool any = __ballot(any_free != 0) != 0ull;
+    const bool allc = __ballot(all_vis == 0) == 0ull;
+    if (lane == 0) {
+        int v0 = vis[0] != 0;
+        if (STEP && a == 0) { v0 = 1; vis[0] = 1; }
+        const int in_time0 = (now + dist2(cx, cy, L[0], L[1])) <= W[1];
+        mask[r * M] = (!((c == 0) && any)) & in_time0;
+        if (STEP) {
+            used[r] = u;
+            time[r] = now;
+            cur[r] = c;
+            done[r] = (allc && v0) ? 1 : 0;
+        }
+    }
+}
+
+// the time-window replay of CVRPTWEnv.check_solution_validity (cvrptw/env.py:203-227): sequential, one thread per row
+__global__ void k_check_cvrptw_time(const int64_t* actions, const float* locs, const float* tw, const float* dur, int64_t R,
+                                    int64_t B, int M, int T, int32_t* bad)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* L = locs + (r % B) * (int64_t)M * 2;
+    const float* W = tw + (r % B) * (int64_t)M * 2;
+    float curr = 0.0f;
+    int64_t node = 0;
+    int late = 0;
+    for (int t = 0; t < T; ++t) {
+        const int64_t nx = actions[r * T + t];
+        if (nx < 0 || nx >= M) { late = 1; break; }
+        int ct = (int)(curr + dist2(L[2 * node], L[2 * node + 1], L[2 * nx], L[2 * nx + 1]));
+        const int ws = (int)W[2 * nx];
+        ct = ws > ct ? ws : ct;
+        if ((float)ct > W[2 * nx + 1]) late = 1;
+        curr = (float)ct + dur[(r % B) * (int64_t)M + nx];
+        node = nx;
+        if (nx == 0) curr = 0.0f;
+    }
+    if (late) atomicAdd(&bad[0], 1);
+}
+
 // OPEnv._get_reward: lane tree over the steps of prize[a_t]
 __global__ __launch_bounds__(EB) void k_op_reward(const float* prize, const int64_t* actions, float* reward, int64_t R,
                                                   int64_t B, int M, int T)
@@ -578,6 +661,27 @@ int launch_sdvrp(float* rem, float* used, const float* vcap, int64_t* cur, const
     else
         hipLaunchKernelGGL(k_sdvrp_step_mask<0>, dim3(row_blocks(R)), dim3(EB), 0, st, rem, used, vcap, cur, action, mask,
                            done, R, M);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_cvrptw(uint8_t* visited, float* used, const float* vcap, const float* demand, int64_t* cur, float* time,
+                  const float* locs, const float* tw, const float* dur, const int64_t* action, uint8_t* mask, uint8_t* done,
+                  int64_t R, int64_t B, int N, hipStream_t st)
+{
+    if (action)
+        hipLaunchKernelGGL(k_cvrptw_step_mask<1>, dim3(row_blocks(R)), dim3(EB), 0, st, visited, used, vcap, demand, cur, time,
+                           locs, tw, dur, action, mask, done, R, B, N);
+    else
+        hipLaunchKernelGGL(k_cvrptw_step_mask<0>, dim3(row_blocks(R)), dim3(EB), 0, st, visited, used, vcap, demand, cur, time,
+                           locs, tw, dur, action, mask, done, R, B, N);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_cvrptw_check(const int64_t* actions, const float* locs, const float* tw, const float* dur, int64_t R, int64_t B,
+                        int M, int T, int32_t* bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_cvrptw_time, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, actions, locs, tw, dur, R, B,
+                       M, T, bad);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 

@@ -36,6 +36,11 @@ int launch_sdvrp(float* rem, float* used, const float* vcap, int64_t* cur, const
 int launch_pctsp(uint8_t* visited, float* prize_tot, float* pen_tot, const float* prize, const float* penalty, int64_t* cur,
                  int64_t* istep, const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int M,
                  hipStream_t st);
+int launch_cvrptw(uint8_t* visited, float* used, const float* vcap, const float* demand, int64_t* cur, float* time,
+                  const float* locs, const float* tw, const float* dur, const int64_t* action, uint8_t* mask, uint8_t* done,
+                  int64_t R, int64_t B, int N, hipStream_t st);
+int launch_cvrptw_check(const int64_t* actions, const float* locs, const float* tw, const float* dur, int64_t R, int64_t B,
+                        int M, int T, int32_t* bad, hipStream_t st);
 int launch_op(uint8_t* visited, float* tour_len, float* prize_tot, const float* prize, const float* locs, const float* maxlen,
               int64_t* cur, int64_t* istep, const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int M,
               hipStream_t st);

@@ -42,8 +42,8 @@ __device__ unsigned long long g_stamps[8];
 #endif
 
 // TM: episode length bound (2M+1 steps for TSP / CVRP, 3M+1 for SDVRP); SDF: floats of the SDVRP-only arrays;
-// XYF: node slots of the OP-only coordinate array
-template <int CP, int TM, int SDF, int XYF>
+// XYF: node slots of the coordinate array (OP, CVRPTW); TWF: node slots of the CVRPTW time-window arrays
+template <int CP, int TM, int SDF, int XYF, int TWF>
 struct ResLds {
     static constexpr int WROW = 4 * CP + 4;     // floats per head row of w (chunk-padded, +4 spreads banks)
     float q[RE];
@@ -57,7 +57,8 @@ struct ResLds {
     int16_t act_out[TM];                        // selected actions of the episode
     float dynv[3 * SDF];                        // SDVRP: dynamic-embedding vectors wk | wv | lw
     float partR[RH];                            // SDVRP: R_h = lane-tree sum of w * rem
-    float xy[2 * XYF];                          // OP: node coordinates
+    float xy[2 * XYF];                          // OP, CVRPTW: node coordinates
+    float twv[3 * TWF];                         // CVRPTW: window start | window end | service time per node
     int done;
     uint8_t msk[RNP];
     uint8_t vis[RNP];
@@ -73,7 +74,8 @@ struct ResLds {
 // over the register-resident, never modified K / V / Lp.
 constexpr int res_tmax(int env) { return (env == EAMRL_ENV_SDVRP ? 3 : 2) * RNP + 2; }
 constexpr int res_sdf(int env) { return env == EAMRL_ENV_SDVRP ? RE : 4; }
-constexpr int res_xyf(int env) { return env == EAMRL_ENV_OP ? RNP : 2; }
+constexpr int res_xyf(int env) { return (env == EAMRL_ENV_OP || env == EAMRL_ENV_CVRPTW) ? RNP : 2; }
+constexpr int res_twf(int env) { return env == EAMRL_ENV_CVRPTW ? RNP : 2; }
 
 template <int ENV, int CP, int CR, bool MS>
 __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, int G)
@@ -81,8 +83,10 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
     constexpr bool SD = ENV == EAMRL_ENV_SDVRP;
     constexpr bool PC = ENV == EAMRL_ENV_PCTSP;     // prize collecting: dem = real_prize, used = collected prize
     constexpr bool OP = ENV == EAMRL_ENV_OP;        // orienteering: dem = arrival limit per node, used = tour length
+    constexpr bool TW = ENV == EAMRL_ENV_CVRPTW;    // CVRP + clock: coordinates and windows in LDS
+    constexpr bool CV = ENV == EAMRL_ENV_CVRP || TW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using L = ResLds<CP, res_tmax(ENV), res_sdf(ENV), res_xyf(ENV)>;
+    using L = ResLds<CP, res_tmax(ENV), res_sdf(ENV), res_xyf(ENV), res_twf(ENV)>;
     L& l = *reinterpret_cast<L*>(smem);
     float* Plds = reinterpret_cast<float*>(smem + ((sizeof(L) + 15) & ~size_t(15)));
     constexpr int WROW = L::WROW;
@@ -158,13 +162,18 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
     // ---- state: mask / visited in LDS; the scalar row state lives in wavefront 0 -----------------------------------------
     if (tid < RNP) {
         l.msk[tid] = (tid < M) ? a.mask[r * M + tid] : 0;
-        l.vis[tid] = ((ENV == EAMRL_ENV_CVRP || PC || OP) && tid < M) ? a.visited[r * M + tid] : 0;
+        l.vis[tid] = ((CV || PC || OP) && tid < M) ? a.visited[r * M + tid] : 0;
         if (PC || OP) l.dem[tid] = (tid < M) ? a.demand[bi * M + tid] : 0.0f;
-        if (OP) {
+        if (OP || TW) {
             l.xy[2 * tid] = (tid < M) ? a.locs[(bi * M + tid) * 2] : 0.0f;
             l.xy[2 * tid + 1] = (tid < M) ? a.locs[(bi * M + tid) * 2 + 1] : 0.0f;
         }
-        if (ENV == EAMRL_ENV_CVRP) l.dem[tid] = (tid < M - 1) ? a.demand[bi * (M - 1) + tid] : 0.0f;
+        if (TW) {
+            l.twv[tid] = (tid < M) ? a.tw[(bi * M + tid) * 2] : 0.0f;
+            l.twv[RNP + tid] = (tid < M) ? a.tw[(bi * M + tid) * 2 + 1] : 0.0f;
+            l.twv[2 * RNP + tid] = (tid < M) ? a.dur[bi * M + tid] : 0.0f;
+        }
+        if (CV) l.dem[tid] = (tid < M - 1) ? a.demand[bi * (M - 1) + tid] : 0.0f;
         if (SD) l.dem[tid] = (tid < M) ? a.rem[r * M + tid] : 0.0f;
     }
     if (tid == 0) l.done = a.done[r] != 0;
@@ -173,15 +182,16 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
     constexpr int fw = 0;      // the wavefront that runs the serial "finish" section of a step
 
     int64_t first = 0, cur = 0, istep = 1, i0 = 0;
-    float used = 0.0f, vcap = 0.0f;
+    float used = 0.0f, vcap = 0.0f, now = 0.0f;
     int count = 0;
-    float gq[2] = {0.f, 0.f}, cv[2] = {0.f, 0.f}, p1f[2] = {0.f, 0.f}, mydem[2] = {0.f, 0.f};
+    float gq[2] = {0.f, 0.f}, cv[2] = {0.f, 0.f}, cv2[2] = {0.f, 0.f}, p1f[2] = {0.f, 0.f}, mydem[2] = {0.f, 0.f};
     bool done = l.done != 0;
     if (wv == fw) {
         cur = a.cur[r];
         if (ENV == EAMRL_ENV_TSP) { first = a.first[r]; istep = a.istep[r]; }
         else { used = a.used[r]; vcap = a.vcap[r]; }
         if (PC || OP) { istep = a.istep[r]; i0 = istep; }
+        if (TW) now = a.time[r];
         // remaining feasible (TSP) / visited (CVRP; PCTSP: visited customers) node count, kept incrementally
         // (== the reference's mask.sum / visited.sum)
         const int c0 = (ENV == EAMRL_ENV_TSP) ? (in0 && l.msk[n0] != 0) : (in0 && l.vis[n0] != 0 && !(PC && n0 == 0));
@@ -194,11 +204,12 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             cv[k] = a.cvec[e];
             if (ENV == EAMRL_ENV_TSP && istep > 0) p1f[k] = a.Pa[(bi * M + first) * ld + e];
             const int nn = lane + 64 * k;
-            if (ENV == EAMRL_ENV_CVRP && nn >= 1 && nn < M) mydem[k] = l.dem[nn - 1];
+            if (CV && nn >= 1 && nn < M) mydem[k] = l.dem[nn - 1];
             float ctx;
             if (ENV == EAMRL_ENV_TSP) ctx = (istep == 0) ? cv[k] : p1f[k] + Plds[cur * RE + e];
             else if (PC) ctx = fma_(cv[k], (vcap - used) < 0.0f ? 0.0f : (vcap - used), Plds[cur * RE + e]);
             else ctx = fma_(cv[k], vcap - used, Plds[cur * RE + e]);
+            if (TW) { cv2[k] = a.cvec[RE + e]; ctx = fma_(cv2[k], now, ctx); }
             l.q[e] = ctx + gq[k];
         }
     }
@@ -490,6 +501,15 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                 if (lane == 0) { l.msk[0] = !((cur == 0) && any_free); l.done = done; }
             } else {
                 const int N = M - 1;
+                float cx = 0.0f, cy = 0.0f;
+                if (TW) {       // clock (cvrptw/env.py:118-138)
+                    cx = l.xy[2 * sel]; cy = l.xy[2 * sel + 1];
+                    const float dx = l.xy[2 * cur] - cx, dy = l.xy[2 * cur + 1] - cy;
+                    const float arrive = now + __builtin_sqrtf(fma_(dy, dy, dx * dx));
+                    const float ws = l.twv[sel];
+                    const float start = arrive > ws ? arrive : ws;
+                    now = (sel != 0 ? 1.0f : 0.0f) * (start + l.twv[2 * RNP + sel]);
+                }
                 int di = sel - 1;
                 di = di < 0 ? 0 : (di > N - 1 ? N - 1 : di);
                 used = (used + l.dem[di]) * (sel != 0 ? 1.0f : 0.0f);
@@ -500,7 +520,11 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                 if (lane == 0) { l.vis[sel] = 1; l.done = done; }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int k = 0; k < 2; ++k) l.q[lane + 64 * k] = fma_(cv[k], vcap - used, Plds[cur * RE + lane + 64 * k]) + gq[k];
+                for (int k = 0; k < 2; ++k) {
+                    float qv = fma_(cv[k], vcap - used, Plds[cur * RE + lane + 64 * k]);
+                    if (TW) qv = fma_(cv2[k], now, qv);
+                    l.q[lane + 64 * k] = qv + gq[k];
+                }
                 const float lim = vcap + 1e-5f;
                 int free_n = 0;
 #pragma unroll
@@ -508,12 +532,24 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                     const int nn = lane + 64 * k;
                     if (nn >= 1 && nn < M) {
                         const int blocked = (l.vis[nn] != 0) | ((mydem[k] + used) > lim);
-                        l.msk[nn] = !blocked;
+                        int ok = !blocked;
+                        if (TW) {
+                            const float dx = cx - l.xy[2 * nn], dy = cy - l.xy[2 * nn + 1];
+                            ok &= (now + __builtin_sqrtf(fma_(dy, dy, dx * dx))) <= l.twv[RNP + nn];
+                        }
+                        l.msk[nn] = ok;
                         free_n |= !blocked;
                     }
                 }
                 const bool any_free = __ballot(free_n) != 0ull;
-                if (lane == 0) l.msk[0] = !((cur == 0) && any_free);
+                if (lane == 0) {
+                    int ok0 = !((cur == 0) && any_free);
+                    if (TW) {
+                        const float dx = cx - l.xy[0], dy = cy - l.xy[1];
+                        ok0 &= (now + __builtin_sqrtf(fma_(dy, dy, dx * dx))) <= l.twv[RNP];
+                    }
+                    l.msk[0] = ok0;
+                }
             }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -537,7 +573,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
     }
     if (tid < M) {
         a.mask[r * M + tid] = l.msk[tid];
-        if (ENV == EAMRL_ENV_CVRP || PC || OP) a.visited[r * M + tid] = l.vis[tid];
+        if (CV || PC || OP) a.visited[r * M + tid] = l.vis[tid];
         if (SD) a.rem[r * M + tid] = l.dem[tid];
     }
     if (wv == fw && lane == 0) {
@@ -546,6 +582,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         if (ENV == EAMRL_ENV_TSP) { a.first[r] = first; a.istep[r] = istep; }
         else a.used[r] = used;
         if (PC || OP) a.istep[r] = i0;    // launch_rollout_pad adds the batch's step count
+        if (TW) a.time[r] = now;
         atomicMax(a.steps_out, t);
         if (!done) st_flags |= EAMRL_ST_STEP_OVERRUN;
         if (st_flags) atomicOr(a.status, st_flags);
@@ -557,7 +594,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
 template <int ENV, int CP, int CR, bool MS>
 int launch_ms(const DecArgs& a, int S, int G, hipStream_t st)
 {
-    const size_t lds = ((sizeof(ResLds<CP, res_tmax(ENV), res_sdf(ENV), res_xyf(ENV)>) + 15) & ~size_t(15)) +
+    const size_t lds = ((sizeof(ResLds<CP, res_tmax(ENV), res_sdf(ENV), res_xyf(ENV), res_twf(ENV)>) + 15) & ~size_t(15)) +
                        (size_t)a.M * RE * sizeof(float);
     auto k = k_rollout_resident<ENV, CP, CR, MS>;
     if (lds > 64 * 1024 &&
@@ -623,7 +660,8 @@ int launch_rollout_resident(int env, const DecArgs& a, hipStream_t st)
     return env == EAMRL_ENV_TSP ? launch_env<EAMRL_ENV_TSP>(a, st)
          : env == EAMRL_ENV_CVRP ? launch_env<EAMRL_ENV_CVRP>(a, st)
          : env == EAMRL_ENV_SDVRP ? launch_env<EAMRL_ENV_SDVRP>(a, st)
-         : env == EAMRL_ENV_PCTSP ? launch_env<EAMRL_ENV_PCTSP>(a, st) : launch_env<EAMRL_ENV_OP>(a, st);
+         : env == EAMRL_ENV_PCTSP ? launch_env<EAMRL_ENV_PCTSP>(a, st)
+         : env == EAMRL_ENV_OP ? launch_env<EAMRL_ENV_OP>(a, st) : launch_env<EAMRL_ENV_CVRPTW>(a, st);
 }
 
 }  // namespace eamrl

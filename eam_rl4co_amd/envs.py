@@ -114,6 +114,55 @@ class CVRPGenerator(Generator):
                           batch_size=batch_size)
 
 
+class CVRPTWGenerator(CVRPGenerator):
+    """CVRP instances on a [0, 150]^2 grid plus integer time windows inside [distance from depot, max_time - distance
+    back] and zero service durations (cvrptw/generator.py:14-142).  Same draw order as the reference."""
+
+    def __init__(self, num_loc: int = 20, min_loc: float = 0.0, max_loc: float = 150.0, loc_distribution="uniform",
+                 depot_distribution="uniform", min_demand: int = 1, max_demand: int = 10, demand_distribution="uniform",
+                 vehicle_capacity: float = 1.0, capacity: float = None, max_time: float = 480, scale: bool = False, **kwargs):
+        super().__init__(num_loc=num_loc, min_loc=min_loc, max_loc=max_loc, loc_distribution=loc_distribution,
+                         depot_distribution=depot_distribution, min_demand=min_demand, max_demand=max_demand,
+                         demand_distribution=demand_distribution, vehicle_capacity=vehicle_capacity, capacity=capacity,
+                         **kwargs)
+        self.max_loc, self.min_time, self.max_time, self.scale = max_loc, 0.0, max_time, scale
+
+    def _generate(self, batch_size):
+        td = super()._generate(batch_size)
+        durations = torch.zeros(*batch_size, self.num_loc + 1, dtype=torch.float32)
+        dist = (td["depot"] - td["locs"].transpose(0, 1)).norm(p=2, dim=-1).transpose(0, 1)
+        dist = torch.cat((torch.zeros(*batch_size, 1), dist), dim=1)
+        upper_bound = self.max_time - dist - durations
+        ts_1 = torch.rand(*batch_size, self.num_loc + 1)
+        ts_2 = torch.rand(*batch_size, self.num_loc + 1)
+        min_ts = (dist + (upper_bound - dist) * ts_1).int()
+        max_ts = (dist + (upper_bound - dist) * ts_2).int()
+        min_times, max_times = torch.min(min_ts, max_ts), torch.max(min_ts, max_ts)
+        min_times[..., :, 0] = 0.0
+        max_times[..., :, 0] = self.max_time
+        mask = min_times == max_times           # empty windows are widened by one unit, downwards first
+        if torch.any(mask):
+            min_tmp = min_times.clone()
+            min_tmp[mask] = torch.max(dist[mask].int(), min_tmp[mask] - 1)
+            min_times = min_tmp
+            mask = min_times == max_times
+            if torch.any(mask):
+                max_tmp = max_times.clone()
+                max_tmp[mask] = torch.min(torch.floor(upper_bound[mask]).int(),
+                                          torch.max(torch.ceil(min_tmp[mask] + durations[mask]).int(), max_tmp[mask] + 1))
+                max_times = max_tmp
+        if self.scale:
+            durations, min_times, max_times = durations / self.max_time, min_times / self.max_time, max_times / self.max_time
+            td["depot"] = td["depot"] / self.max_time
+            td["locs"] = td["locs"] / self.max_time
+        time_windows = torch.stack((min_times, max_times), dim=-1)
+        assert torch.all(min_times < max_times), \
+            "Please make sure the relation between max_loc and max_time allows for feasible solutions."
+        durations[:, 0] = 0.0
+        td.update({"durations": durations, "time_windows": time_windows})
+        return td
+
+
 # Kool et al. (2019) expected tour lengths used to scale the PCTSP penalties (pctsp/generator.py:14)
 MAX_LENGTHS = {20: 2.0, 50: 3.0, 100: 4.0}
 
@@ -307,7 +356,7 @@ class RL4COEnvBase:
 
     def get_num_starts(self, td):
         n = td["action_mask"].shape[-1]
-        return n - 1 if self.name in ("cvrp", "sdvrp", "pctsp", "op") else n          # depot cannot be a start node (utils/ops.py:120-130)
+        return n - 1 if self.name in ("cvrp", "sdvrp", "pctsp", "op", "cvrptw") else n          # depot cannot be a start node (utils/ops.py:120-130)
 
     def select_start_nodes(self, td, num_starts):
         """POMO start nodes: flat row j = s*B + b starts at node s (+1 with a depot) (utils/ops.py:133-169)."""
@@ -317,7 +366,7 @@ class RL4COEnvBase:
             # some customers are out of reach from the start: resample among the reachable ones (utils/ops.py:158-169)
             sel = torch.multinomial(td["action_mask"][..., 1:].float(), num_starts, replacement=True) + 1
             return sel.t().reshape(-1)                     # "b n -> (n b)"
-        return sel + 1 if self.name in ("cvrp", "sdvrp", "pctsp", "op") else sel
+        return sel + 1 if self.name in ("cvrp", "sdvrp", "pctsp", "op", "cvrptw") else sel
 
     def check_solution_validity(self, td, actions) -> None:
         raise NotImplementedError
@@ -564,6 +613,78 @@ class SDVRPEnv(CVRPEnv):
         assert bad[0] == 0, "All demand must be satisfied"
 
 
+class CVRPTWEnv(CVRPEnv):
+    """CVRP with time windows (rl4co/envs/routing/cvrptw/env.py:26-330): the vehicle's clock advances by travel, waiting
+    and service; a customer is feasible only if it can be reached before its window closes; the depot resets the clock."""
+
+    name = "cvrptw"
+
+    def __init__(self, generator: CVRPTWGenerator = None, generator_params: dict = {}, **kwargs):
+        RL4COEnvBase.__init__(self, **kwargs)
+        self.generator = generator if generator is not None else CVRPTWGenerator(**generator_params)
+
+    @staticmethod
+    def _tw_f32(td):
+        """The kernels take the windows as float32 (the reference's int32 windows convert exactly)."""
+        return td["time_windows"].to(torch.float32).contiguous(), td["durations"].to(torch.float32).contiguous()
+
+    def _reset(self, td=None, batch_size=None):
+        dev = td.device
+        n = td["locs"].shape[-2]
+        locs = torch.cat((td["depot"][..., None, :], td["locs"]), -2)
+        demand = td["demand"]
+        vcap = torch.full((*batch_size, 1), self.generator.vehicle_capacity, dtype=torch.float32, device=dev)
+        out = TensorDict({
+            "locs": locs,
+            "demand": demand,
+            "current_node": torch.zeros(*batch_size, 1, dtype=torch.int64, device=dev),
+            "current_time": torch.zeros(*batch_size, 1, dtype=torch.float32, device=dev),
+            "used_capacity": torch.zeros(*batch_size, 1, dtype=torch.float32, device=dev),
+            "vehicle_capacity": vcap,
+            "visited": torch.zeros(*batch_size, n + 1, dtype=torch.uint8, device=dev),
+            "durations": td["durations"],
+            "time_windows": td["time_windows"],
+        }, batch_size=batch_size)
+        # reset-state mask in closed form: the CVRP rule (cvrp/env.py:132-144) AND "reachable from the depot in time"
+        fits = ~((demand + 0.0) > (vcap + 1e-5))
+        cvrp_mask = torch.cat((~fits.any(-1, keepdim=True), fits), -1)
+        dist = (locs[..., 0:1, :] - locs).norm(p=2, dim=-1)
+        out.set("action_mask", cvrp_mask & (0.0 + dist <= td["time_windows"][..., 1]))
+        return out
+
+    def _step(self, td):
+        mask = td["action_mask"]
+        if not mask.is_contiguous():
+            mask = mask.contiguous()
+        done = _flat(td["done"], torch.bool)
+        tw, dur = self._tw_f32(td)
+        ops.cvrptw_step_mask_(td["visited"], _flat(td["used_capacity"], torch.float32),
+                              _flat(td["vehicle_capacity"], torch.float32), td["demand"].contiguous(),
+                              _flat(td["current_node"], torch.int64), _flat(td["current_time"], torch.float32),
+                              td["locs"].contiguous(), tw, dur, td["action"].reshape(-1).contiguous(), mask, done)
+        td.update({"action_mask": mask, "done": done, "reward": torch.zeros_like(done)})
+        return td
+
+    def get_action_mask(self, td):
+        mask = torch.empty(td["visited"].shape, dtype=torch.bool, device=td["visited"].device)
+        tw, dur = self._tw_f32(td)
+        ops.cvrptw_step_mask_(td["visited"], _flat(td["used_capacity"], torch.float32),
+                              _flat(td["vehicle_capacity"], torch.float32), td["demand"].contiguous(),
+                              _flat(td["current_node"], torch.int64), _flat(td["current_time"], torch.float32),
+                              td["locs"].contiguous(), tw, dur, None, mask)
+        return mask
+
+    def check_solution_validity(self, td, actions) -> None:
+        super().check_solution_validity(td, actions)          # CVRP: tours and capacity
+        tw, dur = self._tw_f32(td)
+        late = ops.cvrptw_check_time(actions.contiguous(), td["locs"].contiguous(), tw, dur).tolist()
+        assert late[0] == 0, "vehicle cannot start service before deadline"
+
+    @staticmethod
+    def load_data(fpath, batch_size=[]):
+        return load_npz_to_tensordict(fpath)
+
+
 class PCTSPEnv(RL4COEnvBase):
     """Prize Collecting TSP (rl4co/envs/routing/pctsp/env.py:21-260): visit customers until the collected prize
     reaches 1 (or everyone is visited), then return to the depot; reward = saved penalties - (length + all penalties)."""
@@ -701,12 +822,12 @@ class OPEnv(RL4COEnvBase):
         assert bad[1] == 0, "Max length exceeded"
 
 
-ENV_REGISTRY = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv}
+ENV_REGISTRY = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv, "cvrptw": CVRPTWEnv}
 
 
 def get_env(env_name: str, *args, **kwargs) -> RL4COEnvBase:
     cls = ENV_REGISTRY.get(env_name)
     if cls is None:
         raise ValueError(f"Unknown environment {env_name}. Available environments: {list(ENV_REGISTRY)} "
-                         "(only the TSP / CVRP / SDVRP / PCTSP / OP rollout path is built for MI355X)")
+                         "(only the TSP / CVRP / CVRPTW / SDVRP / PCTSP / OP rollout path is built for MI355X)")
     return cls(*args, **kwargs)

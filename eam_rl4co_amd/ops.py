@@ -8,11 +8,11 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ENV_CVRP, ENV_OP, ENV_PCTSP, ENV_SDVRP, ENV_TSP, EVALUATE, GREEDY, NORM_BATCH_EVAL, NORM_INSTANCE, SAMPLE,  # noqa: F401
+from ._lib import (ENV_CVRP, ENV_CVRPTW, ENV_OP, ENV_PCTSP, ENV_SDVRP, ENV_TSP, EVALUATE, GREEDY, NORM_BATCH_EVAL, NORM_INSTANCE, SAMPLE,  # noqa: F401
                    ST_INFEASIBLE, ST_NAN_LOGITS, ST_STEP_OVERRUN)
 
 MODES = {"greedy": GREEDY, "sampling": SAMPLE, "evaluate": EVALUATE}
-ENVS = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP, "pctsp": ENV_PCTSP, "op": ENV_OP}
+ENVS = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP, "pctsp": ENV_PCTSP, "op": ENV_OP, "cvrptw": ENV_CVRPTW}
 
 
 def _need_gpu(t: torch.Tensor, name: str):
@@ -254,6 +254,49 @@ def pctsp_step_mask_(visited, prize_tot, pen_tot, prize, penalty, cur, istep, ac
                                          _ptr(_bytes(done)) if done is not None else None, R, B, M, _stream(mask)),
                "eamrl_pctsp_step_mask")
     return mask
+
+
+def cvrptw_step_mask_(visited, used, vcap, demand, cur, time, locs, tw, dur, action, mask, done=None):
+    """CVRPTWEnv._step + get_action_mask in place (cvrptw/env.py:103-138); action None: mask only.
+    tw [B, M, 2] and dur [B, M] as float32."""
+    lib = _lib.load()
+    R, M = visited.shape
+    B, N = demand.shape
+    if N + 1 != M or R % B:
+        raise ValueError("cvrptw_step: shape mismatch")
+    _chk(visited, "visited", torch.uint8)
+    _chk(used, "used_capacity", torch.float32, (R,))
+    _chk(vcap, "vehicle_capacity", torch.float32, (R,))
+    _chk(demand, "demand", torch.float32)
+    _chk(cur, "current_node", torch.int64, (R,))
+    _chk(time, "current_time", torch.float32, (R,))
+    _chk(locs, "locs", torch.float32, (B, M, 2))
+    _chk(tw, "time_windows", torch.float32, (B, M, 2))
+    _chk(mask, "action_mask", torch.bool, (R, M))
+    if action is not None:
+        _chk(dur, "durations", torch.float32, (B, M))
+        _chk(action, "action", torch.int64, (R,))
+        _chk(done, "done", torch.bool, (R,))
+    _lib.check(lib.eamrl_cvrptw_step_mask(_ptr(visited), _ptr(used), _ptr(vcap), _ptr(demand), _ptr(cur), _ptr(time),
+                                          _ptr(locs), _ptr(tw), _ptr(dur), _ptr(action), _ptr(_bytes(mask)),
+                                          _ptr(_bytes(done)) if done is not None else None, R, B, N, _stream(mask)),
+               "eamrl_cvrptw_step_mask")
+    return mask
+
+
+def cvrptw_check_time(actions, locs, tw, dur):
+    """-> device int32[2]: [0] = rows that start a service after its window closed (cvrptw/env.py:203-227)."""
+    lib = _lib.load()
+    _chk(actions, "actions", torch.int64)
+    _chk(locs, "locs", torch.float32)
+    B, M, _ = locs.shape
+    _chk(tw, "time_windows", torch.float32, (B, M, 2))
+    _chk(dur, "durations", torch.float32, (B, M))
+    R, T = actions.shape
+    bad = torch.zeros(2, device=actions.device, dtype=torch.int32)
+    _lib.check(lib.eamrl_cvrptw_check_time(_ptr(actions), _ptr(locs), _ptr(tw), _ptr(dur), R, B, M, T, _ptr(bad),
+                                           _stream(actions)), "eamrl_cvrptw_check_time")
+    return bad
 
 
 def op_step_mask_(visited, tour_len, prize_tot, prize, locs, maxlen, cur, istep, action, mask, done=None):
@@ -536,11 +579,14 @@ class RolloutState:
         self.mask = torch.ones(R, M, dtype=torch.bool, device=device)
         self.used = self.vcap = self.visited = self.rem = None
         self.demand = demand
-        self.locs = None                                                       # op: node coordinates [B, M, 2]
-        if env_name in ("cvrp", "sdvrp", "pctsp", "op"):
+        self.locs = None                                                       # op, cvrptw: node coordinates [B, M, 2]
+        self.time = self.tw = self.dur = None                                  # cvrptw: clock [R], windows, service times
+        if env_name == "cvrptw":
+            self.time = torch.zeros(R, dtype=torch.float32, device=device)
+        if env_name in ("cvrp", "sdvrp", "pctsp", "op", "cvrptw"):
             self.used = torch.zeros(R, dtype=torch.float32, device=device)     # pctsp: cur_total_prize; op: tour_length
             self.vcap = torch.ones(R, dtype=torch.float32, device=device)      # pctsp: prize_required; op: max_length[:, 0]
-        if env_name in ("cvrp", "pctsp", "op"):
+        if env_name in ("cvrp", "pctsp", "op", "cvrptw"):
             self.visited = torch.zeros(R, M, dtype=torch.uint8, device=device)
         if env_name == "sdvrp":
             self.rem = torch.zeros(R, M, dtype=torch.float32, device=device)   # demand_with_depot
@@ -548,7 +594,7 @@ class RolloutState:
     def reorder_(self, idx):
         """Rows taken from rows `idx` (beam search: every beam continues the state of its parent beam).  vcap is
         per instance and the row order keeps r % B, so it needs no reordering, nor does demand."""
-        for name in ("first", "cur", "istep", "done", "mask", "used", "visited", "rem"):
+        for name in ("first", "cur", "istep", "done", "mask", "used", "visited", "rem", "time"):
             v = getattr(self, name)
             if v is not None:
                 setattr(self, name, v.index_select(0, idx).contiguous())
@@ -561,6 +607,7 @@ class RolloutState:
         s.visited = _ptr(None if self.visited is None else _bytes(self.visited))
         s.rem = _ptr(getattr(self, "rem", None))
         s.locs = _ptr(getattr(self, "locs", None))
+        s.time, s.tw, s.dur = (_ptr(getattr(self, k, None)) for k in ("time", "tw", "dur"))
         return s
 
 
@@ -584,6 +631,14 @@ def _validate_state(st: RolloutState, cache: DecodeCache):
             _chk(_bytes(st.visited), "visited", torch.uint8, (R, M))
             _chk(st.demand, "real_prize", torch.float32, (cache.B, M))
             _chk(st.istep, "i", torch.int64, (R,))
+        elif st.env_name == "cvrptw":
+            _chk(st.visited, "visited", torch.uint8, (R, M))
+            _chk(st.demand, "demand", torch.float32, (cache.B, M - 1))
+            _chk(st.time, "current_time", torch.float32, (R,))
+            _chk(st.locs, "locs", torch.float32, (cache.B, M, 2))
+            _chk(st.tw, "time_windows", torch.float32, (cache.B, M, 2))
+            _chk(st.dur, "durations", torch.float32, (cache.B, M))
+            _chk(cache.cvec, "context state columns", torch.float32, (2 * cache.E,))
         elif st.env_name == "op":
             _chk(_bytes(st.visited), "visited", torch.uint8, (R, M))
             _chk(st.demand, "max_length", torch.float32, (cache.B, M))
@@ -626,7 +681,7 @@ def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, giv
     _validate_state(st, cache)
     R, M, dev = st.R, st.M, st.mask.device
     if t_max is None:
-        t_max = {"tsp": M, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1, "pctsp": M + 1, "op": M + 1}[st.env_name]
+        t_max = {"tsp": M, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1, "pctsp": M + 1, "op": M + 1, "cvrptw": 2 * M + 1}[st.env_name]
     t_given = 0
     if noise is not None:
         _chk(noise, "noise", torch.float32)

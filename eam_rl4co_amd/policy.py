@@ -70,6 +70,23 @@ class PCTSPInitEmbedding(nn.Module):
         return torch.cat((depot, cust), 1)
 
 
+class VRPTWInitEmbedding(nn.Module):
+    """x, y, demand, window start, window end, service time per customer (nn/env_embeddings/init.py:141-157)."""
+
+    def __init__(self, embed_dim, linear_bias=True):
+        super().__init__()
+        self.init_embed = nn.Linear(6, embed_dim, linear_bias)
+        self.init_embed_depot = nn.Linear(2, embed_dim, linear_bias)
+
+    def forward(self, td):
+        locs = td["locs"]
+        depot = ops.linear(locs[:, :1, :].contiguous(), self.init_embed_depot.weight, self.init_embed_depot.bias)
+        feat = torch.cat((locs[:, 1:, :], td["demand"][..., None], td["time_windows"][..., 1:, :].to(torch.float32),
+                          td["durations"][..., 1:, None]), -1)
+        cust = ops.linear(feat, self.init_embed.weight, self.init_embed.bias)
+        return torch.cat((depot, cust), 1)
+
+
 class OPInitEmbedding(nn.Module):
     """x, y, prize per customer; depot embedded separately (nn/env_embeddings/init.py:260-286)."""
 
@@ -189,7 +206,8 @@ class AttentionModelEncoder(nn.Module):
         self.env_name = env_name
         if init_embedding is None:
             init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding, "sdvrp": VRPInitEmbedding,
-                              "pctsp": PCTSPInitEmbedding, "op": OPInitEmbedding}[env_name](embed_dim)
+                              "pctsp": PCTSPInitEmbedding, "op": OPInitEmbedding,
+                              "cvrptw": VRPTWInitEmbedding}[env_name](embed_dim)
         self.init_embedding = init_embedding
         self.net = GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden) \
             if net is None else net
@@ -248,8 +266,8 @@ class AttentionModelDecoder(nn.Module):
                                       "outside the MI355X rollout path (TSP / CVRP / SDVRP AttentionModel only)")
         assert embed_dim % num_heads == 0
         self.env_name, self.embed_dim, self.num_heads = env_name, embed_dim, num_heads
-        self.context_embedding = _ContextParams(embed_dim, 2 * embed_dim if env_name == "tsp" else embed_dim + 1,
-                                                placeholder=(env_name == "tsp"))
+        ctx_dim = {"tsp": 2 * embed_dim, "cvrptw": embed_dim + 2}.get(env_name, embed_dim + 1)   # node(s) + state columns
+        self.context_embedding = _ContextParams(embed_dim, ctx_dim, placeholder=(env_name == "tsp"))
         self.dynamic_embedding = SDVRPDynamicEmbedding(embed_dim) if env_name == "sdvrp" else StaticEmbedding()
         self.is_dynamic_embedding = env_name == "sdvrp"
         self.pointer = _PointerParams(embed_dim, num_heads, mask_inner, out_bias_pointer_attn, check_nan)
@@ -297,7 +315,8 @@ class AttentionModelDecoder(nn.Module):
                 cvec = ops.linear(ph[None, :].detach(), Wctx.detach())[0].contiguous()
             else:
                 Wb = None
-                cvec = Wctx[:, E].contiguous()
+                # state columns: capacity (CVRP-like), prize / length left (PCTSP / OP); CVRPTW: capacity | time -> [2E]
+                cvec = Wctx[:, E:].t().reshape(-1).contiguous() if self.env_name == "cvrptw" else Wctx[:, E].contiguous()
             self._wc, self._wc_key = (Wa.detach(), None if Wb is None else Wb.detach(), cvec.detach()), key
         return self._wc
 
@@ -321,6 +340,9 @@ def _env_step_(st: ops.RolloutState, action):
         ops.cvrp_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, action, st.mask, st.done)
     elif st.env_name == "pctsp":
         ops.pctsp_step_mask_(st.visited, st.used, None, st.demand, None, st.cur, st.istep, action, st.mask, st.done)
+    elif st.env_name == "cvrptw":
+        ops.cvrptw_step_mask_(st.visited, st.used, st.vcap, st.demand, st.cur, st.time, st.locs, st.tw, st.dur, action,
+                              st.mask, st.done)
     elif st.env_name == "op":
         ops.op_step_mask_(st.visited, st.used, None, None, st.locs, st.demand, st.cur, st.istep, action, st.mask, st.done)
     else:
@@ -330,7 +352,7 @@ def _env_step_(st: ops.RolloutState, action):
 def _max_decode_steps(env_name, M, npre=0):
     """TSP: one step per remaining node; CVRP: every customer visit is followed by at most one depot visit; SDVRP: as
     CVRP plus at most one split delivery per trip."""
-    return {"tsp": M - npre, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1, "pctsp": M + 1, "op": M + 1}[env_name]
+    return {"tsp": M - npre, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1, "pctsp": M + 1, "op": M + 1, "cvrptw": 2 * M + 1}[env_name]
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -368,6 +390,7 @@ def state_from_td(env_name, td, num_starts: int = 0, copy: bool = True) -> ops.R
     done = td["done"] if "done" in td.keys() else torch.zeros(B, dtype=torch.bool, device=dev)
     st.done = rep(done, torch.bool)
     st.first = st.istep = st.used = st.vcap = st.visited = st.demand = st.rem = st.locs = None
+    st.time = st.tw = st.dur = None
     if env_name == "tsp":
         st.first = rep(td["first_node"], torch.int64)
         st.istep = rep(td["i"], torch.int64)
@@ -388,10 +411,15 @@ def state_from_td(env_name, td, num_starts: int = 0, copy: bool = True) -> ops.R
         st.used = rep(td["used_capacity"], torch.float32)
         st.vcap = rep(td["vehicle_capacity"], torch.float32)
         st.demand = td["demand"].contiguous()
-        if env_name == "cvrp":
+        if env_name in ("cvrp", "cvrptw"):
             st.visited = rep(td["visited"], torch.uint8)
         else:
             st.rem = rep(td["demand_with_depot"], torch.float32)
+        if env_name == "cvrptw":
+            st.time = rep(td["current_time"], torch.float32)
+            st.locs = td["locs"].contiguous()
+            st.tw = td["time_windows"].to(torch.float32).contiguous()
+            st.dur = td["durations"].to(torch.float32).contiguous()
     return st
 
 
@@ -411,7 +439,9 @@ def state_to_td(env_name, st: ops.RolloutState, td, locs_rows=None):
     else:
         out.update({"current_node": st.cur.reshape(R, 1), "used_capacity": st.used.reshape(R, 1),
                     "vehicle_capacity": st.vcap.reshape(R, 1)})
-        out.update({"visited": st.visited} if env_name == "cvrp" else {"demand_with_depot": st.rem})
+        out.update({"visited": st.visited} if env_name in ("cvrp", "cvrptw") else {"demand_with_depot": st.rem})
+        if env_name == "cvrptw":
+            out["current_time"] = st.time.reshape(R, 1)
     B = td.batch_size[0]
     S = R // B
     for k, v in td.items():
@@ -443,9 +473,9 @@ class AttentionModelPolicy(nn.Module):
             log.error("Found %d unused kwargs: %s", len(unused_kwargs), unused_kwargs)
         if isinstance(env_name, RL4COEnvBase):
             env_name = env_name.name
-        if env_name not in ("tsp", "cvrp", "sdvrp", "pctsp", "op"):
-            raise NotImplementedError(f"env_name={env_name!r}: the MI355X rollout path covers 'tsp', 'cvrp', 'sdvrp', "
-                                      "'pctsp' and 'op'")
+        if env_name not in ("tsp", "cvrp", "cvrptw", "sdvrp", "pctsp", "op"):
+            raise NotImplementedError(f"env_name={env_name!r}: the MI355X rollout path covers 'tsp', 'cvrp', 'cvrptw', "
+                                      "'sdvrp', 'pctsp' and 'op'")
         if moe_kwargs not in (None, {"encoder": None, "decoder": None}) or any(
                 x is not None for x in (sdpa_fn, sdpa_fn_encoder, sdpa_fn_decoder, encoder_network)):
             raise NotImplementedError("MoE / sdpa_fn / encoder_network injection is outside the MI355X rollout path")
@@ -575,7 +605,7 @@ class AttentionModelPolicy(nn.Module):
         # x + 0 is exact in the lane tree), nor the log-likelihood sum, nor validity.
         actions_pad = torch.cat(pre_actions + [acts], 1) if pre_actions else acts
         logp_pad = torch.cat(pre_logps + [lps], 1) if pre_logps else lps
-        native_env = type(env).__name__ in ("TSPEnv", "CVRPEnv", "SDVRPEnv", "PCTSPEnv", "OPEnv") and type(env).__module__ == RL4COEnvBase.__module__
+        native_env = type(env).__name__ in ("TSPEnv", "CVRPEnv", "SDVRPEnv", "PCTSPEnv", "OPEnv", "CVRPTWEnv") and type(env).__module__ == RL4COEnvBase.__module__
         fast = info is not None and native_env and not select_best
         reward_pad = ll_pad = bad = None
         if fast:
@@ -587,7 +617,7 @@ class AttentionModelPolicy(nn.Module):
                     reward_pad = ops.op_reward(td["prize"].contiguous(), actions_pad)
                 else:
                     reward_pad = ops.tour_length_reward(locs, actions_pad, with_depot=(self.env_name != "tsp"))
-                if env.check_solution and self.env_name != "sdvrp":   # sdvrp: replayed on the exact slice in _finish
+                if env.check_solution and self.env_name not in ("sdvrp", "cvrptw"):   # those: checked in _finish
                     bad = (ops.check_solution("tsp", actions_pad) if self.env_name == "tsp" else
                            ops.check_solution("pctsp", actions_pad, td["real_prize"].contiguous())
                            if self.env_name == "pctsp" else
@@ -647,6 +677,8 @@ class AttentionModelPolicy(nn.Module):
                     else:
                         assert bad_counts[0] == 0, "Invalid tour"
                         assert bad_counts[1] == 0, "Used more than capacity"
+                elif self.env_name == "cvrptw" and env.check_solution:
+                    env.check_solution_validity(td_out, actions_out.contiguous())      # CVRP part + time-window replay
                 elif self.env_name == "sdvrp" and env.check_solution:
                     # the reference's replay starts from (-capacity, demand...) and its verdict depends on where the
                     # action tensor ends, so it runs on the exact [R, T] slice rather than on the padded one

@@ -47,6 +47,9 @@ def encode_autograd(policy, td):
             feat = torch.cat((locs[:, 1:], td["expected_prize"][..., None], td["penalty"][..., 1:, None]), -1)
         elif policy.env_name == "op":
             feat = torch.cat((locs[:, 1:], td["prize"][..., 1:, None]), -1)
+        elif policy.env_name == "cvrptw":
+            feat = torch.cat((locs[:, 1:], td["demand"][..., None], td["time_windows"][..., 1:, :].float(),
+                              td["durations"][..., 1:, None]), -1)
         else:
             feat = torch.cat((locs[:, 1:], td["demand"][..., None]), -1)
         h = torch.cat((depot, F.linear(feat, ie.init_embed.weight, ie.init_embed.bias)), 1)
@@ -127,6 +130,38 @@ def _pctsp_states(actions, prize_rows, prize_required):
         visited[ar, a] = True
         cur = a
     return torch.stack(curs, 1), torch.stack(rems, 1), torch.stack(masks, 1)
+
+
+def _cvrptw_states(actions, demand_rows, vcap, locs_rows, tw_rows, dur_rows):
+    """-> cur [R,T], free capacity [R,T], clock [R,T], mask [R,T,M] before each step (cvrptw/env.py:103-138).
+    tw_rows [R,M,2] and dur_rows [R,M] as float32."""
+    R, T = actions.shape
+    M = locs_rows.shape[1]
+    N = M - 1
+    dev = actions.device
+    visited = torch.zeros(R, M, dtype=torch.bool, device=dev)
+    used = torch.zeros(R, dtype=torch.float32, device=dev)
+    now = torch.zeros(R, dtype=torch.float32, device=dev)
+    cur = torch.zeros(R, dtype=torch.int64, device=dev)
+    lim = vcap + 1e-5
+    curs, rems, nows, masks = [], [], [], []
+    ar = torch.arange(R, device=dev)
+    for t in range(T):
+        blocked = visited[:, 1:] | ((demand_rows + used[:, None]) > lim[:, None])
+        depot_blocked = (cur == 0) & (~blocked).any(-1)
+        dist = (locs_rows[ar, cur][:, None, :] - locs_rows).norm(p=2, dim=-1)
+        in_time = now[:, None] + dist <= tw_rows[..., 1]
+        masks.append(~torch.cat((depot_blocked[:, None], blocked), 1) & in_time)
+        curs.append(cur)
+        rems.append(vcap - used)
+        nows.append(now)
+        a = actions[:, t]
+        now = (a != 0).float() * (torch.maximum(now + dist[ar, a], tw_rows[ar, a, 0]) + dur_rows[ar, a])
+        used = (used + demand_rows[ar, (a - 1).clamp(0, N - 1)]) * (a != 0).float()
+        visited = visited.clone()
+        visited[ar, a] = True
+        cur = a
+    return torch.stack(curs, 1), torch.stack(rems, 1), torch.stack(nows, 1), torch.stack(masks, 1)
 
 
 def _op_states(actions, locs_rows, maxlen_rows):
@@ -219,6 +254,10 @@ def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, tempe
             ctx_in = torch.cat((embr[ar, first], embr[ar, cur]), -1)                       # [Rc, T, 2E]
             if not multistart:   # step 0 uses the learned placeholder (context.py:118-131)
                 ctx_in = torch.cat((dec.context_embedding.W_placeholder.expand(Rc, 1, 2 * E), ctx_in[:, 1:]), 1)
+        elif policy.env_name == "cvrptw":
+            cur, rem, now, mask = _cvrptw_states(act, rep(td["demand"]), rep(td["vehicle_capacity"].reshape(-1)),
+                                                 rep(td["locs"]), rep(td["time_windows"].float()), rep(td["durations"].float()))
+            ctx_in = torch.cat((embr[ar, cur], rem[..., None], now[..., None]), -1)          # [Rc, T, E+2]
         elif policy.env_name == "op":
             cur, rem, mask = _op_states(act, rep(td["locs"]), rep(td["max_length"]))
             ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)                          # [Rc, T, E+1]

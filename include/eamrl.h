@@ -37,6 +37,7 @@ extern "C" {
 #define EAMRL_ENV_SDVRP 2 /* split delivery: CVRP instances, customers may be served in several visits */
 #define EAMRL_ENV_PCTSP 3 /* prize collecting TSP: return to the depot once the collected prize reaches 1 */
 #define EAMRL_ENV_OP 4    /* orienteering: collect prizes within a maximum tour length */
+#define EAMRL_ENV_CVRPTW 5 /* CVRP with time windows: a customer must be reached before its window closes */
 /* selection modes  [rl4co/utils/decoding.py:430-465] */
 #define EAMRL_GREEDY 0
 #define EAMRL_SAMPLE 1   /* argmax(p / noise), noise ~ Exp(1) supplied by the caller (== torch.multinomial) */
@@ -109,6 +110,21 @@ int eamrl_op_step_mask(uint8_t* visited, float* tour_len, float* prize_tot, cons
                        const float* maxlen, int64_t* cur, int64_t* istep, const int64_t* action, uint8_t* mask,
                        uint8_t* done, int64_t R, int64_t B, int M, void* stream);
 
+/* CVRPTWEnv._step + get_action_mask  [rl4co/envs/routing/cvrptw/env.py:103-138] = the CVRP transition and mask plus the
+ * clock: time = (a != 0) * (max(time + distance(cur, a), tw[a][0]) + dur[a]); a node is feasible only if additionally
+ * time + distance(cur, n) <= tw[n][1].  time [R] f32 (current_time), locs [B][M][2], tw [B][M][2] f32 (start, end; the
+ * reference's int32 windows converted, exact), dur [B][M] f32; the rest as eamrl_cvrp_step_mask.  action == NULL: mask
+ * only.  In place. */
+int eamrl_cvrptw_step_mask(uint8_t* visited, float* used, const float* vcap, const float* demand, int64_t* cur, float* time,
+                           const float* locs, const float* tw, const float* dur, const int64_t* action, uint8_t* mask,
+                           uint8_t* done, int64_t R, int64_t B, int N, void* stream);
+
+/* The time-window replay of CVRPTWEnv.check_solution_validity  [cvrptw/env.py:203-227] (arrival times truncated to
+ * integers as there): bad[0] += rows that start a service after its window closed.  The CVRP part of the check is
+ * eamrl_check_solution(EAMRL_ENV_CVRP). */
+int eamrl_cvrptw_check_time(const int64_t* actions, const float* locs, const float* tw, const float* dur, int64_t R,
+                            int64_t B, int M, int T, int32_t* bad, void* stream);
+
 /* ---- one-shot encoder + cache ------------------------------------------------------------------- */
 
 /* y[r][j] = bias[j] + sum_k x[r][k] * W[j][k]  (k-ordered fma chain), optional ReLU, optional residual:
@@ -154,7 +170,8 @@ typedef struct eamrl_cache {
     const float* Lp;   /* logit key * project_out */
     const float* Pa;   /* TSP: first-node half; CVRP: current-node part */
     const float* Pb;   /* TSP: current-node half; CVRP: NULL */
-    const float* cvec; /* [E]  TSP: project_context(W_placeholder); CVRP: capacity column of project_context */
+    const float* cvec; /* [E]  TSP: project_context(W_placeholder); CVRP: capacity column of project_context;
+                        * CVRPTW: [2][E] capacity and current-time columns */
     const float* gctx; /* [B][E] graph context or NULL (POMO: use_graph_context=False) */
     int64_t ld;        /* row stride of K/V/Lp/Pa/Pb in floats (>= E) */
     int64_t B;         /* instances */
@@ -178,7 +195,10 @@ typedef struct eamrl_state {
     uint8_t* visited;  /* [R][M] CVRP visited */
     uint8_t* done;     /* [R] */
     float* rem;        /* [R][M] SDVRP demand_with_depot (remaining demand), else NULL */
-    const float* locs; /* [B][M][2] OP node coordinates (depot first), else NULL */
+    const float* locs; /* [B][M][2] OP / CVRPTW node coordinates (depot first), else NULL */
+    float* time;       /* [R] CVRPTW current_time, else NULL */
+    const float* tw;   /* [B][M][2] CVRPTW time windows (start, end) as f32, else NULL */
+    const float* dur;  /* [B][M] CVRPTW service durations, else NULL */
 } eamrl_state;
 
 /* One decode step for R rows = AttentionModelDecoder.forward + DecodingStrategy.step

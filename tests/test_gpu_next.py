@@ -180,7 +180,8 @@ def test_reference_lightning_checkpoint_loads(tmp_path):
                                       ("pomo_tsp20_multistart_sampling", "pomo_tsp"), ("sdvrp20_sampling", "am_sdvrp"),
                                       ("sdvrp20_multistart_greedy", "am_sdvrp"), ("pctsp20_sampling", "am_pctsp"),
                                       ("pctsp20_multistart_greedy", "am_pctsp"), ("op20_sampling", "am_op"),
-                                      ("op20_multistart_greedy", "am_op")])
+                                      ("op20_multistart_greedy", "am_op"), ("cvrptw20_sampling", "am_cvrptw"),
+                                      ("cvrptw20_multistart_greedy", "am_cvrptw")])
 def test_reevaluation_matches_native_logp_and_reference(name, cfg):
     """evaluate_log_likelihood (autograd, all steps at once) == native per-step log-probs (atol 1e-4) == reference."""
     from eam_rl4co_amd.train import evaluate_log_likelihood
@@ -192,7 +193,8 @@ def test_reevaluation_matches_native_logp_and_reference(name, cfg):
     ns = int(fx["num_starts"])
     logp = evaluate_log_likelihood(pol, td, env, t(fx["actions"]), num_starts=ns)
     assert logp.requires_grad
-    np.testing.assert_allclose(logp.detach().cpu().numpy(), fx["logp_steps"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), fx["logp_steps"], rtol=0,
+                               atol=1e-3 if env_name == "cvrptw" else 1e-4)     # cvrptw: unscaled inputs, see oracle tests
 
 
 def test_reinforce_step_pomo_and_flat_allreduce():
@@ -222,7 +224,7 @@ def test_reinforce_step_pomo_and_flat_allreduce():
     assert np.isfinite(first)
 
 
-@pytest.mark.parametrize("env_name", ["tsp", "cvrp", "sdvrp", "pctsp", "op"])
+@pytest.mark.parametrize("env_name", ["tsp", "cvrp", "sdvrp", "pctsp", "op", "cvrptw"])
 def test_policy_call_leaves_the_callers_tensordict_untouched(env_name):
     """As in the reference, a rollout works on its own copy of the state: the same reset td can be rolled out twice
     (REINFORCE followed by a rollout baseline does exactly that) with identical results."""
@@ -244,7 +246,8 @@ def test_policy_call_leaves_the_callers_tensordict_untouched(env_name):
 # HIP graph replay of the whole rollout
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("env_name,mode", [("tsp", "greedy"), ("cvrp", "greedy"), ("cvrp", "sampling"), ("sdvrp", "greedy"),
-                                           ("pctsp", "greedy"), ("op", "greedy")])
+                                           ("pctsp", "greedy"), ("op", "greedy"),
+                                           ("cvrptw", "greedy")])
 def test_graphed_rollout_equals_eager(env_name, mode):
     import eam_rl4co_amd as ea
 

@@ -59,6 +59,11 @@ def make_td(env_name, locs, demand=None):
     env = ea.get_env(env_name, generator_params=dict(num_loc=locs.shape[1] - (env_name != "tsp")))
     if env_name == "tsp":
         td = ea.TensorDict({"locs": torch.from_numpy(locs)}, batch_size=[locs.shape[0]])
+    elif env_name == "cvrptw":      # demand: {"demand", "time_windows" (int32, as the reference keeps them), "durations"}
+        td = ea.TensorDict({"locs": torch.from_numpy(locs[:, 1:]), "depot": torch.from_numpy(locs[:, 0]),
+                            "demand": torch.from_numpy(demand["demand"]),
+                            "time_windows": torch.from_numpy(demand["time_windows"]),
+                            "durations": torch.from_numpy(demand["durations"])}, batch_size=[locs.shape[0]])
     elif env_name == "op":          # demand: {"prize" [B,M], "max_length" [B,M]} of the post-reset state
         B = locs.shape[0]
         # generator-style td; the per-node limits and prizes of the fixture replace what reset derives from them
@@ -218,7 +223,8 @@ STEP_CASES = ["tsp20_greedy", "tsp100_greedy", "cvrp20_greedy", "cvrp100_greedy"
               "tsp20_multistart_greedy", "cvrp20_multistart_greedy", "pomo_tsp20_multistart_sampling",
               "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy",
               "pctsp20_greedy", "pctsp20_sampling", "pctsp100_sampling", "pctsp20_multistart_greedy",
-              "op20_greedy", "op20_sampling", "op100_sampling", "op20_multistart_greedy"]
+              "op20_greedy", "op20_sampling", "op100_sampling", "op20_multistart_greedy",
+              "cvrptw20_greedy", "cvrptw20_sampling", "cvrptw100_sampling", "cvrptw20_multistart_greedy"]
 
 
 @pytest.mark.parametrize("name", STEP_CASES)
@@ -270,9 +276,11 @@ def test_decode_step_api_bit_exact_every_step(oracle, name):
         if env_name == "tsp":
             assert_bits_equal(st.first, ost.first, "first")
             assert_bits_equal(st.istep, ost.istep, "i")
-        elif env_name == "cvrp":
+        elif env_name in ("cvrp", "cvrptw"):
             assert_bits_equal(st.visited, ost.visited, "visited")
             assert_bits_equal(st.used, ost.used, "used")
+            if env_name == "cvrptw":
+                assert_bits_equal(st.time, ost.time, "current_time")
         elif env_name in ("pctsp", "op"):
             assert_bits_equal(st.visited.to(torch.uint8), ost.visited, "visited")
             assert_bits_equal(st.used, ost.used, "collected prize / tour length")
@@ -294,7 +302,9 @@ POLICY_CASES = ["tsp20_greedy", "tsp20_sampling", "tsp20_evaluate", "tsp20_multi
                 "tsp20_sampling_topk5", "tsp20_sampling_topp", "cvrp20_sampling_topk_topp", "tsp100_greedy_topk",
                 "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy",
                 "pctsp20_greedy", "pctsp20_sampling", "pctsp50_greedy", "pctsp100_sampling", "pctsp20_multistart_greedy",
-                "op20_greedy", "op20_sampling", "op50_greedy", "op100_sampling", "op20_multistart_greedy"]
+                "op20_greedy", "op20_sampling", "op50_greedy", "op100_sampling", "op20_multistart_greedy",
+                "cvrptw20_greedy", "cvrptw20_sampling", "cvrptw50_greedy", "cvrptw100_sampling",
+                "cvrptw20_multistart_greedy"]
 
 
 @pytest.mark.parametrize("stream_kernel", [0, 1])
@@ -339,7 +349,9 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
         lib.eamrl_debug_set(1, 0)
     assert_bits_equal(out["actions"], fx["actions"], "tours vs reference")
     np.testing.assert_allclose(out["reward"].cpu().numpy(), fx["reward"], rtol=1e-6, atol=0)
-    np.testing.assert_allclose(out["log_likelihood"].cpu().numpy(), fx["logp_steps"], rtol=0, atol=1e-5)
+    # (CVRPTW's unscaled inputs make the network ill-conditioned: looser bound vs the reference, see test_oracle_golden)
+    np.testing.assert_allclose(out["log_likelihood"].cpu().numpy(), fx["logp_steps"], rtol=0,
+                               atol=2e-4 if env_name == "cvrptw" else 1e-5)
     o = oracle.policy_rollout(golden_weights(cfg), env_name, fx["locs"], instance_of(fx),
                               decode_type=decode_type if "actions" not in kw else "evaluate", num_starts=ns,
                               noise=fx.get("noise"), given=fx["actions"] if "actions" in kw else None,
@@ -351,7 +363,8 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
 
 
 @pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random",
-                                  "env_pctsp20_random", "env_op20_random", "env_op50_random"])
+                                  "env_pctsp20_random", "env_op20_random", "env_op50_random",
+                                  "env_cvrptw20_random", "env_cvrptw50_random"])
 def test_env_api_matches_reference_state_machine(name):
     """env.reset / env.step / env.get_reward through the RL4COEnvBase API against the reference's recorded states."""
     import eam_rl4co_amd as ea
@@ -382,8 +395,10 @@ def test_env_api_matches_reference_state_machine(name):
                 assert_bits_equal(td[k], fx["step_" + k][:, step], k)
             assert_bits_equal(env.get_action_mask(td), fx["step_action_mask"][:, step], "get_action_mask")
         else:
-            if env_name == "cvrp":
+            if env_name in ("cvrp", "cvrptw"):
                 assert_bits_equal(td["visited"], fx["step_visited"][:, step], "visited")
+                if env_name == "cvrptw":
+                    assert_bits_equal(td["current_time"], fx["step_current_time"][:, step], "current_time")
             else:
                 assert_bits_equal(td["demand_with_depot"], fx["step_demand_with_depot"][:, step], "remaining demand")
             assert_bits_equal(td["used_capacity"], fx["step_used_capacity"][:, step], "used")
@@ -391,6 +406,16 @@ def test_env_api_matches_reference_state_machine(name):
     reward = env.get_reward(td, t(fx["step_action"]))
     np.testing.assert_allclose(reward.cpu().numpy(), fx["reward"], rtol=1e-6, atol=0)
     bad = fx["step_action"].copy()
+    if env_name == "cvrptw":    # CVRP asserts + the time-window replay (cvrptw/env.py:203-227)
+        N = int(fx["num_loc"])
+        naive = np.concatenate([np.stack([np.arange(1, N + 1, dtype=np.int64), np.zeros(N, np.int64)], 1).reshape(-1)[None]]
+                               * bad.shape[0])               # 1 0 2 0 3 0 ...: fits the capacity, ignores the windows
+        with pytest.raises(AssertionError, match="vehicle cannot start service before deadline"):
+            env.get_reward(td, t(naive))
+        bad[0, np.nonzero(bad[0])[0][0]] = 0
+        with pytest.raises(AssertionError, match="Invalid tour"):
+            env.get_reward(td, t(bad))
+        return
     if env_name == "op":        # the reference's own asserts (op/env.py:179-212)
         rows = np.nonzero(bad[:, 1] != 0)[0]
         bad[rows[0], 0] = bad[rows[0], 1]
@@ -435,7 +460,8 @@ def test_random_policy_rollout_helper_shapes():
                                                 ("tsp", 20, 128, "greedy"), ("cvrp", 500, 16, "greedy"),
                                                 ("sdvrp", 100, 256, "sampling"), ("sdvrp", 200, 32, "greedy"),
                                                 ("pctsp", 100, 256, "sampling"), ("pctsp", 200, 32, "greedy"),
-                                                ("op", 100, 256, "sampling"), ("op", 200, 32, "greedy")])
+                                                ("op", 100, 256, "sampling"), ("op", 200, 32, "greedy"),
+                                                ("cvrptw", 100, 256, "sampling"), ("cvrptw", 200, 32, "greedy")])
 def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
     """BASELINE.json configs at full size (C2, C3, C1, C5 with a reduced batch so the CPU oracle finishes in
     seconds): tours bit-identical to the oracle, plus size-independent properties."""
@@ -448,6 +474,8 @@ def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
     td = td_cpu.to(DEV)
     locs = td_cpu["locs"].numpy()
     demand = td_cpu["demand"].numpy() if env_name in ("cvrp", "sdvrp") else None
+    if env_name == "cvrptw":
+        demand = {k: td_cpu[k].numpy() for k in ("demand", "time_windows", "durations")}
     if env_name == "pctsp":
         demand = {k: td_cpu[k].numpy() for k in ("expected_prize", "real_prize", "penalty", "prize_required")}
     if env_name == "op":
@@ -486,7 +514,7 @@ def test_full_size_rollout_equals_oracle(oracle, env_name, N, B, mode):
         want = np.take_along_axis(pen, acts, 1).sum(1) - (length + pen[:, 1:].sum(1))
         np.testing.assert_allclose(out["reward"].cpu().numpy(), want, rtol=1e-5)
     else:
-        if env_name == "cvrp":
+        if env_name in ("cvrp", "cvrptw"):
             srt = np.sort(acts, 1)
             assert (srt[:, -N:] == np.arange(1, N + 1)).all() and (srt[:, :-N] == 0).all()
         else:       # split deliveries: every customer at least once, and everything delivered

@@ -37,7 +37,8 @@ def test_state_dict_contract_matches_reference():
     cfgs = {"am_tsp": dict(env_name="tsp"), "am_cvrp": dict(env_name="cvrp"),
             "pomo_tsp": dict(env_name="tsp", num_encoder_layers=6, normalization="instance", use_graph_context=False),
             "pomo_cvrp": dict(env_name="cvrp", num_encoder_layers=6, normalization="instance", use_graph_context=False),
-            "am_sdvrp": dict(env_name="sdvrp"), "am_pctsp": dict(env_name="pctsp"), "am_op": dict(env_name="op")}
+            "am_sdvrp": dict(env_name="sdvrp"), "am_pctsp": dict(env_name="pctsp"), "am_op": dict(env_name="op"),
+            "am_cvrptw": dict(env_name="cvrptw")}
     for name, kw in cfgs.items():
         sd = ea.AttentionModelPolicy(**kw).state_dict()
         mine = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
@@ -47,7 +48,8 @@ def test_state_dict_contract_matches_reference():
 
 
 @pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random",
-                                  "env_pctsp20_random", "env_op20_random", "env_op50_random"])
+                                  "env_pctsp20_random", "env_op20_random", "env_op50_random",
+                                  "env_cvrptw20_random", "env_cvrptw50_random"])
 def test_generators_reproduce_reference_instances(name):
     """Same torch seed -> bit-identical instances as the reference generators (torch CPU RNG stream)."""
     import eam_rl4co_amd as ea
@@ -59,7 +61,7 @@ def test_generators_reproduce_reference_instances(name):
     torch.manual_seed(int(fx["data_seed"]))
     td = env.generator(batch_size=[fx["gen_locs"].shape[0]])
     for k in ("locs", "depot", "demand", "capacity", "penalty", "deterministic_prize", "stochastic_prize", "prize",
-              "max_length"):
+              "max_length", "durations", "time_windows"):
         if "gen_" + k in fx:
             assert np.array_equal(td[k].numpy(), fx["gen_" + k]), k
     td = env.reset(td)      # the reset-state mask is computed in closed form on the host
@@ -114,18 +116,18 @@ def test_unsupported_features_raise():
     import eam_rl4co_amd as ea
 
     with pytest.raises(NotImplementedError):
-        ea.AttentionModelPolicy(env_name="cvrptw")
+        ea.AttentionModelPolicy(env_name="mtsp")
     with pytest.raises(NotImplementedError):
         ea.AttentionModelPolicy(env_name="tsp", normalization="layer")
     with pytest.raises(ValueError):
-        ea.get_env("cvrptw")
+        ea.get_env("mtsp")
 
 
 def test_multistart_helpers_follow_reference_layout():
     """get_num_starts / select_start_nodes: flat row j = s*B + b starts at node s (TSP) / s+1 (CVRP)."""
     import eam_rl4co_amd as ea
 
-    for name, off in (("tsp", 0), ("cvrp", 1), ("sdvrp", 1), ("pctsp", 1), ("op", 1)):
+    for name, off in (("tsp", 0), ("cvrp", 1), ("sdvrp", 1), ("pctsp", 1), ("op", 1), ("cvrptw", 1)):
         env = ea.get_env(name, generator_params=dict(num_loc=7))
         td = env.reset(batch_size=[3])
         assert env.get_num_starts(td) == 7
