@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/s of the AttentionModel construction rollout on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tsp100|cvrp100|tsp20|cvrp500|pomo100|sdvrp100|pctsp100|op100] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tsp100|cvrp100|tsp20|cvrp500|pomo100|sdvrp100|pctsp100|op100|cvrptw100] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one full rollout of one batch: encoder + decoder cache + the whole decode loop (state update,
@@ -40,6 +40,7 @@ WORKLOADS = {
     "cvrp500": ("cvrp", 500, 512, "greedy"),       # configs[4]
     "sdvrp100": ("sdvrp", 100, 1024, "greedy"),    # sibling env: split deliveries, dynamic embedding
     "pctsp100": ("pctsp", 100, 1024, "greedy"),    # sibling env: prize collecting
+    "cvrptw100": ("cvrptw", 100, 1024, "greedy"),  # sibling env: CVRP with time windows
     "op100": ("op", 100, 1024, "greedy"),          # sibling env: orienteering (distance-dependent mask)
     # configs[3], per-GPU share: POMO policy (6 layers, instance norm, no graph context), num_starts = num_loc
     "pomo100": ("tsp", 100, 1024, "multistart_sampling"),
@@ -110,6 +111,8 @@ def cpu_baseline(env_name, num_loc, decode_type, num_starts=0, pomo=False, secon
             demand = {k: td[k].numpy() for k in ("expected_prize", "real_prize", "penalty", "prize_required")}
         if env_name == "op":
             demand = {k: td[k].numpy() for k in ("prize", "max_length")}
+        if env_name == "cvrptw":
+            demand = {k: td[k].numpy() for k in ("demand", "time_windows", "durations")}
         noise = None
         if "sampling" in decode_type:
             M = locs.shape[1]

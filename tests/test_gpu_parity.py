@@ -408,10 +408,18 @@ def test_env_api_matches_reference_state_machine(name):
     bad = fx["step_action"].copy()
     if env_name == "cvrptw":    # CVRP asserts + the time-window replay (cvrptw/env.py:203-227)
         N = int(fx["num_loc"])
-        naive = np.concatenate([np.stack([np.arange(1, N + 1, dtype=np.int64), np.zeros(N, np.int64)], 1).reshape(-1)[None]]
-                               * bad.shape[0])               # 1 0 2 0 3 0 ...: fits the capacity, ignores the windows
+        locs = np.concatenate([fx["gen_depot"][:, None], fx["gen_locs"]], 1).astype(np.float64)
+        tw = fx["gen_time_windows"].astype(np.float64)
+        rows = []
+        for b in range(bad.shape[0]):       # i then j, where j's window is over before one can get there from i
+            d = np.linalg.norm(locs[b][:, None] - locs[b][None], axis=-1)
+            late = (tw[b, :, 0][:, None] + d > tw[b, :, 1][None] + 1.0)
+            late[0, :] = late[:, 0] = False
+            i, j = np.argwhere(late)[0]
+            rest = [k for k in range(1, N + 1) if k not in (i, j)]
+            rows.append([i, j, 0] + [x for k in rest for x in (k, 0)])
         with pytest.raises(AssertionError, match="vehicle cannot start service before deadline"):
-            env.get_reward(td, t(naive))
+            env.get_reward(td, t(np.array(rows, dtype=np.int64)))
         bad[0, np.nonzero(bad[0])[0][0]] = 0
         with pytest.raises(AssertionError, match="Invalid tour"):
             env.get_reward(td, t(bad))
