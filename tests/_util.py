@@ -48,3 +48,14 @@ def instance_of(fx):
     if str(fx["env_name"]) == "cvrptw":
         return {k: fx[k] for k in ("demand", "time_windows", "durations")}
     return fx.get("demand")
+
+
+def instance_from_td(env_name, td):
+    """The same, from a post-reset (CPU) TensorDict of the package's own envs."""
+    keys = {"cvrp": "demand", "sdvrp": "demand", "pctsp": ("expected_prize", "real_prize", "penalty", "prize_required"),
+            "op": ("prize", "max_length"), "cvrptw": ("demand", "time_windows", "durations")}.get(env_name)
+    if keys is None:
+        return None
+    if isinstance(keys, str):
+        return td[keys].numpy()
+    return {k: td[k].numpy() for k in keys}

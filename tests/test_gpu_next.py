@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import cfg_for, golden, golden_weights, instance_of
+from _util import cfg_for, golden, golden_weights, instance_from_td, instance_of
 from test_gpu_parity import DEV, assert_bits_equal, make_policy, make_td, t
 
 pytestmark = pytest.mark.gpu
@@ -15,10 +15,16 @@ pytestmark = pytest.mark.gpu
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("env_name,N,B", [("tsp", 2, 3), ("tsp", 5, 1), ("cvrp", 3, 2), ("tsp", 64, 5), ("tsp", 65, 5),
                                           ("tsp", 128, 4), ("tsp", 129, 4), ("cvrp", 127, 3), ("cvrp", 128, 3),
-                                          ("cvrp", 50, 7)])
+                                          ("cvrp", 50, 7),
+                                          ("sdvrp", 10, 2), ("sdvrp", 63, 3), ("sdvrp", 127, 2), ("sdvrp", 128, 2),
+                                          ("pctsp", 2, 3), ("pctsp", 64, 3), ("pctsp", 127, 2), ("pctsp", 128, 2),
+                                          ("op", 2, 3), ("op", 64, 3), ("op", 127, 2), ("op", 128, 2),
+                                          ("cvrptw", 3, 2), ("cvrptw", 64, 3), ("cvrptw", 127, 2), ("cvrptw", 128, 2)])
 @pytest.mark.parametrize("mode", ["greedy", "sampling"])
 def test_rollout_shapes_and_kernel_boundaries(oracle, env_name, N, B, mode):
-    """M = 2 .. 129: every register-resident instantiation and the streaming kernel against the oracle."""
+    """M = 2 .. 129: every register-resident instantiation and the streaming kernel against the oracle.
+    (SDVRP starts at 10 customers: with fewer the whole demand fits one trip, the tour never returns to the depot and the
+    reference's validity check -- reproduced faithfully -- rejects it for its never-cleared depot slot, sdvrp/env.py:157.)"""
     import eam_rl4co_amd as ea
 
     cfg = "am_" + env_name
@@ -27,11 +33,11 @@ def test_rollout_shapes_and_kernel_boundaries(oracle, env_name, N, B, mode):
     torch.manual_seed(100 + N)
     td_cpu = env.reset(batch_size=[B])
     locs = td_cpu["locs"].numpy()
-    demand = td_cpu["demand"].numpy() if env_name == "cvrp" else None
+    demand = instance_from_td(env_name, td_cpu)
     M = locs.shape[1]
     kw, noise = {}, None
     if mode == "sampling":
-        noise = torch.empty(B, 2 * M + 1, M).exponential_(1, generator=torch.Generator().manual_seed(N))
+        noise = torch.empty(B, 3 * M + 1, M).exponential_(1, generator=torch.Generator().manual_seed(N))
         kw["noise"] = noise.to(DEV)
     out = pol(td_cpu.to(DEV), env, phase="test", decode_type=mode, return_sum_log_likelihood=False, **kw)
     o = oracle.policy_rollout(golden_weights(cfg), env_name, locs, demand, decode_type=mode,
@@ -94,7 +100,9 @@ def test_multistart_sampling_cvrp_and_select_best(oracle):
 
 
 @pytest.mark.parametrize("env_name,N,B,S", [("tsp", 20, 4, 2), ("tsp", 20, 3, 5), ("tsp", 50, 2, 7), ("tsp", 100, 2, 9),
-                                            ("cvrp", 20, 3, 3), ("cvrp", 100, 2, 6), ("cvrp", 127, 1, 5)])
+                                            ("cvrp", 20, 3, 3), ("cvrp", 100, 2, 6), ("cvrp", 127, 1, 5),
+                                            ("sdvrp", 20, 3, 4), ("sdvrp", 100, 2, 5), ("pctsp", 20, 3, 4),
+                                            ("pctsp", 100, 2, 6), ("cvrptw", 20, 3, 4), ("cvrptw", 100, 2, 5)])
 @pytest.mark.parametrize("mode", ["greedy", "sampling"])
 def test_start_sharing_kernel_matches_oracle_and_single_row_kernel(oracle, env_name, N, B, S, mode):
     """Multistart batches go through the start-sharing kernel (P starts of an instance per workgroup, ragged last
@@ -109,11 +117,11 @@ def test_start_sharing_kernel_matches_oracle_and_single_row_kernel(oracle, env_n
     torch.manual_seed(7 + N)
     td_cpu = env.reset(batch_size=[B])
     locs = td_cpu["locs"].numpy()
-    demand = td_cpu["demand"].numpy() if env_name == "cvrp" else None
+    demand = instance_from_td(env_name, td_cpu)
     M = locs.shape[1]
     kw, noise = dict(num_starts=S), None
     if mode == "sampling":
-        noise = torch.empty(B * S, 2 * M + 1, M).exponential_(1, generator=torch.Generator().manual_seed(N + S))
+        noise = torch.empty(B * S, 3 * M + 1, M).exponential_(1, generator=torch.Generator().manual_seed(N + S))
         kw["noise"] = noise.to(DEV)
     outs = []
     for single in (0, 1):
