@@ -1,9 +1,11 @@
-"""TSP / CVRP environments behind the reference's RL4COEnvBase interface, stepping on MI355X kernels.
+"""TSP / CVRP (and CVRPTW, SDVRP, PCTSP, OP) environments behind the reference's RL4COEnvBase interface, stepping on
+MI355X kernels.
 
 Interface mirrored (same names, argument meaning, TensorDict keys / shapes / dtypes and error messages):
   rl4co/envs/common/base.py:19-346        RL4COEnvBase (reset / step / get_reward / get_action_mask / dataset ...)
   rl4co/envs/common/utils.py:21-102       Generator, get_sampler (uniform branch)
-  rl4co/envs/routing/tsp/{env,generator}.py, rl4co/envs/routing/cvrp/{env,generator}.py
+  rl4co/envs/routing/tsp/{env,generator}.py, rl4co/envs/routing/cvrp/{env,generator}.py,
+  rl4co/envs/routing/{cvrptw,sdvrp,pctsp,op}/{env,generator}.py
 Instances are generated on the host with torch's global CPU generator exactly like the reference
 (SURVEY Appendix A10), so the same seed gives bit-identical instances; every state transition, mask,
 reward and validity check runs in libeamrl_hip.so and requires the TensorDict to live on the GPU.
