@@ -30,6 +30,12 @@
  *   orc_tour_length ........... rl4co/utils/ops.py:59-95 + tsp/env.py:152-159 + cvrp/env.py:146-155
  *   orc_check_tsp/cvrp ........ tsp/env.py:161-168, cvrp/env.py:157-185
  *   orc_rollout ............... rl4co/models/common/constructive/base.py:236-250 (decode loop)
+ *   orc_sdvrp_mask/step ....... rl4co/envs/routing/sdvrp/env.py:58-92,137-146 (+ dynamic embedding, dynamic.py:59-78)
+ *   orc_cvrptw_mask/step ...... rl4co/envs/routing/cvrptw/env.py:103-138; orc_check_cvrptw_time: :203-227
+ *   orc_pctsp_mask/step ....... rl4co/envs/routing/pctsp/env.py:64-97,156-163; orc_pctsp_reward: :165-187;
+ *                               orc_check_pctsp: :189-205
+ *   orc_op_mask/step .......... rl4co/envs/routing/op/env.py:69-102,149-165; orc_op_reward: :167-177; orc_check_op: :179-212
+ *   top-k / top-p, beam search  rl4co/utils/decoding.py:110-136,170-176,468-608 (beam search in oracle.py)
  *
  * DEFINED ORDER (DESIGN.md "Canonical arithmetic"):
  *   chain(x,y,K,init): acc=init; for k ascending: acc=fmaf(x[k],y[k],acc).  This is exactly
