@@ -1,6 +1,6 @@
 """eam_rl4co_amd: MI355X-native construction rollout (TSP / CVRP and the sibling routing envs CVRPTW, SDVRP, PCTSP, OP
 + AttentionModel decode) behind the RL4CO interfaces of Tarseus/eam-rl4co.  See DESIGN.md."""
-from .envs import (CVRPEnv, CVRPGenerator, CVRPTWEnv, CVRPTWGenerator, OPEnv, OPGenerator, PCTSPEnv, PCTSPGenerator, RL4COEnvBase, SDVRPEnv,  # noqa: F401
+from .envs import (CVRPEnv, CVRPGenerator, CVRPTWEnv, CVRPTWGenerator, OPEnv, OPGenerator, PCTSPEnv, PCTSPGenerator, RL4COEnvBase, SDVRPEnv, SPCTSPEnv,  # noqa: F401
                    TSPEnv, TSPGenerator, get_env)  # noqa: F401
 from .policy import (AttentionModelDecoder, AttentionModelEncoder, AttentionModelPolicy, GraphedRollout,  # noqa: F401
                      load_reference_checkpoint, random_policy, rollout)

@@ -358,7 +358,7 @@ class RL4COEnvBase:
 
     def get_num_starts(self, td):
         n = td["action_mask"].shape[-1]
-        return n - 1 if self.name in ("cvrp", "sdvrp", "pctsp", "op", "cvrptw") else n          # depot cannot be a start node (utils/ops.py:120-130)
+        return n - 1 if self.name in ("cvrp", "sdvrp", "pctsp", "spctsp", "op", "cvrptw") else n          # depot cannot be a start node (utils/ops.py:120-130)
 
     def select_start_nodes(self, td, num_starts):
         """POMO start nodes: flat row j = s*B + b starts at node s (+1 with a depot) (utils/ops.py:133-169)."""
@@ -368,7 +368,7 @@ class RL4COEnvBase:
             # some customers are out of reach from the start: resample among the reachable ones (utils/ops.py:158-169)
             sel = torch.multinomial(td["action_mask"][..., 1:].float(), num_starts, replacement=True) + 1
             return sel.t().reshape(-1)                     # "b n -> (n b)"
-        return sel + 1 if self.name in ("cvrp", "sdvrp", "pctsp", "op", "cvrptw") else sel
+        return sel + 1 if self.name in ("cvrp", "sdvrp", "pctsp", "spctsp", "op", "cvrptw") else sel
 
     def check_solution_validity(self, td, actions) -> None:
         raise NotImplementedError
@@ -757,6 +757,14 @@ class PCTSPEnv(RL4COEnvBase):
         assert bad[1] == 0, "Total prize does not satisfy min total prize"
 
 
+class SPCTSPEnv(PCTSPEnv):
+    """Stochastic PCTSP (rl4co/envs/routing/spctsp/env.py:8-33): as PCTSP, but the prize collected at a node is the
+    stochastic one while the policy only sees the expected prize."""
+
+    name = "spctsp"
+    _stochastic = True
+
+
 class OPEnv(RL4COEnvBase):
     """Orienteering Problem (rl4co/envs/routing/op/env.py:24-267): collect as much prize as possible on a tour from and
     to the depot no longer than max_length; a customer stays feasible while it can be reached AND the depot afterwards."""
@@ -824,7 +832,7 @@ class OPEnv(RL4COEnvBase):
         assert bad[1] == 0, "Max length exceeded"
 
 
-ENV_REGISTRY = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv, "cvrptw": CVRPTWEnv}
+ENV_REGISTRY = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "spctsp": SPCTSPEnv, "op": OPEnv, "cvrptw": CVRPTWEnv}
 
 
 def get_env(env_name: str, *args, **kwargs) -> RL4COEnvBase:

@@ -28,6 +28,17 @@ log = logging.getLogger(__name__)
 DECODE_TYPES = ("greedy", "sampling", "multistart_greedy", "multistart_sampling", "evaluate")
 
 
+# envs that share kernels, embeddings and state layout with another one: SPCTSP is PCTSP whose collected prize is the
+# stochastic one (the policy sees the expected prize either way)
+_ENV_KIND = {"spctsp": "pctsp"}
+
+
+def _kind(env_name):
+    if isinstance(env_name, RL4COEnvBase):
+        env_name = env_name.name
+    return _ENV_KIND.get(env_name, env_name)
+
+
 # ------------------------------------------------------------------------------------------------------------
 # parameter containers (names = reference state_dict keys)
 # ------------------------------------------------------------------------------------------------------------
@@ -199,8 +210,7 @@ class AttentionModelEncoder(nn.Module):
     def __init__(self, embed_dim=128, init_embedding=None, env_name="tsp", num_heads=8, num_layers=3,
                  normalization="batch", feedforward_hidden=512, net=None, sdpa_fn=None, moe_kwargs=None):
         super().__init__()
-        if isinstance(env_name, RL4COEnvBase):
-            env_name = env_name.name
+        env_name = _kind(env_name)
         if moe_kwargs is not None or sdpa_fn is not None:
             raise NotImplementedError("moe_kwargs / sdpa_fn injection is outside the MI355X rollout path")
         self.env_name = env_name
@@ -259,8 +269,7 @@ class AttentionModelDecoder(nn.Module):
                  mask_inner=True, out_bias_pointer_attn=False, linear_bias=False, use_graph_context=True,
                  check_nan=True, sdpa_fn=None, pointer=None, moe_kwargs=None):
         super().__init__()
-        if isinstance(env_name, RL4COEnvBase):
-            env_name = env_name.name
+        env_name = _kind(env_name)
         if any(x is not None for x in (context_embedding, dynamic_embedding, sdpa_fn, pointer, moe_kwargs)) or linear_bias:
             raise NotImplementedError("custom context/dynamic embeddings, pointer, sdpa_fn, MoE and decoder biases are "
                                       "outside the MI355X rollout path (TSP / CVRP / SDVRP AttentionModel only)")
@@ -473,9 +482,11 @@ class AttentionModelPolicy(nn.Module):
             log.error("Found %d unused kwargs: %s", len(unused_kwargs), unused_kwargs)
         if isinstance(env_name, RL4COEnvBase):
             env_name = env_name.name
+        self.env_alias = env_name            # the name the env must carry (e.g. "spctsp")
+        env_name = _kind(env_name)           # the kernel / embedding family (e.g. "pctsp")
         if env_name not in ("tsp", "cvrp", "cvrptw", "sdvrp", "pctsp", "op"):
             raise NotImplementedError(f"env_name={env_name!r}: the MI355X rollout path covers 'tsp', 'cvrp', 'cvrptw', "
-                                      "'sdvrp', 'pctsp' and 'op'")
+                                      "'sdvrp', 'pctsp', 'spctsp' and 'op'")
         if moe_kwargs not in (None, {"encoder": None, "decoder": None}) or any(
                 x is not None for x in (sdpa_fn, sdpa_fn_encoder, sdpa_fn_decoder, encoder_network)):
             raise NotImplementedError("MoE / sdpa_fn / encoder_network injection is outside the MI355X rollout path")
@@ -509,9 +520,9 @@ class AttentionModelPolicy(nn.Module):
     def _enqueue(self, td, env, phase, calc_reward, return_actions, return_entropy, return_hidden, return_init_embeds,
                  return_sum_log_likelihood, actions, max_steps, **decoding_kwargs) -> dict:
         if isinstance(env, str) or env is None:
-            env = get_env(self.env_name if env is None else env)
-        if env.name != self.env_name:
-            raise ValueError(f"policy built for {self.env_name!r} got env {env.name!r}")
+            env = get_env(self.env_alias if env is None else env)
+        if _kind(env.name) != self.env_name:
+            raise ValueError(f"policy built for {self.env_alias!r} got env {env.name!r}")
 
         # decode type and strategy options (base.py:203-219, decoding.py:17-35,193-262)
         decode_type = decoding_kwargs.pop("decode_type", None)
@@ -605,7 +616,7 @@ class AttentionModelPolicy(nn.Module):
         # x + 0 is exact in the lane tree), nor the log-likelihood sum, nor validity.
         actions_pad = torch.cat(pre_actions + [acts], 1) if pre_actions else acts
         logp_pad = torch.cat(pre_logps + [lps], 1) if pre_logps else lps
-        native_env = type(env).__name__ in ("TSPEnv", "CVRPEnv", "SDVRPEnv", "PCTSPEnv", "OPEnv", "CVRPTWEnv") and type(env).__module__ == RL4COEnvBase.__module__
+        native_env = type(env).__name__ in ("TSPEnv", "CVRPEnv", "SDVRPEnv", "PCTSPEnv", "SPCTSPEnv", "OPEnv", "CVRPTWEnv") and type(env).__module__ == RL4COEnvBase.__module__
         fast = info is not None and native_env and not select_best
         reward_pad = ll_pad = bad = None
         if fast:

@@ -168,11 +168,17 @@ def mean_nodes(emb):
 # ---------------------------------------------------------------------------------------------
 # encoder + cache (AttentionModelEncoder.forward, AttentionModelDecoder._precompute_cache)
 # ---------------------------------------------------------------------------------------------
+def _kind(env_name):
+    """SPCTSP = PCTSP whose real_prize is the stochastic one (rl4co/envs/routing/spctsp/env.py)."""
+    return {"spctsp": "pctsp"}.get(env_name, env_name)
+
+
 def encode(sd, env_name, locs, demand=None, num_heads=8):
     """-> (init_embeds, embeddings).  locs: TSP [B,N,2]; CVRP [B,N+1,2] with depot first.
     PCTSP: `demand` is the dict of instance tensors (expected_prize [B,N], real_prize / penalty [B,N+1], prize_required);
     node features = (x, y, expected prize, penalty)  [nn/env_embeddings/init.py:227-257]."""
     pre = "encoder.init_embedding."
+    env_name = _kind(env_name)
     if env_name == "tsp":
         h = linear(locs, sd[pre + "init_embed.weight"], sd[pre + "init_embed.bias"])
     else:
@@ -212,6 +218,7 @@ def _norm(sd, p, h):
 
 def precompute(sd, env_name, emb, use_graph_context=True):
     """K/V/L cache plus the folded tensors of DESIGN.md (Pa/Pb, cvec, Lp) and the graph context."""
+    env_name = _kind(env_name)
     emb = _f32(emb)
     E = emb.shape[-1]
     kvl = linear(emb, sd["decoder.project_node_embeddings.weight"])
@@ -242,6 +249,7 @@ class State:
     """Per-row rollout state in the oracle's flat layout (R rows over Binst instances)."""
 
     def __init__(self, env_name, locs, demand=None, vehicle_capacity=1.0, num_starts=0):
+        env_name = _kind(env_name)
         self.env_name = env_name
         self.env = {"tsp": ENV_TSP, "cvrp": ENV_CVRP, "sdvrp": ENV_SDVRP, "pctsp": ENV_PCTSP, "op": ENV_OP,
                     "cvrptw": ENV_CVRPTW}[env_name]
@@ -468,6 +476,7 @@ def policy_rollout(sd, env_name, locs, demand=None, decode_type="greedy", num_st
     locs for CVRP already include the depot at index 0 (post-reset layout).
     Returns dict(actions, logp_steps, log_likelihood, reward, steps).
     """
+    env_name = _kind(env_name)
     _, emb = encode(sd, env_name, locs, demand, num_heads)
     cache = precompute(sd, env_name, emb, use_graph_context)
     multistart = "multistart" in decode_type and num_starts > 1
@@ -505,6 +514,7 @@ def policy_beam_search(sd, env_name, locs, demand=None, beam_width=None, select_
     nodes; each step keeps per instance the beam_width best (beam, node) continuations by cumulative log-prob
     (descending, ties to the lower beam*M + node), every new beam continues its parent's state; tours are recovered by
     backtracking the parent pointers.  Returns dict(actions, logp_steps, log_likelihood, reward)."""
+    env_name = _kind(env_name)
     _, emb = encode(sd, env_name, locs, demand, num_heads)
     cache = precompute(sd, env_name, emb, use_graph_context)
     B, M = locs.shape[:2]

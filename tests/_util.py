@@ -16,6 +16,9 @@ for _name in ("state_dict_contract_sdvrp.json", "state_dict_contract_pctsp.json"
         CONTRACT.update(json.load(_f))
 
 
+CONTRACT["am_spctsp"] = CONTRACT["am_pctsp"]      # same policy (embeddings see the expected prize either way)
+
+
 def golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
         return {k: z[k] for k in z.files}
@@ -41,7 +44,7 @@ def cfg_for(fx):
 def instance_of(fx):
     """The per-instance tensors besides locs, as the oracle / make_td take them: the demand array (CVRP, SDVRP), the
     dict of prize tensors (PCTSP) or None (TSP)."""
-    if str(fx["env_name"]) == "pctsp":
+    if str(fx["env_name"]) in ("pctsp", "spctsp"):
         return {k: fx[k] for k in ("expected_prize", "real_prize", "penalty", "prize_required")}
     if str(fx["env_name"]) == "op":
         return {k: fx[k] for k in ("prize", "max_length")}
@@ -53,6 +56,7 @@ def instance_of(fx):
 def instance_from_td(env_name, td):
     """The same, from a post-reset (CPU) TensorDict of the package's own envs."""
     keys = {"cvrp": "demand", "sdvrp": "demand", "pctsp": ("expected_prize", "real_prize", "penalty", "prize_required"),
+            "spctsp": ("expected_prize", "real_prize", "penalty", "prize_required"),
             "op": ("prize", "max_length"), "cvrptw": ("demand", "time_windows", "durations")}.get(env_name)
     if keys is None:
         return None

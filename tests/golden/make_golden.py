@@ -40,6 +40,7 @@ from rl4co.envs.routing.cvrptw.env import CVRPTWEnv  # noqa: E402
 from rl4co.envs.routing.op.env import OPEnv  # noqa: E402
 from rl4co.envs.routing.pctsp.env import PCTSPEnv  # noqa: E402
 from rl4co.envs.routing.sdvrp.env import SDVRPEnv  # noqa: E402
+from rl4co.envs.routing.spctsp.env import SPCTSPEnv  # noqa: E402
 from rl4co.envs.routing.tsp.env import TSPEnv  # noqa: E402
 from rl4co.models.zoo.am.policy import AttentionModelPolicy  # noqa: E402
 
@@ -119,7 +120,8 @@ def np_(t):
 def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_starts=None,
              keep_steps=None, keep_embeds=False, data_seed=1234, sample_seed=4321, actions=None,
              td_init=None, decode_kw=None):
-    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv, "cvrptw": CVRPTWEnv}[env_name]
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv, "cvrptw": CVRPTWEnv,
+           "spctsp": SPCTSPEnv}[env_name]
     env = Env(generator_params=gen_params(env_name, num_loc), seed=data_seed)
     if td_init is None:
         torch.manual_seed(data_seed)
@@ -158,7 +160,7 @@ def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_st
     if env_name == "cvrptw":
         for k in ("durations", "time_windows"):
             fx[k] = np_(td_init[k])
-    if env_name == "pctsp":
+    if env_name in ("pctsp", "spctsp"):
         for k in ("expected_prize", "real_prize", "penalty", "prize_required"):
             fx[k] = np_(td_init[k])
     if env_name == "op":
@@ -188,7 +190,8 @@ def run_case(name, env_name, num_loc, batch, decode_type, policy_kw=None, num_st
 
 def run_env_case(name, env_name, num_loc, batch, data_seed=99, act_seed=7):
     """Env-only golden: random feasible policy, every state tensor after every step."""
-    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv, "cvrptw": CVRPTWEnv}[env_name]
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv, "pctsp": PCTSPEnv, "op": OPEnv, "cvrptw": CVRPTWEnv,
+           "spctsp": SPCTSPEnv}[env_name]
     env = Env(generator_params=gen_params(env_name, num_loc), seed=data_seed)
     torch.manual_seed(data_seed)
     gen = env.generator(batch_size=[batch])
@@ -203,6 +206,7 @@ def run_env_case(name, env_name, num_loc, batch, data_seed=99, act_seed=7):
     extra = {"tsp": ("first_node", "i"), "cvrp": ("used_capacity", "visited"),
              "sdvrp": ("used_capacity", "demand_with_depot"),
              "pctsp": ("cur_total_prize", "cur_total_penalty", "visited", "i"),
+             "spctsp": ("cur_total_prize", "cur_total_penalty", "visited", "i"),
              "op": ("tour_length", "current_total_prize", "visited", "i"),
              "cvrptw": ("used_capacity", "visited", "current_time")}[env_name]
     for k in extra:
@@ -339,6 +343,9 @@ def pctsp():
     run_case("pctsp100_sampling", "pctsp", 100, 4, "sampling", keep_steps=first4, data_seed=75)
     run_case("pctsp20_multistart_greedy", "pctsp", 20, 3, "multistart_greedy", num_starts=20, keep_steps=first4, data_seed=74)
     run_env_case("env_pctsp20_random", "pctsp", 20, 8)
+    run_case("spctsp20_sampling", "spctsp", 20, 4, "sampling", keep_steps=first4, data_seed=77)
+    run_case("spctsp50_greedy", "spctsp", 50, 4, "greedy", keep_steps=first4, data_seed=78)
+    run_env_case("env_spctsp20_random", "spctsp", 20, 8, data_seed=96)
     run_case("pctsp20_beam", "pctsp", 20, 3, "beam_search", keep_steps=first4, data_seed=76, decode_kw=dict(beam_width=6, select_best=True))
 
 

@@ -42,7 +42,7 @@ def assert_bits_equal(a, b, what=""):
 def make_policy(cfg, **kw):
     import eam_rl4co_amd as ea
 
-    env_name = cfg.split("_")[1]
+    env_name = cfg.split("_")[1]          # (am_spctsp: the policy of the stochastic variant = PCTSP's)
     if cfg.startswith("pomo"):
         kw = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False, **kw)
     pol = ea.AttentionModelPolicy(env_name=env_name, **kw).eval()
@@ -73,10 +73,10 @@ def make_td(env_name, locs, demand=None):
         td = env.reset(td)
         assert np.array_equal(td["max_length"].numpy(), demand["max_length"])        # reset == the reference's reset
         return env, td.to(DEV)
-    elif env_name == "pctsp":       # demand: the dict of prize tensors (tests/_util.py instance_of)
+    elif env_name in ("pctsp", "spctsp"):       # demand: the dict of prize tensors (tests/_util.py instance_of)
         td = ea.TensorDict({"locs": torch.from_numpy(locs[:, 1:]), "depot": torch.from_numpy(locs[:, 0]),
                             "deterministic_prize": torch.from_numpy(demand["expected_prize"]),
-                            "stochastic_prize": torch.from_numpy(demand["expected_prize"]),
+                            "stochastic_prize": torch.from_numpy(np.ascontiguousarray(demand["real_prize"][:, 1:])),
                             "penalty": torch.from_numpy(demand["penalty"][:, 1:])}, batch_size=[locs.shape[0]])
     else:
         td = ea.TensorDict({"locs": torch.from_numpy(locs[:, 1:]), "depot": torch.from_numpy(locs[:, 0]),
@@ -302,6 +302,7 @@ POLICY_CASES = ["tsp20_greedy", "tsp20_sampling", "tsp20_evaluate", "tsp20_multi
                 "tsp20_sampling_topk5", "tsp20_sampling_topp", "cvrp20_sampling_topk_topp", "tsp100_greedy_topk",
                 "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy",
                 "pctsp20_greedy", "pctsp20_sampling", "pctsp50_greedy", "pctsp100_sampling", "pctsp20_multistart_greedy",
+                "spctsp20_sampling", "spctsp50_greedy",
                 "op20_greedy", "op20_sampling", "op50_greedy", "op100_sampling", "op20_multistart_greedy",
                 "cvrptw20_greedy", "cvrptw20_sampling", "cvrptw50_greedy", "cvrptw100_sampling",
                 "cvrptw20_multistart_greedy"]
@@ -363,8 +364,8 @@ def test_policy_forward_reproduces_reference_tours(oracle, name, stream_kernel):
 
 
 @pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random",
-                                  "env_pctsp20_random", "env_op20_random", "env_op50_random",
-                                  "env_cvrptw20_random", "env_cvrptw50_random"])
+                                  "env_pctsp20_random", "env_spctsp20_random", "env_op20_random",
+                                  "env_op50_random", "env_cvrptw20_random", "env_cvrptw50_random"])
 def test_env_api_matches_reference_state_machine(name):
     """env.reset / env.step / env.get_reward through the RL4COEnvBase API against the reference's recorded states."""
     import eam_rl4co_amd as ea
@@ -390,7 +391,7 @@ def test_env_api_matches_reference_state_machine(name):
             for k in ("visited", "tour_length", "current_total_prize", "i"):
                 assert_bits_equal(td[k], fx["step_" + k][:, step], k)
             assert_bits_equal(env.get_action_mask(td), fx["step_action_mask"][:, step], "get_action_mask")
-        elif env_name == "pctsp":
+        elif env_name in ("pctsp", "spctsp"):
             for k in ("visited", "cur_total_prize", "cur_total_penalty", "i"):
                 assert_bits_equal(td[k], fx["step_" + k][:, step], k)
             assert_bits_equal(env.get_action_mask(td), fx["step_action_mask"][:, step], "get_action_mask")
@@ -433,7 +434,7 @@ def test_env_api_matches_reference_state_machine(name):
         with pytest.raises(AssertionError, match="Max length exceeded"):
             env.get_reward(td, t(far))
         return
-    if env_name == "pctsp":     # the reference's own asserts (pctsp/env.py:189-205)
+    if env_name in ("pctsp", "spctsp"):     # the reference's own asserts (pctsp/env.py:189-205)
         bad[0, 1] = bad[0, 0]
         with pytest.raises(AssertionError, match="Duplicates"):
             env.get_reward(td, t(bad))

@@ -48,7 +48,7 @@ def test_state_dict_contract_matches_reference():
 
 
 @pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random",
-                                  "env_pctsp20_random", "env_op20_random", "env_op50_random",
+                                  "env_pctsp20_random", "env_spctsp20_random", "env_op20_random", "env_op50_random",
                                   "env_cvrptw20_random", "env_cvrptw50_random"])
 def test_generators_reproduce_reference_instances(name):
     """Same torch seed -> bit-identical instances as the reference generators (torch CPU RNG stream)."""

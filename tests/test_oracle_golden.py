@@ -26,6 +26,7 @@ POLICY_CASES = [
     "sdvrp20_greedy", "sdvrp20_sampling", "sdvrp50_greedy", "sdvrp20_multistart_greedy",
     # PCTSP (prize collecting): prize-gated depot, penalty reward
     "pctsp20_greedy", "pctsp20_sampling", "pctsp50_greedy", "pctsp100_sampling", "pctsp20_multistart_greedy",
+    "spctsp20_sampling", "spctsp50_greedy",          # stochastic prizes: the env collects a prize the policy does not see
     # OP (orienteering): distance-dependent mask, prize reward
     "op20_greedy", "op20_sampling", "op50_greedy", "op100_sampling", "op20_multistart_greedy",
     # CVRPTW (time windows): CVRP + clock, reachability mask, two state columns in the context
@@ -124,7 +125,7 @@ def test_per_step_logits_logprobs_masks(oracle, name):
 
 
 @pytest.mark.parametrize("name", ["env_tsp20_random", "env_cvrp20_random", "env_cvrp100_random", "env_sdvrp20_random",
-                                  "env_pctsp20_random", "env_op20_random", "env_op50_random",
+                                  "env_pctsp20_random", "env_spctsp20_random", "env_op20_random", "env_op50_random",
                                   "env_cvrptw20_random", "env_cvrptw50_random"])
 def test_env_state_machine_bit_exact(oracle, name):
     fx = golden(name)
@@ -142,10 +143,12 @@ def test_env_state_machine_bit_exact(oracle, name):
         ml = torch.from_numpy(fx["gen_max_length"])[..., None] - (td_[..., None, :] - tl).norm(p=2, dim=-1) - 1e-6
         demand = {"prize": np.concatenate([np.zeros((locs.shape[0], 1), np.float32), fx["gen_prize"]], 1),
                   "max_length": ml.numpy()}
-    elif env == "pctsp":
+    elif env in ("pctsp", "spctsp"):
         locs = np.concatenate([fx["gen_depot"][:, None], fx["gen_locs"]], 1)
         pad = lambda a: np.concatenate([np.zeros((a.shape[0], 1), np.float32), a], 1)
-        demand = {"expected_prize": fx["gen_deterministic_prize"], "real_prize": pad(fx["gen_deterministic_prize"]),
+        real = fx["gen_stochastic_prize"] if env == "spctsp" else fx["gen_deterministic_prize"]
+        env = "pctsp"
+        demand = {"expected_prize": fx["gen_deterministic_prize"], "real_prize": pad(real),
                   "penalty": pad(fx["gen_penalty"]), "prize_required": 1.0}
     else:
         locs = np.concatenate([fx["gen_depot"][:, None], fx["gen_locs"]], 1)
