@@ -18,7 +18,14 @@ namespace eamrl {
 
 constexpr int BLOCK = 256;
 constexpr int DU2 = 8;    // score stage: (node, head) pairs whose key loads are in flight together
-constexpr int DU4 = 16;   // glimpse stage: value loads in flight per thread
+#ifndef EAMRL_DU4
+#define EAMRL_DU4 16
+#endif
+#ifndef EAMRL_DU5
+#define EAMRL_DU5 2
+#endif
+constexpr int DU4 = EAMRL_DU4;   // glimpse stage: value loads in flight per thread
+constexpr int DU5 = EAMRL_DU5;   // logit stage: (node, column chunk) pairs per trip, 8 float4 loads each
 constexpr int NWAVE = BLOCK / EAMRL_WAVE;
 
 struct RowState {
@@ -178,30 +185,40 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
 
     // ---- D4 glimpse: NCHUNK node chunks, sequential inside a chunk, chunks added left to right ----------
     const int C = (M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
-    for (int pp = tid; pp < E * EAMRL_NCHUNK; pp += BLOCK) {
-        const int g = pp / E, e = pp - g * E, h = e / D;
-        const float* wh = l.w + h * M;
-        const int n0 = g * C, n1 = min(M, n0 + C);
-        float zg = 0.0f, ag = 0.0f;
-        // DU4 value loads in flight per thread; a masked node has w == +0 exactly, so adding its terms unconditionally
-        // (with v = 0 in place of the skipped load) leaves both sums bit-identical
-        for (int nb = n0; nb < n1; nb += DU4) {
-            float vv[DU4], ww[DU4];
+    {
+        // A thread owns four adjacent columns of one chunk (D % 4 == 0 is an entry requirement): float4 value loads, DU4
+        // of them in flight.  One column per thread (4-byte loads, all threads busy) is 18 % slower on CVRP-500: the stage
+        // is bound by the number of load instructions, not by idle lanes.  A masked node has w == +0 exactly, so adding
+        // its terms unconditionally (with v = 0 in place of the skipped load) leaves the sums bit-identical.
+        const int E4 = E / 4;
+        for (int pp = tid; pp < E4 * EAMRL_NCHUNK; pp += BLOCK) {
+            const int g = pp / E4, e = 4 * (pp - g * E4), h = e / D;
+            const float* wh = l.w + h * M;
+            const int n0 = g * C, n1 = min(M, n0 + C);
+            float zg = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            for (int nb = n0; nb < n1; nb += DU4) {
+                float4 vv[DU4];
+                float ww[DU4];
 #pragma unroll
-            for (int u = 0; u < DU4; ++u) {
-                const int n = nb + u;
-                const bool onv = n < n1 && l.msk[n] != 0;
-                vv[u] = onv ? V[(int64_t)n * ld + e] : 0.0f;
-                ww[u] = onv ? wh[n] : 0.0f;
-            }
+                for (int u = 0; u < DU4; ++u) {
+                    const int n = nb + u;
+                    const bool onv = n < n1 && l.msk[n] != 0;
+                    vv[u] = onv ? *reinterpret_cast<const float4*>(V + (int64_t)n * ld + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    ww[u] = onv ? wh[n] : 0.0f;
+                }
 #pragma unroll
-            for (int u = 0; u < DU4; ++u) {
-                zg = zg + ww[u];
-                ag = fma_(ww[u], vv[u], ag);
+                for (int u = 0; u < DU4; ++u) {
+                    zg = zg + ww[u];
+                    a0 = fma_(ww[u], vv[u].x, a0);
+                    a1 = fma_(ww[u], vv[u].y, a1);
+                    a2 = fma_(ww[u], vv[u].z, a2);
+                    a3 = fma_(ww[u], vv[u].w, a3);
+                }
             }
+            float* pa = l.partA + g * E + e;      // (partA is only 4-byte aligned for odd M)
+            pa[0] = a0; pa[1] = a1; pa[2] = a2; pa[3] = a3;
+            if (e - h * D == 0) l.partZ[g * H + h] = zg;
         }
-        l.partA[g * E + e] = ag;
-        if (e - h * D == 0) l.partZ[g * H + h] = zg;
     }
     __syncthreads();
     for (int e = tid; e < E; e += BLOCK) {
@@ -226,13 +243,13 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
     // ---- D5 logit partials over NCHUNK column chunks ---------------------------------------------------------
     const int EC = E / EAMRL_NCHUNK;
     if (EC == 32) {
-        // two (node, column chunk) pairs per trip: 16 float4 loads in flight
-        for (int p0 = tid; p0 < M * EAMRL_NCHUNK; p0 += 2 * BLOCK) {
-            float4 lv[2][8];
-            bool on[2];
-            float rn[2];
+        // DU5 (node, column chunk) pairs per trip: 8 * DU5 float4 loads in flight
+        for (int p0 = tid; p0 < M * EAMRL_NCHUNK; p0 += DU5 * BLOCK) {
+            float4 lv[DU5][8];
+            bool on[DU5];
+            float rn[DU5];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < DU5; ++u) {
                 const int p = p0 + u * BLOCK;
                 const int pc = p < M * EAMRL_NCHUNK ? p : M * EAMRL_NCHUNK - 1;
                 const int n = pc / EAMRL_NCHUNK, c = pc - n * EAMRL_NCHUNK;
@@ -244,7 +261,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
                     lv[u][e4] = on[u] ? *reinterpret_cast<const float4*>(lp + 4 * e4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < DU5; ++u) {
                 const int p = p0 + u * BLOCK;
                 if (p >= M * EAMRL_NCHUNK) break;
                 const int c = p % EAMRL_NCHUNK;
