@@ -28,6 +28,16 @@ constexpr int DU4 = EAMRL_DU4;   // glimpse stage: value loads in flight per thr
 constexpr int DU5 = EAMRL_DU5;   // logit stage: (node, column chunk) pairs per trip, 8 float4 loads each
 constexpr int NWAVE = BLOCK / EAMRL_WAVE;
 
+#ifdef EAMRL_STAMPS   // development build only (tools/build_stamps.sh): per-stage cycle sums seen by thread 0 of each row
+__device__ unsigned long long g_sstamps[16];
+#define SSTAMP(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+                       atomicAdd(&g_sstamps[i], now_ - sst_t); sst_t = now_; } } while (0)
+#define SSTAMP_DECL unsigned long long sst_t = __builtin_readcyclecounter()
+#else
+#define SSTAMP(i) do { } while (0)
+#define SSTAMP_DECL do { } while (0)
+#endif
+
 struct RowState {
     int64_t first, cur, istep;
     float used, vcap;
@@ -74,6 +84,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
     const float* V = a.V + bi * M * ld;
     const float* Lp = a.Lp + bi * M * ld;
 
+    SSTAMP_DECL;
     // ---- D1 context query ----------------------------------------------------------------------
     for (int e = tid; e < E; e += BLOCK) {
         float g = a.gctx ? a.gctx[bi * E + e] : 0.0f;
@@ -163,6 +174,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         __syncthreads();
     }
 
+    SSTAMP(0);      // D1 + D2 (keys)
     // ---- D3 per-head max, w = exp(s - max) -------------------------------------------------------------
     for (int h = wv; h < H; h += NWAVE) {
         float* wh = l.w + h * M;
@@ -183,6 +195,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
     }
     __syncthreads();
 
+    SSTAMP(1);      // D3 (softmax weights)
     // ---- D4 glimpse: NCHUNK node chunks, sequential inside a chunk, chunks added left to right ----------
     const int C = (M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
     {
@@ -240,6 +253,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         __syncthreads();
     }
 
+    SSTAMP(2);      // D4 (values) + heads
     // ---- D5 logit partials over NCHUNK column chunks ---------------------------------------------------------
     const int EC = E / EAMRL_NCHUNK;
     if (EC == 32) {
@@ -299,6 +313,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
     }
     __syncthreads();
 
+    SSTAMP(3);      // D5 (logit keys)
     // ---- D6 combine, /sqrt(E), tanh clip, mask, /temperature ------------------------------------------------------
     const float sqrtE = __builtin_sqrtf((float)E);
     float tmax = -INFINITY;
@@ -425,6 +440,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
     }
     out_a = sel;
     out_lp = l.x[sel];
+    SSTAMP(4);      // D6-D8 (finish)
 }
 
 // Apply the env transition to the LDS copy of the row (msk, vis for CVRP, rem for SDVRP) and the uniform state.
@@ -742,3 +758,15 @@ int launch_decode_step(int env, const DecArgs& a, hipStream_t st) { return launc
 int launch_rollout_stream(int env, const DecArgs& a, hipStream_t st) { return launch_decode(env, a, true, st); }
 
 }  // namespace eamrl
+
+#ifdef EAMRL_STAMPS
+extern "C" __attribute__((visibility("default"))) int eamrl_debug_read_stream_stamps(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(eamrl::g_sstamps), sizeof(eamrl::g_sstamps)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(eamrl::g_sstamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

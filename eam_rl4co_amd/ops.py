@@ -509,9 +509,13 @@ def ea_cvrp_run_(locs, demand, vcap, pop, num_generations, mutation_rate, crosso
 class DecodeCache:
     """Device-resident decoder cache (struct eamrl_cache).
 
-    One [B, M, ld] fp32 buffer holds the per-node rows side by side in E-wide slots:
-        TSP : K | V | L | P_first | P_current | Lp        (ld = 6E)
-        CVRP: K | V | L | P_current | Lp                  (ld = 5E)
+    Two layouts of the same E-wide per-node rows (the kernels take base pointers and a row stride, so both work):
+      * slot-major, one [B, M, ld] fp32 buffer with the rows of a node side by side -- graphs up to 128 nodes, where
+        the register-resident kernel reads everything once:
+            TSP : K | V | L | P_first | P_current | Lp        (ld = 6E)
+            CVRP: K | V | L | P_current | Lp                  (ld = 5E)
+      * plane-major, [P, B, M, E] (ld = E) -- larger graphs, where the streaming kernel re-reads one kind of row per
+        stage and step: a stage then walks one dense plane instead of 512 bytes out of every 2.5-3 KB.
     K, V, L are AttentionModelDecoder's glimpse_key / glimpse_val / logit_key
     (zoo/am/decoder.py:206-235); P_* and Lp are the weight folds described in DESIGN.md.
     """
@@ -520,15 +524,20 @@ class DecodeCache:
         self.env_name, self.buf, self.cvec, self.gctx = env_name, buf, cvec, gctx
         self.dyn = dyn          # sdvrp: [3, E] dynamic-embedding vectors (key, value, folded logit key)
         self.node_embeddings = embeddings
-        self.B, self.M, self.ld = buf.shape
         self.E = embeddings.shape[-1]
         self.H = num_heads
         self.slots = slot_map(env_name)
-        assert self.ld == len(self.slots) * self.E
+        self.planes = buf.dim() == 4
+        if self.planes:
+            P, self.B, self.M, self.ld = buf.shape
+            assert P == len(self.slots) and self.ld == self.E
+        else:
+            self.B, self.M, self.ld = buf.shape
+            assert self.ld == len(self.slots) * self.E
 
     def view(self, name):
         i = self.slots[name]
-        return self.buf[..., i * self.E:(i + 1) * self.E]
+        return self.buf[i] if self.planes else self.buf[..., i * self.E:(i + 1) * self.E]
 
     # the reference's vocabulary (PrecomputedCache fields, zoo/am/decoder.py:22-41)
     @property
@@ -549,7 +558,7 @@ class DecodeCache:
 
     def struct(self):
         c = _lib.Cache()
-        base, step = self.buf.data_ptr(), self.E * 4
+        base, step = self.buf.data_ptr(), (self.B * self.M * self.E * 4 if self.planes else self.E * 4)
         c.K = C.c_void_p(base + self.slots["K"] * step)
         c.V = C.c_void_p(base + self.slots["V"] * step)
         c.Lp = C.c_void_p(base + self.slots["Lp"] * step)

@@ -13,6 +13,7 @@ No CPU / PyTorch implementation of the rollout exists here: tensors must live on
 from __future__ import annotations
 
 import logging
+import os
 from typing import Optional
 
 import torch
@@ -290,15 +291,27 @@ class AttentionModelDecoder(nn.Module):
         emb = embeddings.contiguous()
         B, M, _ = emb.shape
         slots = ops.slot_map(self.env_name)
-        buf = torch.empty(B, M, len(slots) * E, device=emb.device, dtype=torch.float32)
-        flat = buf.view(B * M, -1)
         Wa, Wb, cvec = self._weight_constants()
-        ops.linear(emb, self.project_node_embeddings.weight, out=flat[:, 0:3 * E])
-        ops.linear(emb, Wa, out=flat[:, slots["Pa"] * E:(slots["Pa"] + 1) * E])
-        if self.env_name == "tsp":
-            ops.linear(emb, Wb, out=flat[:, slots["Pb"] * E:(slots["Pb"] + 1) * E])
-        ops.matmul_right(flat[:, slots["L"] * E:(slots["L"] + 1) * E], self.pointer.project_out.weight.contiguous(),
-                         out=flat[:, slots["Lp"] * E:(slots["Lp"] + 1) * E])
+        Wkvl = self.project_node_embeddings.weight
+        if M > 128 and os.environ.get("EAMRL_CACHE_PLANES", "1") != "0":     # streaming-kernel territory: one dense
+            # plane per kind of row (ops.DecodeCache); the variable exists for A/B measurements only
+            buf = torch.empty(len(slots), B, M, E, device=emb.device, dtype=torch.float32)
+            plane = lambda n: buf[slots[n]].view(B * M, E)
+            for i, n in enumerate(("K", "V", "L")):
+                ops.linear(emb, Wkvl[i * E:(i + 1) * E], out=plane(n))
+            ops.linear(emb, Wa, out=plane("Pa"))
+            if self.env_name == "tsp":
+                ops.linear(emb, Wb, out=plane("Pb"))
+            ops.matmul_right(plane("L"), self.pointer.project_out.weight.contiguous(), out=plane("Lp"))
+        else:
+            buf = torch.empty(B, M, len(slots) * E, device=emb.device, dtype=torch.float32)
+            flat = buf.view(B * M, -1)
+            ops.linear(emb, Wkvl, out=flat[:, 0:3 * E])
+            ops.linear(emb, Wa, out=flat[:, slots["Pa"] * E:(slots["Pa"] + 1) * E])
+            if self.env_name == "tsp":
+                ops.linear(emb, Wb, out=flat[:, slots["Pb"] * E:(slots["Pb"] + 1) * E])
+            ops.matmul_right(flat[:, slots["L"] * E:(slots["L"] + 1) * E], self.pointer.project_out.weight.contiguous(),
+                             out=flat[:, slots["Lp"] * E:(slots["Lp"] + 1) * E])
         gctx = None
         if self.use_graph_context:
             gctx = ops.linear(ops.mean_nodes(emb), self.project_fixed_context.weight)
