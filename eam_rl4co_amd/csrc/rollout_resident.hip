@@ -379,14 +379,13 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             lpv[1] = fe[1] ? lp2.y : -INFINITY;
             int sel;
             if (a.mode == EAMRL_SAMPLE) {
+                // argmax of p / noise, lowest index on ties: the maximum by a value-only butterfly, then the first lane
+                // (node) that equals it -- a NaN key (0 / 0) never equals anything and is skipped by v_max, as before
                 const f32x2 k2 = d_expf2_nonpos((f32x2){lpv[0], lpv[1]}) / (f32x2){nz0, nz1};
-                float best = in0 ? k2.x : -INFINITY;
-                int besti = in0 ? n0 : 0x7fffffff;
-                const bool take1 = in1 & (k2.y > best);
-                best = take1 ? k2.y : best;
-                besti = take1 ? n1 : besti;
-                wave_argmax(best, besti);
-                sel = besti;
+                const float k0 = in0 ? k2.x : -INFINITY, k1 = in1 ? k2.y : -INFINITY;
+                const float top = wave_max(vmax_raw(k0, k1));
+                const unsigned long long b0 = __ballot(k0 == top), b1 = __ballot(k1 == top);
+                sel = b0 ? __builtin_ctzll(b0) : (b1 ? 64 + __builtin_ctzll(b1) : 0);
             } else {
                 // argmax of the log-probs, lowest index on ties: the maximum is known -- the lanes holding the
                 // largest logit have (mx - mx) - lse = 0 - lse, and rounding is monotonic -- so the winner is the
