@@ -3,9 +3,11 @@
 
 Run only in the build container (the reference never travels to the GPU box):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [extra | beam | filtering | sdvrp | pctsp | op | cvrptw]
 
-The reference modules (TSPEnv, CVRPEnv, AttentionModelPolicy, decoding strategies,
+(no argument: the first batch, TSP / CVRP / POMO; `extra`: larger graphs and decoding options; `beam`: beam search;
+`filtering`: top-k / top-p; `sdvrp`, `pctsp` (incl. SPCTSP), `op`, `cvrptw`: the sibling envs and their state_dict
+contracts.)  The reference modules (TSPEnv, CVRPEnv, AttentionModelPolicy, decoding strategies,
 PointerAttention ...) are imported unmodified from /root/reference through the
 container stand-ins of `_refshim.py` (tensordict/torchrl are absent; they carry no
 arithmetic of this path).  Weights are the closed-form `goldweights` streams, instances
