@@ -306,10 +306,9 @@ class AttentionModelDecoder(nn.Module):
         else:
             buf = torch.empty(B, M, len(slots) * E, device=emb.device, dtype=torch.float32)
             flat = buf.view(B * M, -1)
-            ops.linear(emb, Wkvl, out=flat[:, 0:3 * E])
-            ops.linear(emb, Wa, out=flat[:, slots["Pa"] * E:(slots["Pa"] + 1) * E])
-            if self.env_name == "tsp":
-                ops.linear(emb, Wb, out=flat[:, slots["Pb"] * E:(slots["Pb"] + 1) * E])
+            nproj = 5 if self.env_name == "tsp" else 4           # K, V, L, Pa (, Pb): slots 0 .. nproj-1
+            assert slots["Pa"] == 3 and slots.get("Pb", 4) == 4
+            ops.linear(emb, self._w_cache, out=flat[:, 0:nproj * E])
             ops.matmul_right(flat[:, slots["L"] * E:(slots["L"] + 1) * E], self.pointer.project_out.weight.contiguous(),
                              out=flat[:, slots["Lp"] * E:(slots["Lp"] + 1) * E])
         gctx = None
@@ -329,7 +328,9 @@ class AttentionModelDecoder(nn.Module):
         E = self.embed_dim
         Wctx = self.context_embedding.project_context.weight
         ph = getattr(self.context_embedding, "W_placeholder", None)
-        key = (Wctx.data_ptr(), Wctx._version, None if ph is None else (ph.data_ptr(), ph._version))
+        Wkvl = self.project_node_embeddings.weight
+        key = (Wctx.data_ptr(), Wctx._version, None if ph is None else (ph.data_ptr(), ph._version),
+               Wkvl.data_ptr(), Wkvl._version)
         if getattr(self, "_wc_key", None) != key:
             Wa = Wctx[:, 0:E].contiguous()
             if self.env_name == "tsp":
@@ -340,6 +341,9 @@ class AttentionModelDecoder(nn.Module):
                 # state columns: capacity (CVRP-like), prize / length left (PCTSP / OP); CVRPTW: capacity | time -> [2E]
                 cvec = Wctx[:, E:].t().reshape(-1).contiguous() if self.env_name == "cvrptw" else Wctx[:, E].contiguous()
             self._wc, self._wc_key = (Wa.detach(), None if Wb is None else Wb.detach(), cvec.detach()), key
+            # slot-major cache: K | V | L | Pa (| Pb) are adjacent slots, so one GEMM with the stacked weights writes them all
+            # (each output element is the same k-ordered chain as with separate launches)
+            self._w_cache = torch.cat([Wkvl.detach(), Wa.detach()] + ([Wb.detach()] if Wb is not None else []), 0).contiguous()
         return self._wc
 
     def pre_decoder_hook(self, td, env, embeddings, num_starts: int = 0):
