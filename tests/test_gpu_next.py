@@ -47,6 +47,42 @@ def test_rollout_shapes_and_kernel_boundaries(oracle, env_name, N, B, mode):
     assert_bits_equal(out["reward"], o["reward"], "reward")
 
 
+@pytest.mark.parametrize("env_name", ["tsp", "cvrp", "cvrptw", "sdvrp", "pctsp", "spctsp", "op"])
+def test_randomized_instances_match_oracle(oracle, env_name):
+    """Seeded sweep over instance sizes, batch sizes, decode modes and (for the depot envs) multistart: tours, log-probs
+    and rewards bit-equal to the oracle every time."""
+    import eam_rl4co_amd as ea
+
+    cfg = "am_" + env_name
+    pol = make_policy(cfg)
+    rng = np.random.default_rng(sum(env_name.encode()))      # (not hash(): that is salted per process)
+    for trial in range(8):
+        N = int(rng.integers(10 if env_name == "sdvrp" else 5, 90))
+        B = int(rng.integers(1, 6))
+        mode = ("greedy", "sampling")[trial % 2]
+        S = int(rng.integers(2, 6)) if (trial % 4 >= 2 and env_name != "op") else 0     # (op may resample its starts)
+        env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=1000 + trial)
+        torch.manual_seed(2000 + 31 * trial + N)
+        td_cpu = env.reset(batch_size=[B])
+        locs = td_cpu["locs"].numpy()
+        M = locs.shape[1]
+        R = B * max(S, 1)
+        kw, noise = {}, None
+        if mode == "sampling":
+            noise = torch.empty(R, 3 * M + 1, M).exponential_(1, generator=torch.Generator().manual_seed(trial))
+            kw["noise"] = noise.to(DEV)
+        dt = ("multistart_" if S else "") + mode
+        if S:
+            kw["num_starts"] = S
+        out = pol(td_cpu.to(DEV), env, phase="test", decode_type=dt, return_sum_log_likelihood=False, **kw)
+        o = oracle.policy_rollout(golden_weights(cfg), env_name, locs, instance_from_td(env_name, td_cpu), decode_type=dt,
+                                  num_starts=S, noise=None if noise is None else noise.numpy())
+        what = f"{env_name} trial {trial}: N={N} B={B} S={S} {mode}"
+        assert_bits_equal(out["actions"], o["actions"], "tours " + what)
+        assert_bits_equal(out["log_likelihood"], o["logp_steps"], "logp " + what)
+        assert_bits_equal(out["reward"], o["reward"], "reward " + what)
+
+
 @pytest.mark.parametrize("clip,temp", [(0.0, 1.0), (10.0, 0.7), (5.0, 2.5)])
 def test_temperature_and_clipping_options(oracle, clip, temp):
     import eam_rl4co_amd as ea
