@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmarks of single kernels at the TSP-100 B=1024 shapes (run on the GPU box).
 
-    python tools/kernel_bench.py gemm | mha | decode | all      [--iters 20]
+    python tools/kernel_bench.py gemm | mha | decode | ea | train | all      [--iters 20]
 """
 import argparse
 import os
@@ -95,6 +95,49 @@ def bench_ea(iters):
         print(f"ea_tsp_run B={B} S={S} N={N} G={G} rates={rates}: {us:8.1f} us  ({B * S * G / us:.1f} M individuals-generations/s)")
 
 
+def bench_train(iters):
+    """One EAM training step of the fork (zoo/earl/model.py:129-247) end to end: sampled multistart rollout (native),
+    evolutionary improvement (native), teacher-forced re-evaluation with autograd, backward, Adam step."""
+    import time
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import train
+
+    for env_name, N, B, S in (("tsp", 50, 64, 50), ("tsp", 100, 64, 100), ("cvrp", 50, 64, 50)):
+        env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=3)
+        pol = ea.AttentionModelPolicy(env_name=env_name, num_encoder_layers=6, normalization="instance",
+                                      use_graph_context=False).to("cuda")
+        opt = torch.optim.Adam(pol.parameters(), lr=1e-4)
+        runner = ea.EA(env, dict(num_generations=3, mutation_rate=0.1, crossover_rate=0.6, selection_rate=0.2))
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        td = env.reset(batch_size=[B]).to("cuda")
+        parts = {}
+
+        def step():
+            t0 = time.perf_counter()
+            res = train.eam_loss(pol, env, td, runner, num_starts=S, generator=gen)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            opt.zero_grad()
+            res["loss"].backward()
+            opt.step()
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            parts["forward (rollout + EA + re-evaluation)"] = parts.get("forward (rollout + EA + re-evaluation)", 0) + t1 - t0
+            parts["backward + Adam"] = parts.get("backward + Adam", 0) + t2 - t1
+
+        for _ in range(2):
+            step()
+        parts.clear()
+        n = max(3, iters // 4)
+        for _ in range(n):
+            step()
+        tot = sum(parts.values()) / n * 1e3
+        print(f"EAM training step {env_name}{N} B={B} S={S} (POMO policy): {tot:8.1f} ms  "
+              + "  ".join(f"{k} {v / n * 1e3:.1f} ms" for k, v in parts.items())
+              + f"  = {B * S * N / tot * 1e3 / 1e6:.1f} M sampled env-steps/s incl. the update")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
@@ -111,6 +154,8 @@ def main():
         bench_mha(a.iters)
     if a.what in ("ea", "all"):
         bench_ea(a.iters)
+    if a.what in ("train",):
+        bench_train(a.iters)
     if a.what in ("decode",):
         for tm in (None, 1, 11, 51):
             bench_decode(a.iters, tm)
