@@ -227,6 +227,19 @@ __attribute__((visibility("default"))) int eamrl_normalize(float* x, int64_t B, 
                     "eamrl_normalize");
 }
 
+__attribute__((visibility("default"))) int eamrl_batchnorm_train(float* x, int64_t rows, int E, const float* gamma,
+                                                                const float* beta, float* running_mean, float* running_var,
+                                                                float momentum, float eps, float* save_mean, float* save_var,
+                                                                float* ws, int64_t ws_floats, void* stream)
+{
+    REQUIRE(x && gamma && beta && save_mean && save_var && ws, "eamrl_batchnorm_train");
+    REQUIRE(rows >= 0 && E > 0 && E <= 8192, "eamrl_batchnorm_train");
+    REQUIRE((running_mean == nullptr) == (running_var == nullptr), "eamrl_batchnorm_train");
+    REQUIRE(ws_floats >= ((rows + 127) / 128) * (int64_t)E, "eamrl_batchnorm_train");
+    return launched(launch_batchnorm_train(x, rows, E, gamma, beta, running_mean, running_var, momentum, eps, save_mean,
+                                           save_var, ws, (hipStream_t)stream), "eamrl_batchnorm_train");
+}
+
 __attribute__((visibility("default"))) int eamrl_mean_nodes(const float* emb, float* out, int64_t B, int M, int E,
                                                            void* stream)
 {

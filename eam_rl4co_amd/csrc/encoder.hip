@@ -793,6 +793,73 @@ __global__ void k_mean_nodes(const float* emb, float* out, int M, int E)
     }
 }
 
+// BatchNorm1d with BATCH statistics (policy.train(), nn/ops.py:45-47): per-channel mean and biased variance over all
+// rows in a defined order -- chunks of BN_CHUNK rows summed sequentially (thread = channel, coalesced across channels),
+// chunk sums added in ascending order; variance as the mean of fma(d, d, .) with d = x - mean (second pass).
+constexpr int BN_CHUNK = 128;
+
+__global__ void k_bn_partial(const float* x, int64_t rows, int E, const float* mean, float* ws)
+{
+    const int64_t r0 = (int64_t)blockIdx.x * BN_CHUNK;
+    const int64_t r1 = r0 + BN_CHUNK < rows ? r0 + BN_CHUNK : rows;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        float s = 0.0f;
+        if (!mean) {
+            for (int64_t r = r0; r < r1; ++r) s = s + x[r * E + e];
+        } else {
+            const float m = mean[e];
+            for (int64_t r = r0; r < r1; ++r) { const float d = x[r * E + e] - m; s = fma_(d, d, s); }
+        }
+        ws[(int64_t)blockIdx.x * E + e] = s;
+    }
+}
+
+// pass 0: mean -> save_mean; pass 1: biased variance -> save_var, and the running statistics as torch updates them
+// (running = (1 - momentum) * running + momentum * stat, the variance one unbiased: sum / (n - 1)).
+__global__ void k_bn_final(const float* ws, int nchunks, int E, int64_t rows, int pass, float* save_mean, float* save_var,
+                           float* running_mean, float* running_var, float momentum)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float s = 0.0f;
+    for (int c = 0; c < nchunks; ++c) s = s + ws[(int64_t)c * E + e];
+    const float n = (float)rows;
+    if (pass == 0) {
+        save_mean[e] = s / n;
+    } else {
+        save_var[e] = s / n;
+        if (running_mean) {
+            const float keep = 1.0f - momentum;
+            const float a = keep * running_mean[e], b = momentum * save_mean[e];
+            running_mean[e] = a + b;
+            const float unb = rows > 1 ? s / (n - 1.0f) : s / n;
+            const float c = keep * running_var[e], d = momentum * unb;
+            running_var[e] = c + d;
+        }
+    }
+}
+
+int launch_batchnorm_train(float* x, int64_t rows, int E, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float momentum, float eps, float* save_mean, float* save_var, float* ws,
+                           hipStream_t st)
+{
+    if (rows <= 0) return 0;
+    const int nchunks = (int)((rows + BN_CHUNK - 1) / BN_CHUNK);
+    const int thr = E <= 1024 ? ((E + 63) / 64) * 64 : 1024;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(k_bn_partial, dim3((unsigned)nchunks), dim3(thr), 0, st, x, rows, E,
+                           pass ? (const float*)save_mean : (const float*)nullptr, ws);
+        hipLaunchKernelGGL(k_bn_final, dim3((unsigned)((E + 127) / 128)), dim3(128), 0, st, ws, nchunks, E, rows, pass,
+                           save_mean, save_var, running_mean, running_var, momentum);
+    }
+    const int64_t total = rows * E;
+    const int64_t want = (total + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(k_norm_batch_eval, dim3(blocks), dim3(256), 2 * E * sizeof(float), st, x, rows, E, gamma, beta,
+                       save_mean, save_var, eps);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
 int launch_normalize(float* x, int64_t B, int N, int E, int kind, const float* gamma, const float* beta,
                      const float* mean, const float* var, float eps, hipStream_t st)
 {

@@ -26,6 +26,9 @@ int launch_mha_mfma(const float* qkv, float* out, int64_t B, int N, int E, int H
 bool mha_mfma_supports(int64_t B, int N, int E, int H, const float* qkv, const float* out);
 int launch_normalize(float* x, int64_t B, int N, int E, int kind, const float* gamma, const float* beta,
                      const float* mean, const float* var, float eps, hipStream_t st);
+int launch_batchnorm_train(float* x, int64_t rows, int E, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float momentum, float eps, float* save_mean, float* save_var, float* ws,
+                           hipStream_t st);
 int launch_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, hipStream_t st);
 int launch_tsp_step(uint8_t* mask, int64_t* first, int64_t* cur, int64_t* istep, const int64_t* action,
                     uint8_t* done, int64_t R, int N, hipStream_t st);

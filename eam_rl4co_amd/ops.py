@@ -141,6 +141,29 @@ def normalize_(x, kind, gamma, beta, mean=None, var=None, eps=1e-5):
     return x
 
 
+def batchnorm_train_(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """BatchNorm1d with batch statistics over all rows of x [..., E], in place; running stats updated as torch does.
+    -> (x, batch_mean [E], batch_var [E] (biased))."""
+    lib = _lib.load()
+    _chk(x, "x", torch.float32)
+    E = x.shape[-1]
+    rows = x.numel() // E
+    for nm, t in (("gamma", gamma), ("beta", beta)):
+        _chk(t, nm, torch.float32, (E,))
+    if (running_mean is None) != (running_var is None):
+        raise ValueError("batchnorm_train: running_mean and running_var come together")
+    if running_mean is not None:
+        _chk(running_mean, "running_mean", torch.float32, (E,))
+        _chk(running_var, "running_var", torch.float32, (E,))
+    nws = ((rows + 127) // 128) * E
+    ws = torch.empty(nws + 2 * E, device=x.device, dtype=torch.float32)
+    save_mean, save_var = ws[nws:nws + E], ws[nws + E:]
+    _lib.check(lib.eamrl_batchnorm_train(_ptr(x), rows, E, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                         float(momentum), float(eps), _ptr(save_mean), _ptr(save_var), _ptr(ws), nws,
+                                         _stream(x)), "eamrl_batchnorm_train")
+    return x, save_mean, save_var
+
+
 def mean_nodes(emb):
     lib = _lib.load()
     _chk(emb, "emb", torch.float32)

@@ -146,23 +146,25 @@ class Normalization(nn.Module):
         elif normalization == "instance":
             self.normalizer = nn.InstanceNorm1d(embed_dim, affine=True)
         else:
-            raise NotImplementedError(f"normalization={normalization!r}: only 'batch' (eval) and 'instance' are "
-                                      "built for MI355X")
+            raise NotImplementedError(f"normalization={normalization!r}: only 'batch' and 'instance' are built for MI355X")
 
     def fused_bn(self):
-        """(gamma, beta, mean, var, eps) when this is an eval-mode BatchNorm that the producing GEMM can apply."""
+        """(gamma, beta, mean, var, eps) when this is an eval-mode BatchNorm that the producing GEMM can apply;
+        None for instance norm and for a BatchNorm in training mode (batch statistics: `apply_`)."""
         n = self.normalizer
-        if not isinstance(n, nn.BatchNorm1d):
+        if not isinstance(n, nn.BatchNorm1d) or self.training:
             return None
-        if self.training:
-            raise NotImplementedError(
-                "BatchNorm batch statistics (policy.train()) are not part of the MI355X rollout path; "
-                "call policy.eval() (RolloutBaseline / evaluation do, reinforce/baselines.py:232)")
         return (n.weight, n.bias, n.running_mean, n.running_var, n.eps)
 
     def apply_(self, x):
         n = self.normalizer
         if isinstance(n, nn.BatchNorm1d):
+            if self.training:
+                # batch statistics over all B*M rows, running statistics updated (nn/ops.py:45-47; SURVEY Appendix A9)
+                momentum = 0.1 if n.momentum is None else n.momentum
+                ops.batchnorm_train_(x, n.weight.detach(), n.bias.detach(), n.running_mean, n.running_var, momentum, n.eps)
+                n.num_batches_tracked.add_(1)
+                return x
             g, b, m, v, eps = self.fused_bn()
             return ops.normalize_(x, ops.NORM_BATCH_EVAL, g, b, m, v, eps)
         return ops.normalize_(x, ops.NORM_INSTANCE, n.weight, n.bias, eps=n.eps)
@@ -521,18 +523,50 @@ class AttentionModelPolicy(nn.Module):
         self.train_decode_type, self.val_decode_type, self.test_decode_type = (
             train_decode_type, val_decode_type, test_decode_type)
 
-    @torch.no_grad()
     def forward(self, td, env: Optional[str | RL4COEnvBase] = None, phase: str = "train", calc_reward: bool = True,
                 return_actions: bool = True, return_entropy: bool = False, return_hidden: bool = False,
                 return_init_embeds: bool = False, return_sum_log_likelihood: bool = True, actions=None,
                 max_steps=1_000_000, **decoding_kwargs) -> dict:
         """The construction rollout (constructive/base.py:157-275): encode once, precompute the cache, run the
-        whole decode loop on the device, compute reward and log-likelihood.  Gradients are not produced here.
+        whole decode loop on the device, compute reward and log-likelihood.
         Two halves: `_enqueue` launches every kernel without touching the host (it can be captured into a HIP
-        graph, see GraphedRollout), `_finish` performs the rollout's single device->host sync and slices."""
-        p = self._enqueue(td, env, phase, calc_reward, return_actions, return_entropy, return_hidden,
-                          return_init_embeds, return_sum_log_likelihood, actions, max_steps, **decoding_kwargs)
-        return p["out"] if "out" in p else self._finish(p)     # beam search is host-driven and arrives finished
+        graph, see GraphedRollout), `_finish` performs the rollout's single device->host sync and slices.
+
+        Gradients: the kernels build no graph.  With autograd enabled and phase == "train" (what REINFORCE / POMO /
+        EAM.shared_step call, reinforce.py:62-64, pomo/model.py:103, earl/model.py:179-195) the returned
+        `log_likelihood` carries a grad_fn: its value is the native rollout's, its gradient is that of the
+        teacher-forced re-evaluation of the chosen actions (train.attach_log_likelihood_grad), so
+        `loss = -(advantage * out["log_likelihood"]).mean(); loss.backward()` works as with the reference.  Validation /
+        test phases run under no_grad in the reference's trainers and are not re-evaluated here."""
+        want_grad = (torch.is_grad_enabled() and phase == "train" and not torch.is_inference_mode_enabled()
+                     and any(q.requires_grad for q in self.parameters()))
+        with torch.no_grad():
+            p = self._enqueue(td, env, phase, calc_reward, return_actions, return_entropy, return_hidden,
+                              return_init_embeds, return_sum_log_likelihood, actions, max_steps, **decoding_kwargs)
+            if "out" in p:          # beam search is host-driven and arrives finished (inference only)
+                return p["out"]
+            out = self._finish(p)
+        return self._attach_grad(out, p) if want_grad else out
+
+    def _attach_grad(self, out: dict, p: dict) -> dict:
+        from .train import evaluate_log_likelihood
+
+        if p["S"] > 0 and p["select_best"]:
+            raise NotImplementedError("select_best=True under autograd: the reference's trainers select the best start "
+                                      "only outside training (reinforce.py:64)")
+        if p["top_k"] or p["top_p"]:
+            raise NotImplementedError("top-k / top-p filtering is not part of the differentiable re-evaluation")
+        re = evaluate_log_likelihood(self, p["td"], p["env"], p["final_actions"], num_starts=p["S"],
+                                     multistart=bool(p["pre"]), temperature=p["temperature"],
+                                     tanh_clipping=p["tanh_clipping"])
+        td_mask = p["td"].get("mask", None) if hasattr(p["td"], "get") else None
+        if td_mask is not None:
+            re = re.masked_fill(~td_mask, 0)
+        if p["return_sum_log_likelihood"]:
+            re = re.sum(1)
+        out = dict(out)
+        out["log_likelihood"] = out["log_likelihood"].detach() + (re - re.detach())     # native value, re-eval gradient
+        return out
 
     def _enqueue(self, td, env, phase, calc_reward, return_actions, return_entropy, return_hidden, return_init_embeds,
                  return_sum_log_likelihood, actions, max_steps, **decoding_kwargs) -> dict:
@@ -660,6 +694,7 @@ class AttentionModelPolicy(nn.Module):
         else:
             flags = torch.tensor([T, status], dtype=torch.int32)
         return dict(flags=flags, has_bad=bad is not None, pre=1 if pre_actions else 0, t_max=t_max, M=M, S=S,
+                    temperature=temperature, tanh_clipping=tanh_clipping, top_k=top_k, top_p=top_p,
                     select_best=select_best, calc_reward=calc_reward, env=env, st=st, td=td, cache=cache,
                     actions_pad=actions_pad, logp_pad=logp_pad, reward_pad=reward_pad, ll_pad=ll_pad,
                     all_logp=all_logp, init_embeds=init_embeds, return_actions=return_actions,
@@ -736,6 +771,7 @@ class AttentionModelPolicy(nn.Module):
         if p["return_init_embeds"]:
             out["init_embeds"] = p["init_embeds"]
         self._last_td = td_out   # final env state of the last rollout (the reference keeps it in a local)
+        p["final_actions"] = actions_out
         return out
 
     def _beam_search(self, td, env, kw, calc_reward, return_actions, return_sum_log_likelihood, return_hidden,

@@ -1,13 +1,16 @@
 """Training companion of the native rollout: gradients by teacher-forced re-evaluation.
 
-The rollout itself (`AttentionModelPolicy.forward`) runs on the HIP kernels and produces no gradients.  For
-REINFORCE / POMO / EAM the log-likelihood of the *chosen* actions is what must be differentiated; because the
-actions are known after the rollout, every decode step's state (current / first node, visited set, used
-capacity) is a prefix function of the action sequence, so all T steps are re-evaluated AT ONCE as dense batched
-contractions with PyTorch autograd -- the same trick serves EAM's `policy(..., actions=improved)` pass
-(rl4co/models/zoo/earl/model.py:179-195).  This module is the gradient path only: it is not used by inference,
-benchmarks or parity tests of the rollout, and its forward values are checked against the native log-probs
-(tests/test_gpu_train.py, tolerance 1e-4).
+The rollout itself runs on the HIP kernels without a graph.  For REINFORCE / POMO / EAM the log-likelihood of the
+*chosen* actions is what must be differentiated; because the actions are known after the rollout, every decode
+step's state (current / first node, visited set, used capacity) is a prefix function of the action sequence, so all
+T steps are re-evaluated AT ONCE as dense batched contractions -- the same trick serves EAM's
+`policy(..., actions=improved)` pass (rl4co/models/zoo/earl/model.py:179-195).
+`AttentionModelPolicy.forward(phase="train")` attaches this re-evaluation to the `log_likelihood` it returns
+(`attach_log_likelihood_grad`): the value is the native rollout's, the gradient is the re-evaluation's, so the
+reference's trainers (`out["log_likelihood"]` -> loss -> backward, reinforce.py:79-106, pomo/model.py:89-112) run on
+the policy unchanged.  This module is the gradient path only: it is not used by inference, benchmarks or parity tests
+of the rollout, and its forward values are checked against the native log-probs (tests/test_gpu_next.py,
+tests/test_gpu_train.py).
 
 Reference call sites: rl4co/models/rl/reinforce/reinforce.py:59-106 (REINFORCE.shared_step / calculate_loss),
 rl4co/models/rl/reinforce/baselines.py:57-61 (SharedBaseline), rl4co/models/zoo/pomo/model.py:89-148.
@@ -28,9 +31,14 @@ from .utils import unbatchify
 # ------------------------------------------------------------------------------------------------------------
 def _normalize(norm: nn.Module, x: torch.Tensor, training: bool) -> torch.Tensor:
     n = norm.normalizer
-    if isinstance(n, nn.BatchNorm1d):   # batch statistics when training, as the reference (nn/ops.py:45-47)
-        y = F.batch_norm(x.reshape(-1, x.size(-1)), n.running_mean, n.running_var, n.weight, n.bias, training,
-                         n.momentum if n.momentum is not None else 0.1, n.eps)
+    if isinstance(n, nn.BatchNorm1d):
+        # Batch statistics when training, as the reference (nn/ops.py:45-47) and as the native rollout that drew the
+        # actions (ops.batchnorm_train_); the running statistics were updated by that rollout, not again here.
+        x2 = x.reshape(-1, x.size(-1))
+        if training:
+            y = F.batch_norm(x2, None, None, n.weight, n.bias, True, 0.0, n.eps)
+        else:
+            y = F.batch_norm(x2, n.running_mean, n.running_var, n.weight, n.bias, False, 0.0, n.eps)
         return y.view_as(x)
     return F.instance_norm(x.permute(0, 2, 1), weight=n.weight, bias=n.bias, eps=n.eps).permute(0, 2, 1)
 
@@ -218,111 +226,189 @@ def _sdvrp_states(actions, demand_rows, vcap, M):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# differentiable decoder inputs and the per-chunk log-probabilities
+# ------------------------------------------------------------------------------------------------------------
+_STATE_KEYS = {"cvrp": ("demand", "vehicle_capacity"), "sdvrp": ("demand", "vehicle_capacity"),
+               "cvrptw": ("demand", "vehicle_capacity", "locs", "time_windows", "durations"),
+               "op": ("locs", "max_length"), "pctsp": ("real_prize", "prize_required"), "tsp": ()}
+
+
+def decoder_tensors(policy, td):
+    """The differentiable tensors the decode steps read: node embeddings, glimpse key / value, logit key, graph
+    context (encoder + `_precompute_cache` with autograd) and the decoder's own parameters.  -> dict name -> tensor."""
+    dec = policy.decoder
+    emb = encode_autograd(policy, td)
+    K, V, L = F.linear(emb, dec.project_node_embeddings.weight).chunk(3, dim=-1)
+    t = {"emb": emb, "K": K, "V": V, "L": L, "Wctx": dec.context_embedding.project_context.weight,
+         "Wout": dec.pointer.project_out.weight}
+    if dec.use_graph_context:
+        t["gctx"] = F.linear(emb.mean(1), dec.project_fixed_context.weight)
+    if policy.env_name == "tsp":
+        t["placeholder"] = dec.context_embedding.W_placeholder
+    if policy.env_name == "sdvrp":
+        t["dyn"] = dec.dynamic_embedding.projection.weight
+    return t
+
+
+def _logp_rows(env_name, t, static, act, nrep, multistart, H, temperature, clip):
+    """Per-step log-probabilities [Rc, T] of the rows `act` (nrep whole start groups of the B instances, (s b) order).
+    `t`: decoder_tensors; `static`: the instance tensors the masks are rebuilt from."""
+    emb, K, V, L = t["emb"], t["K"], t["V"], t["L"]
+    B, M, E = emb.shape
+    D = E // H
+    rep = lambda x: x.repeat(nrep, *([1] * (x.dim() - 1)))   # (s b) order: instance index = row % B
+    embr, Kr, Vr, Lr = rep(emb), rep(K), rep(V), rep(L)
+    Rc, T = act.shape
+    ar = torch.arange(Rc, device=act.device)[:, None]
+    dem_t = None
+    with torch.no_grad():
+        if env_name == "tsp":
+            first, cur, mask = _tsp_states(act, M, multistart)
+            rem = now = None
+        elif env_name == "cvrptw":
+            cur, rem, now, mask = _cvrptw_states(act, rep(static["demand"]), rep(static["vehicle_capacity"].reshape(-1)),
+                                                 rep(static["locs"]), rep(static["time_windows"].float()),
+                                                 rep(static["durations"].float()))
+        elif env_name == "op":
+            cur, rem, mask = _op_states(act, rep(static["locs"]), rep(static["max_length"]))
+        elif env_name == "pctsp":
+            cur, rem, mask = _pctsp_states(act, rep(static["real_prize"]), rep(static["prize_required"].reshape(-1)))
+        elif env_name == "cvrp":
+            cur, rem, mask = _cvrp_states(act, rep(static["demand"]), rep(static["vehicle_capacity"].reshape(-1)), M)
+        else:
+            cur, rem, mask, dem_t = _sdvrp_states(act, rep(static["demand"]), rep(static["vehicle_capacity"].reshape(-1)), M)
+    if env_name == "tsp":
+        ctx_in = torch.cat((embr[ar, first], embr[ar, cur]), -1)                       # [Rc, T, 2E]
+        if not multistart:   # step 0 uses the learned placeholder (context.py:118-131)
+            ctx_in = torch.cat((t["placeholder"].expand(Rc, 1, 2 * E), ctx_in[:, 1:]), 1)
+    elif env_name == "cvrptw":
+        ctx_in = torch.cat((embr[ar, cur], rem[..., None], now[..., None]), -1)          # [Rc, T, E+2]
+    else:
+        ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)                          # [Rc, T, E+1]
+    q = F.linear(ctx_in, t["Wctx"])
+    if "gctx" in t:
+        q = q + rep(t["gctx"])[:, None, :]
+    qh = q.view(Rc, T, H, D).permute(0, 2, 1, 3)
+    kh = Kr.view(Rc, M, H, D).permute(0, 2, 1, 3)
+    vh = Vr.view(Rc, M, H, D).permute(0, 2, 1, 3)
+    if env_name == "sdvrp":
+        # dynamic embedding (dynamic.py:59-78): K/V/L rows + remaining demand * projection columns.  The update is
+        # rank one, so it enters as a score bias and two outer products instead of [Rc, T, M, E] tensors
+        wk, wv, wl = t["dyn"].view(3, E)
+        qw = (qh * wk.view(1, H, 1, D)).sum(-1)                                              # [Rc, H, T]
+        bias = (dem_t[:, None] * qw[..., None]) / math.sqrt(D)                               # [Rc, H, T, M]
+        bias = bias.masked_fill(~mask[:, None], float("-inf"))
+        att = torch.softmax(torch.matmul(qh, kh.transpose(-1, -2)) / math.sqrt(D) + bias, dim=-1)
+        heads = torch.matmul(att, vh) + (att * dem_t[:, None]).sum(-1, keepdim=True) * wv.view(1, H, 1, D)
+    else:
+        heads = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=mask[:, None])     # [Rc, H, T, D]
+    glimpse = F.linear(heads.permute(0, 2, 1, 3).reshape(Rc, T, E), t["Wout"])
+    logits = torch.bmm(glimpse, Lr.transpose(1, 2))
+    if env_name == "sdvrp":
+        logits = logits + dem_t * (glimpse @ wl)[..., None]
+    logits = logits / math.sqrt(E)
+    if clip > 0:
+        logits = torch.tanh(logits) * clip
+    logits = logits.masked_fill(~mask, float("-inf")) / temperature
+    logp = F.log_softmax(logits, dim=-1).gather(-1, act[..., None]).squeeze(-1)
+    if multistart:   # the start node is not a decision (decoding.py:318-324)
+        logp = torch.cat((torch.zeros_like(logp[:, :1]), logp[:, 1:]), 1)
+        # steps t >= 1 were evaluated with the state after the start action: column t uses prefix a_{<t} as built
+    return logp
+
+
+class _ChunkedReeval(torch.autograd.Function):
+    """logp = cat_c fn(c, *tensors) with activation memory bounded to one chunk: the forward keeps no graph, the
+    backward recomputes each chunk with autograd and accumulates the gradients of `tensors`."""
+
+    @staticmethod
+    def forward(ctx, fn, n_chunks, *tensors):
+        with torch.no_grad():
+            outs = [fn(c, *tensors) for c in range(n_chunks)]
+        ctx.fn, ctx.n_chunks = fn, n_chunks
+        ctx.save_for_backward(*tensors)
+        return torch.cat(outs, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        leaves = [x.detach().requires_grad_(need) for x, need in zip(ctx.saved_tensors, ctx.needs_input_grad[2:])]
+        need = [x for x in leaves if x.requires_grad]
+        acc = [None] * len(need)
+        off = 0
+        for c in range(ctx.n_chunks):
+            with torch.enable_grad():
+                out = ctx.fn(c, *leaves)
+            gs = torch.autograd.grad(out, need, g[off:off + out.shape[0]], allow_unused=True)
+            off += out.shape[0]
+            for i, gi in enumerate(gs):
+                if gi is not None:
+                    acc[i] = gi if acc[i] is None else acc[i].add_(gi)
+        it = iter(acc)
+        return (None, None) + tuple(next(it) if x.requires_grad else None for x in leaves)
+
+
 def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, temperature=None, tanh_clipping=None,
-                            chunk_rows: int = 4096):
-    """Differentiable per-step log-probabilities of `actions` [R, T] (R = B or S*B rows in (s b) order; for
-    multistart the first column is the start node and gets log-prob 0).  Returns logp [R, T]."""
+                            chunk_rows: int = 4096, multistart=None, checkpoint=None):
+    """Differentiable per-step log-probabilities of `actions` [R, T] (R = B or S*B rows in (s b) order).  multistart
+    (default: num_starts > 1): the first column is the start node and gets log-prob 0; False with num_starts > 1 is
+    the multi-sample layout (every column a decision).  checkpoint (default: by size): keep no activations in the
+    forward and recompute chunk by chunk in the backward.  Returns logp [R, T]."""
     temperature = policy.temperature if temperature is None else temperature
     clip = policy.tanh_clipping if tanh_clipping is None else tanh_clipping
-    dec = policy.decoder
-    E, H = dec.embed_dim, dec.num_heads
-    D = E // H
-    emb = encode_autograd(policy, td)
-    B, M, _ = emb.shape
-    kvl = F.linear(emb, dec.project_node_embeddings.weight)
-    K, V, L = kvl.chunk(3, dim=-1)
-    gctx = F.linear(emb.mean(1), dec.project_fixed_context.weight) if dec.use_graph_context else None
-    Wctx = dec.context_embedding.project_context.weight
+    H = policy.decoder.num_heads
+    t = decoder_tensors(policy, td)
+    B, M, _ = t["emb"].shape
     R, T = actions.shape
     S = max(int(num_starts), 1)
     assert R == S * B
-    multistart = S > 1
-    out = []
+    if multistart is None:
+        multistart = S > 1
+    env_name = policy.env_name
+    static = {k: td[k] for k in _STATE_KEYS[env_name]}
     # rows are processed in chunks of whole start-groups so that memory stays bounded ([rows, H, T, M] scores)
     starts_per_chunk = max(1, chunk_rows // B)
-    for s0 in range(0, S, starts_per_chunk):
-        s1 = min(S, s0 + starts_per_chunk)
-        rows = slice(s0 * B, s1 * B)
-        act = actions[rows]
-        nrep = s1 - s0
-        rep = lambda x: x.repeat(nrep, *([1] * (x.dim() - 1)))   # (s b) order: instance index = row % B
-        embr, Kr, Vr, Lr = rep(emb), rep(K), rep(V), rep(L)
-        Rc = act.shape[0]
-        ar = torch.arange(Rc, device=act.device)[:, None]
-        if policy.env_name == "tsp":
-            first, cur, mask = _tsp_states(act, M, multistart)
-            ctx_in = torch.cat((embr[ar, first], embr[ar, cur]), -1)                       # [Rc, T, 2E]
-            if not multistart:   # step 0 uses the learned placeholder (context.py:118-131)
-                ctx_in = torch.cat((dec.context_embedding.W_placeholder.expand(Rc, 1, 2 * E), ctx_in[:, 1:]), 1)
-        elif policy.env_name == "cvrptw":
-            cur, rem, now, mask = _cvrptw_states(act, rep(td["demand"]), rep(td["vehicle_capacity"].reshape(-1)),
-                                                 rep(td["locs"]), rep(td["time_windows"].float()), rep(td["durations"].float()))
-            ctx_in = torch.cat((embr[ar, cur], rem[..., None], now[..., None]), -1)          # [Rc, T, E+2]
-        elif policy.env_name == "op":
-            cur, rem, mask = _op_states(act, rep(td["locs"]), rep(td["max_length"]))
-            ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)                          # [Rc, T, E+1]
-        elif policy.env_name == "pctsp":
-            cur, rem, mask = _pctsp_states(act, rep(td["real_prize"]), rep(td["prize_required"].reshape(-1)))
-            ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)                          # [Rc, T, E+1]
-        elif policy.env_name == "cvrp":
-            cur, rem, mask = _cvrp_states(act, rep(td["demand"]), rep(td["vehicle_capacity"].reshape(-1)), M)
-            ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)                          # [Rc, T, E+1]
-        else:
-            cur, rem, mask, dem_t = _sdvrp_states(act, rep(td["demand"]), rep(td["vehicle_capacity"].reshape(-1)), M)
-            ctx_in = torch.cat((embr[ar, cur], rem[..., None]), -1)
-        q = F.linear(ctx_in, Wctx)
-        if gctx is not None:
-            q = q + rep(gctx)[:, None, :]
-        qh = q.view(Rc, T, H, D).permute(0, 2, 1, 3)
-        kh = Kr.view(Rc, M, H, D).permute(0, 2, 1, 3)
-        vh = Vr.view(Rc, M, H, D).permute(0, 2, 1, 3)
-        if policy.env_name == "sdvrp":
-            # dynamic embedding (dynamic.py:59-78): K/V/L rows + remaining demand * projection columns.  The update is
-            # rank one, so it enters as a score bias and two outer products instead of [Rc, T, M, E] tensors
-            wk, wv, wl = dec.dynamic_embedding.projection.weight.view(3, E)
-            qw = (qh * wk.view(1, H, 1, D)).sum(-1)                                              # [Rc, H, T]
-            bias = (dem_t[:, None] * qw[..., None]) / math.sqrt(D)                               # [Rc, H, T, M]
-            bias = bias.masked_fill(~mask[:, None], float("-inf"))
-            att = torch.softmax(torch.matmul(qh, kh.transpose(-1, -2)) / math.sqrt(D) + bias, dim=-1)
-            heads = torch.matmul(att, vh) + (att * dem_t[:, None]).sum(-1, keepdim=True) * wv.view(1, H, 1, D)
-        else:
-            heads = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=mask[:, None])     # [Rc, H, T, D]
-        glimpse = F.linear(heads.permute(0, 2, 1, 3).reshape(Rc, T, E), dec.pointer.project_out.weight)
-        logits = torch.bmm(glimpse, Lr.transpose(1, 2))
-        if policy.env_name == "sdvrp":
-            logits = logits + dem_t * (glimpse @ wl)[..., None]
-        logits = logits / math.sqrt(E)
-        if clip > 0:
-            logits = torch.tanh(logits) * clip
-        logits = logits.masked_fill(~mask, float("-inf")) / temperature
-        logp = F.log_softmax(logits, dim=-1).gather(-1, act[..., None]).squeeze(-1)
-        if multistart:   # the start node is not a decision (decoding.py:318-324)
-            logp = torch.cat((torch.zeros_like(logp[:, :1]), logp[:, 1:]), 1)
-            # steps t >= 1 were evaluated with the state after the start action: column t uses prefix a_{<t} as built
-        out.append(logp)
-    return torch.cat(out, 0)
+    bounds = [(s0, min(S, s0 + starts_per_chunk)) for s0 in range(0, S, starts_per_chunk)]
+    names = list(t)
+
+    def chunk(c, *tensors):
+        s0, s1 = bounds[c]
+        return _logp_rows(env_name, dict(zip(names, tensors)), static, actions[s0 * B:s1 * B], s1 - s0, multistart, H,
+                          temperature, clip)
+
+    if checkpoint is None:      # ~6 live [rows, H, T, M] fp32 tensors per chunk if the graph is kept
+        checkpoint = len(bounds) > 1 and 24.0 * R * H * T * M > 8e9
+    if checkpoint and torch.is_grad_enabled():
+        return _ChunkedReeval.apply(chunk, len(bounds), *[t[k] for k in names])
+    return torch.cat([chunk(c, *[t[k] for k in names]) for c in range(len(bounds))], 0)
+
+
+def attach_log_likelihood_grad(policy, td, env, actions, native_logp, num_starts: int = 0, multistart=None,
+                               temperature=None, tanh_clipping=None):
+    """[R, T] per-step log-probs whose VALUE is the native rollout's `native_logp` and whose GRADIENT is the
+    re-evaluation's: native + (re - re.detach()).  This is what `AttentionModelPolicy.forward(phase="train")` returns
+    under autograd, the counterpart of the reference's graph-attached logprobs (constructive/base.py:236-263)."""
+    re = evaluate_log_likelihood(policy, td, env, actions, num_starts=num_starts, multistart=multistart,
+                                 temperature=temperature, tanh_clipping=tanh_clipping)
+    return native_logp.detach() + (re - re.detach())
 
 
 def reinforce_loss(policy, env, td, baseline: str = "shared", num_starts: int = 0, decode_type: str = None,
                    **rollout_kwargs):
-    """One REINFORCE forward: native sampled rollout (no grad) -> differentiable log-likelihood -> loss.
+    """One REINFORCE forward as the reference's trainers run it (REINFORCE.shared_step + calculate_loss,
+    reinforce.py:59-106; POMO.shared_step, pomo/model.py:89-112): `policy(td, env, phase="train")` under autograd ->
+    loss = -((reward - bl) * log_likelihood).mean().
 
     baseline: "shared" (POMO: mean over the starts of an instance, needs num_starts > 1), "mean" (batch mean) or
-    "no".  Returns dict(loss, reward, log_likelihood, actions).  loss = -((reward - bl) * ll).mean()
-    (reinforce.py:103-106)."""
+    "no".  Returns dict(loss, reward, log_likelihood, actions, ...)."""
     if decode_type is None:
         decode_type = "multistart_sampling" if num_starts > 1 else "sampling"
     kw = dict(rollout_kwargs)
     if num_starts > 1:
         kw["num_starts"] = num_starts
-    was_training = policy.training
-    policy.eval()            # the native rollout uses running statistics (see DESIGN.md 7)
-    with torch.no_grad():
-        out = policy(td, env, phase="train", decode_type=decode_type, **kw)
-    policy.train(was_training)
-    actions, reward = out["actions"], out["reward"]
+    with torch.enable_grad():
+        out = policy(td, env, phase="train", decode_type=decode_type, return_sum_log_likelihood=False, **kw)
+    actions, reward, logp = out["actions"], out["reward"], out["log_likelihood"]
     # finished CVRP rows are padded with depot visits of probability 1: their log-prob is 0 and carries no gradient
-    logp = evaluate_log_likelihood(policy, td, env, actions, num_starts=num_starts)
     ll = logp.sum(1)
     if baseline == "shared":
         assert num_starts > 1, "shared baseline needs multistart"
@@ -334,33 +420,27 @@ def reinforce_loss(policy, env, td, baseline: str = "shared", num_starts: int = 
     else:
         loss = -(reward * ll).mean()
     return {"loss": loss, "reward": reward, "log_likelihood": ll, "actions": actions, "logp_steps": logp,
-            "native_log_likelihood": out["log_likelihood"]}
+            "native_log_likelihood": ll.detach()}
 
 
 def eam_loss(policy, env, td, ea, num_starts: int, improve: bool = True, draws=None, generator=None):
     """One EAM training step of the fork with the POMO (shared) baseline (rl4co/models/zoo/earl/model.py:129-247):
 
-    1. sampled multistart rollout on the native path (no grad);
+    1. sampled multistart rollout, `policy(td, env, phase="train", num_starts=S)` (log-likelihood with grad);
     2. the sampled tours are improved by the evolutionary operators on the GPU (`evolution_worker`; the reference
        ships them to CPU threads, model.py:166-171) and get their start column back (`_align_improved_actions`);
-    3. both sets of tours are re-evaluated with autograd (`evaluate_log_likelihood`, the reference's
-       `policy(..., actions=improved)`, model.py:189-195);
+    3. the improved tours are evaluated by `policy(td, env, phase="train", actions=improved)` (model.py:189-195);
     4. REINFORCE with the per-instance mean over starts as baseline, over the concatenation [original; improved]
        treated as 2B instances (model.py:226-244, reinforce.py:103-106).
 
     Returns dict(loss, reward, improved_reward, log_likelihood, improved_log_likelihood, actions, improved_actions)."""
     from .evolution import evolution_worker
-    from .utils import batchify
 
     S = int(num_starts)
     assert S > 1, "the EAM step uses the multistart (shared) baseline"
-    was_training = policy.training
-    policy.eval()
-    with torch.no_grad():
+    with torch.enable_grad():
         out = policy(td, env, phase="train", decode_type="multistart_sampling", num_starts=S)
-    policy.train(was_training)
-    actions, reward = out["actions"], out["reward"]
-    ll = evaluate_log_likelihood(policy, td, env, actions, num_starts=S).sum(1)
+    actions, reward, ll = out["actions"], out["reward"], out["log_likelihood"]
     rs, lls = [unbatchify(reward, S)], [unbatchify(ll, S)]
     res = {"reward": reward, "log_likelihood": ll, "actions": actions}
     if improve:
@@ -368,8 +448,9 @@ def eam_loss(policy, env, td, ea, num_starts: int, improve: bool = True, draws=N
             improved, _ = evolution_worker(actions, td, ea, env, draws=draws, generator=generator)
             if improved.shape[-1] + 1 == actions.shape[-1]:          # _align_improved_actions
                 improved = torch.cat([actions[:, :1], improved], dim=-1)
-            r_imp = env.get_reward(batchify(td, S), improved)
-        ll_imp = evaluate_log_likelihood(policy, td, env, improved, num_starts=S).sum(1)
+        with torch.enable_grad():
+            out2 = policy(td, env, phase="train", actions=improved, num_starts=S, decode_type="multistart_sampling")
+        r_imp, ll_imp = out2["reward"], out2["log_likelihood"]
         rs.append(unbatchify(r_imp, S))
         lls.append(unbatchify(ll_imp, S))
         res.update(improved_actions=improved, improved_reward=r_imp, improved_log_likelihood=ll_imp)

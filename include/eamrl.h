@@ -155,6 +155,17 @@ int eamrl_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int
 int eamrl_normalize(float* x, int64_t B, int N, int E, int kind, const float* gamma, const float* beta,
                     const float* mean, const float* var, float eps, void* stream);
 
+/* Normalization(batch) with BATCH statistics, in place on x [rows][E] -- BatchNorm1d in training mode, what the
+ * reference's encoder runs under policy.train()  [nn/ops.py:45-47, SURVEY Appendix A9].  Mean and biased variance per
+ * channel in a defined order (chunks of 128 rows summed sequentially, chunk sums ascending; variance = mean of
+ * fma(d, d, .), d = x - mean), y = fma(x, gamma / sqrt(var + eps), beta - mean * scale).  save_mean / save_var [E]
+ * receive the batch statistics; running_mean / running_var (both or neither) are updated as torch does:
+ * running = (1 - momentum) * running + momentum * stat, the variance one unbiased.  ws: scratch of at least
+ * ceil(rows / 128) * E floats (ws_floats = its size). */
+int eamrl_batchnorm_train(float* x, int64_t rows, int E, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float momentum, float eps, float* save_mean, float* save_var, float* ws,
+                          int64_t ws_floats, void* stream);
+
 /* out[b][e] = (sum_n emb[b][n][e]) / M   (embeddings.mean(1), zoo/am/decoder.py:225-227) */
 int eamrl_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, void* stream);
 

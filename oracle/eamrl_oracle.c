@@ -18,6 +18,7 @@
  *   orc_mha_encoder ........... rl4co/models/nn/attention.py:66-136 (MultiHeadAttention)
  *   orc_batchnorm_eval ........ rl4co/models/nn/ops.py:32-47  (BatchNorm1d, eval mode)
  *   orc_instancenorm .......... rl4co/models/nn/ops.py:48-49  (InstanceNorm1d, affine)
+ *   orc_batchnorm_train ....... rl4co/models/nn/ops.py:45-47  (BatchNorm1d, training mode: batch statistics)
  *   orc_init_embed_* .......... rl4co/models/nn/env_embeddings/init.py:55-68,115-138
  *   orc_mean_nodes ............ rl4co/models/zoo/am/decoder.py:225-227 (embeddings.mean(1))
  *   orc_decode_step ........... rl4co/models/zoo/am/decoder.py:133-198 (_compute_q/_compute_kvl/forward),
@@ -271,6 +272,45 @@ ORC_API void orc_batchnorm_eval(float* x, long rows, int E, const float* gamma, 
         for (int e = 0; e < E; ++e) x[r * E + e] = fmaf(x[r * E + e], scale[e], shift[e]);
     free(scale);
     free(shift);
+}
+
+/* BatchNorm1d with BATCH statistics (training mode, rl4co/models/nn/ops.py:45-47): per channel, chunks of 128 rows
+ * summed sequentially, chunk sums added ascending; mean = sum / n; variance = (sum of fma(d, d, .), d = x - mean, same
+ * chunking) / n; then the eval formula with those statistics.  running_* (may be NULL) updated as torch does:
+ * running = (1 - momentum) * running + momentum * stat, the variance one unbiased (sum / (n - 1)). */
+ORC_API void orc_batchnorm_train(float* x, long rows, int E, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, float momentum, float eps, float* save_mean, float* save_var)
+{
+    const long nch = (rows + 127) / 128;
+    const float n = (float)rows;
+    for (int e = 0; e < E; ++e) {
+        float tot = 0.0f;
+        for (long c = 0; c < nch; ++c) {
+            const long r1 = (c + 1) * 128 < rows ? (c + 1) * 128 : rows;
+            float s = 0.0f;
+            for (long r = c * 128; r < r1; ++r) s = s + x[r * E + e];
+            tot = tot + s;
+        }
+        const float mean = tot / n;
+        float vt = 0.0f;
+        for (long c = 0; c < nch; ++c) {
+            const long r1 = (c + 1) * 128 < rows ? (c + 1) * 128 : rows;
+            float s = 0.0f;
+            for (long r = c * 128; r < r1; ++r) { const float d = x[r * E + e] - mean; s = fmaf(d, d, s); }
+            vt = vt + s;
+        }
+        save_mean[e] = mean;
+        save_var[e] = vt / n;
+        if (running_mean) {
+            const float keep = 1.0f - momentum;
+            const float a = keep * running_mean[e], b = momentum * mean;
+            running_mean[e] = a + b;
+            const float unb = rows > 1 ? vt / (n - 1.0f) : vt / n;
+            const float c2 = keep * running_var[e], d2 = momentum * unb;
+            running_var[e] = c2 + d2;
+        }
+    }
+    orc_batchnorm_eval(x, rows, E, gamma, beta, save_mean, save_var, eps);
 }
 
 /* InstanceNorm1d(affine) over nodes per (instance, channel): sequential sums, biased variance. */

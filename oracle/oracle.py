@@ -149,6 +149,16 @@ def batchnorm_eval(x, gamma, beta, mean, var, eps=1e-5):
     return x
 
 
+def batchnorm_train(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """-> (y, batch_mean, batch_var); running_mean / running_var (float32 arrays) are updated in place."""
+    x = _f32(x).copy()
+    E = x.shape[-1]
+    sm, sv = np.empty(E, np.float32), np.empty(E, np.float32)
+    lib().orc_batchnorm_train(_p(x), C.c_long(x.size // E), C.c_int(E), _p(_f32(gamma)), _p(_f32(beta)),
+                              _p(running_mean), _p(running_var), C.c_float(momentum), C.c_float(eps), _p(sm), _p(sv))
+    return x, sm, sv
+
+
 def instancenorm(x, gamma, beta, eps=1e-5):
     x = _f32(x).copy()
     B, N, E = x.shape
@@ -173,8 +183,9 @@ def _kind(env_name):
     return {"spctsp": "pctsp"}.get(env_name, env_name)
 
 
-def encode(sd, env_name, locs, demand=None, num_heads=8):
-    """-> (init_embeds, embeddings).  locs: TSP [B,N,2]; CVRP [B,N+1,2] with depot first.
+def encode(sd, env_name, locs, demand=None, num_heads=8, training=False):
+    """-> (init_embeds, embeddings).  training=True: BatchNorm layers use batch statistics and update the running
+    statistics inside `sd` in place (policy.train(), nn/ops.py:45-47).  locs: TSP [B,N,2]; CVRP [B,N+1,2] with depot first.
     PCTSP: `demand` is the dict of instance tensors (expected_prize [B,N], real_prize / penalty [B,N+1], prize_required);
     node features = (x, y, expected prize, penalty)  [nn/env_embeddings/init.py:227-257]."""
     pre = "encoder.init_embedding."
@@ -202,15 +213,20 @@ def encode(sd, env_name, locs, demand=None, num_heads=8):
         qkv = linear(h, sd[p + "0.module.Wqkv.weight"], sd[p + "0.module.Wqkv.bias"])
         att = mha_encoder(qkv, num_heads)
         h = h + linear(att, sd[p + "0.module.out_proj.weight"], sd[p + "0.module.out_proj.bias"])
-        h = _norm(sd, p + "1.normalizer.", h)
+        h = _norm(sd, p + "1.normalizer.", h, training)
         f = linear(h, sd[p + "2.module.lins.0.weight"], sd[p + "2.module.lins.0.bias"], relu=True)
         h = h + linear(f, sd[p + "2.module.lins.1.weight"], sd[p + "2.module.lins.1.bias"])
-        h = _norm(sd, p + "3.normalizer.", h)
+        h = _norm(sd, p + "3.normalizer.", h, training)
         layer += 1
     return init_h, h
 
 
-def _norm(sd, p, h):
+def _norm(sd, p, h, training=False):
+    if p + "running_mean" in sd and training:
+        rm, rv = (np.ascontiguousarray(sd[p + k], dtype=np.float32) for k in ("running_mean", "running_var"))
+        y, _, _ = batchnorm_train(h, sd[p + "weight"], sd[p + "bias"], rm, rv)
+        sd[p + "running_mean"], sd[p + "running_var"] = rm, rv
+        return y
     if p + "running_mean" in sd:
         return batchnorm_eval(h, sd[p + "weight"], sd[p + "bias"], sd[p + "running_mean"], sd[p + "running_var"])
     return instancenorm(h, sd[p + "weight"], sd[p + "bias"])
@@ -470,14 +486,15 @@ def check_cvrp(actions, demand, vcap):
 
 
 def policy_rollout(sd, env_name, locs, demand=None, decode_type="greedy", num_starts=0, noise=None, given=None,
-                   use_graph_context=True, clip=10.0, temp=1.0, num_heads=8, top_k=0, top_p=0.0, start_nodes=None):
+                   use_graph_context=True, clip=10.0, temp=1.0, num_heads=8, top_k=0, top_p=0.0, start_nodes=None,
+                   training=False):
     """ConstructivePolicy.forward restated on the oracle: encoder, cache, (multistart hook), loop, reward.
 
     locs for CVRP already include the depot at index 0 (post-reset layout).
     Returns dict(actions, logp_steps, log_likelihood, reward, steps).
     """
     env_name = _kind(env_name)
-    _, emb = encode(sd, env_name, locs, demand, num_heads)
+    _, emb = encode(sd, env_name, locs, demand, num_heads, training=training)
     cache = precompute(sd, env_name, emb, use_graph_context)
     multistart = "multistart" in decode_type and num_starts > 1
     st = State(env_name, locs, demand, num_starts=num_starts if multistart else 0)

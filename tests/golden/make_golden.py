@@ -3,7 +3,7 @@
 
 Run only in the build container (the reference never travels to the GPU box):
 
-    python tests/golden/make_golden.py [extra | beam | filtering | sdvrp | pctsp | op | cvrptw]
+    python tests/golden/make_golden.py [extra | beam | filtering | sdvrp | pctsp | op | cvrptw | train | eval]
 
 (no argument: the first batch, TSP / CVRP / POMO; `extra`: larger graphs and decoding options; `beam`: beam search;
 `filtering`: top-k / top-p; `sdvrp`, `pctsp` (incl. SPCTSP), `op`, `cvrptw`: the sibling envs and their state_dict
@@ -377,8 +377,82 @@ def filtering():
     run_case("tsp100_greedy_topk", "tsp", 100, 2, "greedy", keep_steps=first4, data_seed=44, decode_kw=dict(top_k=3))
 
 
+def run_train_case(name, env_name, num_loc, batch, policy_kw=None, num_starts=None, baseline="shared", data_seed=1234,
+                   sample_seed=4321):
+    """One training forward + backward of the reference policy in train() mode (BatchNorm: batch statistics), as
+    REINFORCE.shared_step / POMO.shared_step run it: out = policy(td, env, phase="train"[, num_starts]);
+    loss = -((reward - baseline) * log_likelihood).mean()  [rl/reinforce/reinforce.py:59-106, zoo/pomo/model.py:89-112,
+    rl/reinforce/baselines.py:45-61: NoBaseline -> 0, SharedBaseline -> reward.mean(1)].  The trainer classes themselves
+    need Lightning (absent), so those four lines are applied here to the reference policy's own outputs.  Stored: the
+    recorded sampling noise, actions, reward, per-step log-probs, loss, the gradient of every parameter (norm; full
+    tensors for the small ones) and the BatchNorm running statistics after the forward."""
+    from rl4co.utils.ops import unbatchify as ref_unbatchify
+
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv}[env_name]
+    env = Env(generator_params=gen_params(env_name, num_loc), seed=data_seed)
+    torch.manual_seed(data_seed)
+    td_init = env.reset(batch_size=[batch])
+    policy = make_policy(env_name, **(policy_kw or {})).train()
+    kw = {} if num_starts is None else dict(num_starts=num_starts)
+    decode_type = "sampling" if num_starts is None else "multistart_sampling"
+    torch.manual_seed(sample_seed)
+    with Recorder(policy) as rec:
+        out = policy(td_init.clone(), env, phase="train", decode_type=decode_type, return_sum_log_likelihood=False,
+                     return_hidden=True, **kw)
+    logp = out["log_likelihood"]
+    ll, reward = logp.sum(1), out["reward"]
+    if baseline == "shared":
+        r = ref_unbatchify(reward, num_starts)
+        l2 = ref_unbatchify(ll, num_starts)
+        loss = -((r - r.mean(dim=1, keepdims=True)) * l2).mean()
+    elif baseline == "no":
+        loss = -(reward * ll).mean()
+    else:
+        raise ValueError(baseline)
+    loss.backward()
+    fx = {
+        "torch_version": np.array(torch.__version__), "env_name": np.array(env_name),
+        "decode_type": np.array(decode_type), "baseline": np.array(baseline),
+        "num_starts": np.array(0 if num_starts is None else num_starts, dtype=np.int64),
+        "locs": np_(td_init["locs"]), "actions": np_(out["actions"]), "reward": np_(reward), "logp_steps": np_(logp),
+        "loss": np_(loss), "noise": np.stack([np_(q) for q in rec.noise], 1),
+        "embeddings": np_(out["hidden"].node_embeddings),
+    }
+    if env_name == "cvrp":
+        fx["demand"] = np_(td_init["demand"])
+    for k, v in (policy_kw or {}).items():
+        fx["policy_kw_" + k] = np.array(v)
+    names, norms = [], []
+    for k, prm in policy.named_parameters():
+        g = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+        names.append(k)
+        norms.append(float(g.double().norm()))
+        if g.numel() <= 512:
+            fx["grad__" + k] = np_(g)
+    fx["grad_names"] = np.array(names)
+    fx["grad_norms"] = np.array(norms, dtype=np.float64)
+    for k, b in policy.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            fx["buf__" + k] = np_(b)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"{name}: loss={float(loss):.6f} |grad|={np.sqrt((fx['grad_norms'] ** 2).sum()):.6f} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def train():
+    """Ninth batch (python make_golden.py train): training forward / backward of the reference policy."""
+    pomo = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False)
+    run_train_case("train_pomo_tsp20", "tsp", 20, 4, policy_kw=pomo, num_starts=20, baseline="shared")
+    run_train_case("train_am_tsp20_bn", "tsp", 20, 8, baseline="no", data_seed=11)
+    run_train_case("train_am_cvrp20_bn", "cvrp", 20, 8, baseline="no", data_seed=12)
+    run_train_case("train_am_tsp20_bn_multistart", "tsp", 20, 4, num_starts=10, baseline="shared", data_seed=13)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "cvrptw":
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        train()
+    elif len(sys.argv) > 1 and sys.argv[1] == "cvrptw":
         cvrptw()
     elif len(sys.argv) > 1 and sys.argv[1] == "op":
         op()

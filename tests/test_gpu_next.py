@@ -275,6 +275,7 @@ def test_reinforce_step_pomo_and_flat_allreduce():
         out = reinforce_loss(pol, env, td.clone(), baseline="shared", num_starts=20)
         np.testing.assert_allclose(out["log_likelihood"].detach().cpu().numpy(),
                                    out["native_log_likelihood"].cpu().numpy(), rtol=0, atol=2e-3)
+        assert out["log_likelihood"].requires_grad
         opt.zero_grad()
         out["loss"].backward()
         n = allreduce_gradients(pol)          # single process: identity, exercises the flat-buffer path
@@ -533,7 +534,8 @@ def test_eam_training_step(env_name, cfg, N):
     env.check_solution_validity(ea.batchify(td, S), imp)
     if env_name == "tsp":
         assert (res["improved_reward"] >= res["reward"] - 1e-6).all() and (res["improved_reward"] > res["reward"] + 1e-6).any()
-    native = pol(td.clone(), env, phase="train", num_starts=S, actions=imp)      # policy(..., actions=improved)
+    with torch.no_grad():
+        native = pol(td.clone(), env, phase="train", num_starts=S, actions=imp)      # policy(..., actions=improved)
     assert torch.equal(native["reward"], res["improved_reward"])
     np.testing.assert_allclose(native["log_likelihood"].cpu().numpy(), res["improved_log_likelihood"].detach().cpu().numpy(),
                                rtol=1e-4, atol=1e-4)

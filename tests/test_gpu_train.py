@@ -1,0 +1,190 @@
+"""GPU: the training-side boundary.
+
+`AttentionModelPolicy.forward(phase="train")` under autograd returns a `log_likelihood` with a grad_fn, so the
+reference's trainers run on it unchanged.  The tests restate `REINFORCE.calculate_loss`
+(rl4co/models/rl/reinforce/reinforce.py:79-106) and `POMO.shared_step` (rl4co/models/zoo/pomo/model.py:89-112) line
+for line around the policy call, backpropagate, and compare with gradients recorded from the reference itself
+(`tests/golden/make_golden.py train`: the reference policy in train() mode, sampling with recorded noise).
+"""
+import numpy as np
+import pytest
+import torch
+
+from _util import cfg_for, golden, golden_weights, instance_of
+from test_gpu_parity import DEV, assert_bits_equal, make_policy, make_td, t
+
+pytestmark = pytest.mark.gpu
+
+TRAIN_CASES = ["train_pomo_tsp20", "train_am_tsp20_bn", "train_am_cvrp20_bn", "train_am_tsp20_bn_multistart"]
+
+
+class NoBaseline:
+    """rl4co/models/rl/reinforce/baselines.py:45-49"""
+
+    def eval(self, td, reward, env=None):
+        return 0, 0
+
+
+class SharedBaseline:
+    """rl4co/models/rl/reinforce/baselines.py:52-61"""
+
+    def eval(self, td, reward, env=None, on_dim=1):
+        return reward.mean(dim=on_dim, keepdims=True), 0
+
+
+def calculate_loss(baseline, td, env, policy_out, reward=None, log_likelihood=None):
+    """REINFORCE.calculate_loss, reinforce.py:79-106 (no `extra`, advantage scaler = identity)."""
+    reward = reward if reward is not None else policy_out["reward"]
+    log_likelihood = log_likelihood if log_likelihood is not None else policy_out["log_likelihood"]
+    bl_val, bl_loss = baseline.eval(td, reward, env)
+    advantage = reward - bl_val
+    reinforce_loss = -(advantage * log_likelihood).mean()
+    loss = reinforce_loss + bl_loss
+    policy_out.update({"loss": loss, "reinforce_loss": reinforce_loss, "bl_loss": bl_loss, "bl_val": bl_val})
+    return policy_out
+
+
+def _train_policy(fx):
+    pol = make_policy(cfg_for(fx)).train()
+    return pol
+
+
+def _shared_step(fx, pol, env, td):
+    """REINFORCE.shared_step (reinforce.py:59-71) / POMO.shared_step (pomo/model.py:89-112), training phase."""
+    import eam_rl4co_amd as ea
+
+    ns = int(fx["num_starts"])
+    noise = t(fx["noise"])
+    if ns > 1:      # POMO.shared_step
+        out = pol(td, env, phase="train", num_starts=ns, decode_type="multistart_sampling", noise=noise)
+        reward = ea.unbatchify(out["reward"], (0, ns))
+        log_likelihood = ea.unbatchify(out["log_likelihood"], (0, ns))
+        calculate_loss(SharedBaseline(), td, env, out, reward, log_likelihood)
+    else:           # REINFORCE.shared_step with the "no" baseline
+        out = pol(td, env, phase="train", select_best=False, decode_type="sampling", noise=noise)
+        calculate_loss(NoBaseline(), td, env, out)
+    return out
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_reference_trainer_step_runs_on_the_policy_and_matches_reference_gradients(oracle, name):
+    fx = golden(name)
+    env_name = str(fx["env_name"])
+    pol = _train_policy(fx)
+    env, td = make_td(env_name, fx["locs"], instance_of(fx))
+    out = _shared_step(fx, pol, env, td)
+    # forward: the native rollout in train() mode (batch statistics) reproduces the reference's sampled tours ...
+    assert_bits_equal(out["actions"], fx["actions"], "actions")
+    np.testing.assert_allclose(out["reward"].cpu().numpy(), fx["reward"], rtol=1e-6)
+    ll = out["log_likelihood"]
+    assert ll.requires_grad and ll.grad_fn is not None
+    np.testing.assert_allclose(ll.detach().cpu().numpy(), fx["logp_steps"].sum(1), rtol=2e-5, atol=2e-5)
+    # ... and is bit-equal to the oracle in the same mode (the value of the differentiable log-likelihood IS the native one)
+    sd = golden_weights(cfg_for(fx))
+    o = oracle.policy_rollout(sd, env_name, fx["locs"], instance_of(fx), decode_type=str(fx["decode_type"]),
+                              num_starts=int(fx["num_starts"]), noise=fx["noise"],
+                              use_graph_context=bool(fx.get("policy_kw_use_graph_context", True)), training=True)
+    assert_bits_equal(ll.detach(), o["log_likelihood"], "log_likelihood (native value)")
+    for k in fx:     # running statistics after the forward: bit-equal to the oracle, 1e-6 from the reference
+        if k.startswith("buf__"):
+            buf = dict(pol.named_buffers())[k[5:]]
+            assert_bits_equal(buf, sd[k[5:]], k)
+            np.testing.assert_allclose(buf.cpu().numpy(), fx[k], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(float(out["loss"].detach()), float(fx["loss"]), rtol=2e-5)
+    # backward: gradient of every parameter against the reference's
+    out["loss"].backward()
+    params = dict(pol.named_parameters())
+    total_ref = float(np.sqrt((fx["grad_norms"] ** 2).sum()))
+    for k, ref_norm in zip(fx["grad_names"], fx["grad_norms"]):
+        g = params[str(k)].grad
+        got = 0.0 if g is None else float(g.double().norm())
+        assert abs(got - ref_norm) <= 1e-4 * max(ref_norm, 1e-3 * total_ref) + 1e-7, (str(k), got, ref_norm)
+        if "grad__" + str(k) in fx and g is not None:
+            ref = fx["grad__" + str(k)]
+            np.testing.assert_allclose(g.cpu().numpy(), ref, rtol=0, atol=1e-4 * max(float(np.abs(ref).max()), 1e-3 * total_ref),
+                                       err_msg=str(k))
+
+
+@pytest.mark.parametrize("cfg,env_name,ns", [("am_tsp", "tsp", 0), ("am_cvrp", "cvrp", 0), ("am_cvrp", "cvrp", 5),
+                                              ("pomo_tsp", "tsp", 8)])
+def test_differentiated_policy_is_the_sampled_policy(cfg, env_name, ns):
+    """ADVICE r1 (train.py:319): in train() mode the re-evaluated log-likelihood equals the native rollout's (same
+    normalisation statistics in both passes), for batch-norm (am_*) and instance-norm policies."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd.train import evaluate_log_likelihood
+
+    env = ea.get_env(env_name, generator_params=dict(num_loc=20), seed=7)
+    torch.manual_seed(7)
+    td = env.reset(batch_size=[16]).to(DEV)
+    pol = make_policy(cfg).train()
+    kw = dict(num_starts=ns) if ns else {}
+    with torch.no_grad():
+        out = pol(td, env, phase="train", return_sum_log_likelihood=False, **kw)
+    assert not out["log_likelihood"].requires_grad
+    re = evaluate_log_likelihood(pol, td, env, out["actions"], num_starts=ns)
+    np.testing.assert_allclose(re.detach().cpu().numpy(), out["log_likelihood"].cpu().numpy(), rtol=0, atol=1e-4)
+    # and eval() mode (running statistics) is a different network for a BatchNorm policy
+    if cfg.startswith("am"):
+        re_eval = evaluate_log_likelihood(pol.eval(), td, env, out["actions"], num_starts=ns)
+        assert (re_eval - re).abs().max() > 1e-3
+
+
+def test_forward_is_not_differentiated_outside_training():
+    import eam_rl4co_amd as ea
+
+    env = ea.get_env("tsp", generator_params=dict(num_loc=10), seed=1)
+    td = env.reset(batch_size=[4]).to(DEV)
+    pol = make_policy("am_tsp").train()
+    assert not pol(td, env, phase="val", decode_type="greedy")["log_likelihood"].requires_grad
+    with torch.no_grad():
+        assert not pol(td, env, phase="train")["log_likelihood"].requires_grad
+    with torch.inference_mode():
+        assert not pol(td, env, phase="train")["log_likelihood"].requires_grad
+    out = pol(td, env, phase="train")
+    assert out["log_likelihood"].requires_grad and out["log_likelihood"].shape == (4,)
+    out2 = pol(td, env, phase="train", actions=out["actions"])       # teacher forcing (EAM, earl/model.py:189-195)
+    assert out2["log_likelihood"].requires_grad
+    assert torch.equal(out2["reward"], out["reward"])
+    with pytest.raises(NotImplementedError):
+        pol(td, env, phase="train", num_starts=4, select_best=True)
+
+
+def test_checkpointed_reevaluation_gives_the_same_gradients():
+    """The chunked, recompute-in-backward form (bounded memory at POMO scale) == the plain autograd graph."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd.train import evaluate_log_likelihood
+
+    env = ea.get_env("cvrp", generator_params=dict(num_loc=15), seed=2)
+    torch.manual_seed(2)
+    td = env.reset(batch_size=[6]).to(DEV)
+    pol = make_policy("am_cvrp").train()
+    with torch.no_grad():
+        out = pol(td, env, phase="train", num_starts=9, return_sum_log_likelihood=False)
+    w = torch.randn(out["actions"].shape[0], device=DEV)
+    grads = []
+    for ck in (False, True):
+        pol.zero_grad()
+        lp = evaluate_log_likelihood(pol, td, env, out["actions"], num_starts=9, chunk_rows=12, checkpoint=ck)
+        (lp.sum(1) * w).sum().backward()
+        grads.append({k: p.grad.clone() for k, p in pol.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 20
+    top = max(float(g.abs().max()) for g in grads[0].values())
+    for k in grads[0]:      # (rounding noise is relative to the largest gradients: e.g. key biases have a zero true gradient)
+        scale = max(float(grads[0][k].abs().max()), 1e-2 * top)
+        assert float((grads[0][k] - grads[1][k]).abs().max()) <= 1e-4 * scale, k
+
+
+def test_batchnorm_train_kernel_bit_exact(oracle):
+    from eam_rl4co_amd import ops
+
+    rng = np.random.default_rng(3)
+    for rows, E in ((1, 128), (127, 128), (128, 128), (129, 64), (5000, 128), (2100, 96)):
+        x = (rng.standard_normal((rows, E)) * 2 + 0.5).astype(np.float32)
+        g, b = rng.standard_normal(E).astype(np.float32), rng.standard_normal(E).astype(np.float32)
+        rm, rv = rng.standard_normal(E).astype(np.float32), (rng.random(E) + 0.5).astype(np.float32)
+        orm, orv = rm.copy(), rv.copy()
+        y, m, v = oracle.batchnorm_train(x, g, b, orm, orv, momentum=0.1, eps=1e-5)
+        xt, rmt, rvt = t(x), t(rm), t(rv)
+        _, mt, vt = ops.batchnorm_train_(xt, t(g), t(b), rmt, rvt, 0.1, 1e-5)
+        for got, want, what in ((xt, y, "y"), (mt, m, "mean"), (vt, v, "var"), (rmt, orm, "running_mean"), (rvt, orv, "running_var")):
+            assert_bits_equal(got, want, f"{what} rows={rows} E={E}")

@@ -341,3 +341,49 @@ def test_beam_search_matches_reference(oracle, name):
     assert np.array_equal(out["actions"], fx["actions"]), "beam-search tours differ from the reference"
     np.testing.assert_allclose(out["reward"], fx["reward"], rtol=1e-6, atol=0)
     np.testing.assert_allclose(out["logp_steps"], fx["logp_steps"], rtol=0, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# training mode: BatchNorm with batch statistics (policy.train(), nn/ops.py:45-47) -- `make_golden.py train`
+# ---------------------------------------------------------------------------------------------------------
+TRAIN_CASES = ["train_pomo_tsp20", "train_am_tsp20_bn", "train_am_cvrp20_bn", "train_am_tsp20_bn_multistart"]
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_train_mode_forward_matches_reference(oracle, name):
+    """The reference policy in train() mode (sampling with recorded noise): same tours, log-probs within 1e-5,
+    embeddings within 1e-5, running statistics after the forward within 1e-6."""
+    fx = golden(name)
+    sd = golden_weights(cfg_for(fx))
+    ns = int(fx["num_starts"])
+    out = oracle.policy_rollout(sd, str(fx["env_name"]), fx["locs"], instance_of(fx), decode_type=str(fx["decode_type"]),
+                                num_starts=ns, noise=fx["noise"],
+                                use_graph_context=bool(fx.get("policy_kw_use_graph_context", True)), training=True)
+    assert np.array_equal(out["actions"], fx["actions"]), "tours differ from the reference"
+    np.testing.assert_allclose(out["reward"], fx["reward"], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(out["logp_steps"], fx["logp_steps"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["embeddings"], fx["embeddings"], rtol=0, atol=1e-5)
+    nbuf = 0
+    for k in fx:
+        if k.startswith("buf__"):
+            np.testing.assert_allclose(sd[k[5:]], fx[k], rtol=0, atol=1e-6, err_msg=k)
+            nbuf += 1
+    assert nbuf == (0 if name.startswith("train_pomo") else 12)     # 3 layers x 2 norms x (mean, var)
+
+
+def test_batchnorm_train_is_the_defined_order(oracle):
+    """orc_batchnorm_train against a float64 evaluation and torch's batch_norm (values; its own order is the contract)."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1000, 24)).astype(np.float32) * 3 + 1
+    g, b = rng.standard_normal(24).astype(np.float32), rng.standard_normal(24).astype(np.float32)
+    rm, rv = np.zeros(24, np.float32), np.ones(24, np.float32)
+    y, m, v = oracle.batchnorm_train(x, g, b, rm, rv)
+    trm, trv = torch.zeros(24), torch.ones(24)
+    ty = torch.nn.functional.batch_norm(torch.from_numpy(x), trm, trv, torch.from_numpy(g), torch.from_numpy(b), True, 0.1, 1e-5)
+    np.testing.assert_allclose(y, ty.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(m, x.astype(np.float64).mean(0), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(v, x.astype(np.float64).var(0), rtol=2e-6, atol=0)
+    np.testing.assert_allclose(rm, trm.numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rv, trv.numpy(), rtol=2e-6, atol=0)
