@@ -1,26 +1,40 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/s of the AttentionModel construction rollout on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tsp100|cvrp100|tsp20|cvrp500|pomo100|sdvrp100|pctsp100|op100|cvrptw100] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W] [--batch B] [--strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one full rollout of one batch: encoder + decoder cache + the whole decode loop (state update,
-mask, masked single-query attention, selection) + tour-length reward, inputs already resident in HBM
-(env.reset / instance generation excluded).  Default workload = BASELINE.json configs[1]:
-TSP num_loc=100, batch=1024, greedy.  Metric: env-steps/s = ranks * batch * num_loc * K / wall time.
-Multi-GPU: independent instance batches per rank (weak scaling), no data-path collective.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: the parent process (which never
+touches the GPU) runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child and exits with its
+code; rank 0 of the child prints the one JSON line with n_gpus == N.
+
+Rollout workloads (tsp100 = BASELINE.json configs[1] is the default): one "step" = one full rollout of one batch --
+encoder + decoder cache + the whole decode loop (state update, mask, masked single-query attention, selection) +
+tour-length reward, inputs already resident in HBM (env.reset / instance generation excluded).
+Training workload (pomo100_train = configs[3], per-GPU share 1024 instances x 100 starts): one step = sampled multistart
+rollout -> teacher-forced re-evaluation + backward -> ONE flat RCCL all-reduce -> clip 1.0 -> Adam
+(eam_rl4co_amd.train.PolicyGradientStep, the reference's POMO.shared_step + trainer).
+Metric: env-steps/s = ranks * batch * starts * num_loc * K / wall time (max over ranks, barrier on both sides).
+Multi-GPU: independent instance batches per rank, no data-path collective ("weak": the batch is per GPU; `--strong`: the
+workload's batch is the GLOBAL batch, split over the ranks).  A weak run on N > 1 ranks also times the strong split of
+the same global batch and reports it under "strong_scaling".
 
 Besides the contract keys the JSON line carries
-  roofline      the decode-loop kernel (the dominant hot-loop kernel): algorithmic bytes per launch
-                (154,852 B per TSP-100 decode step) / its mean duration measured with HIP events
-  cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/) timed on this host's cores on a
-                bounded sample of the same workload
+  roofline         the launch family with the largest share of the step (today the encoder / cache GEMMs on fp32 MFMA):
+                   algorithmic flops per step / its time measured with HIP events on the launch stream, against the
+                   dense fp32 MFMA peak
+  roofline_decode  the decode-loop kernel against the bound it actually sits on: per-ROLLOUT bytes for
+                   the register-resident kernel, per-step bytes for the streaming one, plus the step-API view
+  cpu_baseline     the CPU oracle (a port of the reference's algorithm, oracle/) timed on this host's cores on a
+                   bounded sample of the same workload
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,21 +43,23 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 WORKLOADS = {
-    # name: (env, num_loc, default batch, decode type)
-    "tsp100": ("tsp", 100, 1024, "greedy"),        # BASELINE.json configs[1]  (headline)
-    "tsp20": ("tsp", 20, 128, "greedy"),           # configs[0]
-    "cvrp100": ("cvrp", 100, 1024, "sampling"),    # configs[2]
-    "cvrp500": ("cvrp", 500, 512, "greedy"),       # configs[4]
-    "sdvrp100": ("sdvrp", 100, 1024, "greedy"),    # sibling env: split deliveries, dynamic embedding
-    "pctsp100": ("pctsp", 100, 1024, "greedy"),    # sibling env: prize collecting
-    "cvrptw100": ("cvrptw", 100, 1024, "greedy"),  # sibling env: CVRP with time windows
-    "op100": ("op", 100, 1024, "greedy"),          # sibling env: orienteering (distance-dependent mask)
+    # name: (env, num_loc, default batch per GPU, decode type, kind)
+    "tsp100": ("tsp", 100, 1024, "greedy", "rollout"),        # BASELINE.json configs[1]  (headline)
+    "tsp20": ("tsp", 20, 128, "greedy", "rollout"),           # configs[0]
+    "cvrp100": ("cvrp", 100, 1024, "sampling", "rollout"),    # configs[2]
+    "cvrp500": ("cvrp", 500, 512, "greedy", "rollout"),       # configs[4]
+    "sdvrp100": ("sdvrp", 100, 1024, "greedy", "rollout"),    # sibling env: split deliveries, dynamic embedding
+    "pctsp100": ("pctsp", 100, 1024, "greedy", "rollout"),    # sibling env: prize collecting
+    "cvrptw100": ("cvrptw", 100, 1024, "greedy", "rollout"),  # sibling env: CVRP with time windows
+    "op100": ("op", 100, 1024, "greedy", "rollout"),          # sibling env: orienteering (distance-dependent mask)
     # configs[3], per-GPU share: POMO policy (6 layers, instance norm, no graph context), num_starts = num_loc
-    "pomo100": ("tsp", 100, 1024, "multistart_sampling"),
+    "pomo100": ("tsp", 100, 1024, "multistart_sampling", "rollout"),
+    "pomo100_train": ("tsp", 100, 1024, "multistart_sampling", "train"),   # configs[3]: the whole REINFORCE step
+    "pomo20_train": ("tsp", 20, 64, "multistart_sampling", "train"),       # small rehearsal of the same step
+    # no GPU work at all: the launcher, the rendezvous and the collective half of the training step (flat all-reduce ->
+    # clip -> Adam on synthetic per-rank gradients) -- what the CPU (gloo) tests drive
+    "dist_selftest": ("tsp", 20, 4, "multistart_sampling", "selftest"),
 }
 POMO_KW = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
@@ -56,7 +72,7 @@ def algorithmic_flops_per_query_step(M, E=128):
 
 
 def algorithmic_bytes_per_decode_step(env, M, E=128, S=1):
-    """12*M*E (K,V,L) + 4*E*g (context rows) + 2*M (mask r/w) + c; multistart (per
+    """SURVEY.md 8(d), step-at-a-time API: 12*M*E (K,V,L) + 4*E*g (context rows) + 2*M (mask r/w) + c; multistart (per
     instance-step, S queries sharing K/V/L): 12*M*E + S*(8*E + 2*M + 28)."""
     if S > 1:
         return 12 * M * E + S * (8 * E + 2 * M + 28)
@@ -67,19 +83,33 @@ def algorithmic_bytes_per_decode_step(env, M, E=128, S=1):
     return 12 * M * E + 4 * E * 1 + 2 * M + 32 + 2 * M
 
 
+def resident_bytes_per_rollout(env, M, T, E=128, S=1, sampling=False):
+    """Bytes the register-resident decode kernel must move per INSTANCE and rollout: K, V, Lp once
+    (12*M*E), the context rows Pa (, Pb) once (4*M*E*g), and per row the state (mask / visited bytes in, final state out),
+    the outputs (action i64 + log-prob f32 per step) and, for sampling, the Exp(1) noise (4*M per step)."""
+    g = 2 if env == "tsp" else 1
+    per_row = 2 * M + 64 + T * 12 + (4 * M * T if sampling else 0)
+    return 12 * M * E + 4 * M * E * g + max(S, 1) * per_row
+
+
 def measured_traffic(workload, batch):
-    """HBM bytes per decode-loop launch from the committed PMC passes (profiles/r01_traffic.json): rocprofv3
-    counters cannot be collected from inside the timed run, so `traffic` is the separately profiled value for
-    exactly this workload, or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            t = json.load(f)
-        return t.get(f"{workload}_b{batch}", {}).get("traffic_bytes")
-    except (OSError, ValueError):
-        return None
+    """HBM bytes per decode-loop launch from the committed PMC passes (profiles/r0N_traffic.json): rocprofv3 counters
+    cannot be collected from inside the timed run, so `traffic` is the separately profiled value for exactly this
+    workload, or None."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f).get(f"{workload}_b{batch}", {}).get("traffic_bytes")
+            if t is not None:
+                return t
+        except (OSError, ValueError):
+            pass
+    return None
 
 
 def build_policy(env_name, device, pomo=False):
+    import torch
+
     import eam_rl4co_amd as ea
     from _util import golden_weights
 
@@ -93,9 +123,11 @@ def build_policy(env_name, device, pomo=False):
 
 def cpu_baseline(env_name, num_loc, decode_type, num_starts=0, pomo=False, seconds_budget=20.0):
     """Time the CPU oracle on a bounded sample (batch chosen so the run takes ~10-30 s)."""
+    import torch
+
+    import eam_rl4co_amd as ea
     from _util import golden_weights
     from oracle import oracle as orc
-    import eam_rl4co_amd as ea
 
     threads = orc.set_threads(min(orc.usable_cpus(), 64))   # the box's CPU share, not its core count
     sd = golden_weights(("pomo_" if pomo else "am_") + env_name)
@@ -132,6 +164,97 @@ def cpu_baseline(env_name, num_loc, decode_type, num_starts=0, pomo=False, secon
                       f"{t:.2f} s on {threads} OpenMP threads (oracle/eamrl_oracle.c)"}
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """Parent of a `--gpus N` run: start the N ranks as a child `torch.distributed.run` and mirror its exit code.
+    Nothing here initialises the GPU (no torch.cuda call, no HIP library loaded), and nothing is exec'ed."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class FamilyTimer:
+    """HIP events (torch.cuda.Event on the launch stream = torch's current stream, which is the stream the C ABI gets)
+    around the calls of one launch family, in eager passes before the timed region."""
+
+    def __init__(self, torch):
+        self.torch, self.ev, self.flops = torch, {}, {}
+
+    def wrap(self, fam, fn, flops_of=None):
+        def wrapper(*a, **k):
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            self.ev.setdefault(fam, []).append((e0, e1))
+            if flops_of is not None:
+                self.flops[fam] = self.flops.get(fam, 0.0) + flops_of(a, r)
+            return r
+        return wrapper
+
+    def clear(self):
+        self.ev.clear(); self.flops.clear()
+
+    def ms(self, fam, passes):
+        return sum(a.elapsed_time(b) for a, b in self.ev.get(fam, [])) / passes
+
+    def launches(self, fam, passes):
+        return len(self.ev.get(fam, [])) // passes
+
+
+def params_checksum(policy, torch):
+    """Order-independent bit checksum of all parameters (int64 sum of the fp32 bit patterns)."""
+    tot = torch.zeros((), dtype=torch.int64, device=next(policy.parameters()).device)
+    for p in policy.parameters():
+        tot += p.detach().view(torch.int32).to(torch.int64).sum()
+    return tot
+
+
+def run_selftest(args, torch, dist, rank, world):
+    """No GPU: N ranks over gloo run the collective half of the training step on synthetic per-rank gradients."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd.dist import FlatGradBuffer
+
+    torch.manual_seed(0)
+    pol = ea.AttentionModelPolicy(env_name="tsp", **POMO_KW)
+    buf = FlatGradBuffer(pol)
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-4, weight_decay=1e-6)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for it in range(args.warmup + args.steps):
+        buf.zero_()
+        g = torch.Generator().manual_seed(1000 * rank + it)          # every rank its own gradients
+        loss = sum((p * torch.randn(p.shape, generator=g)).sum() for p in pol.parameters())
+        loss.backward()
+        assert buf.attached()
+        buf.allreduce(average=True)
+        buf.clip_(1.0)
+        opt.step()
+    elapsed = time.perf_counter() - t0
+    cs = params_checksum(pol, torch)
+    lo, hi = cs.clone(), cs.clone()
+    if world > 1:
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "dist_selftest (no GPU work)", "value": round(args.steps / elapsed, 2), "unit": "steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / max(args.steps + args.warmup, 1) * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "flat gradient all-reduce -> clip 1.0 -> Adam on synthetic gradients (POMO policy, "
+                                                 f"{buf.flat.numel()} parameters)", "backend": dist.get_backend() if world > 1 else None},
+                          "params_identical": bool(lo.item() == hi.item()), "params_checksum": int(cs.item())}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,18 +269,32 @@ def main():
                          "the batch is per GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    backend = os.environ.get("EAMRL_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm; gloo only for rehearsals
+    env_name, num_loc, batch, decode_type, kind = WORKLOADS[args.workload]
+    backend = os.environ.get("EAMRL_DIST_BACKEND", "gloo" if kind == "selftest" else "nccl")   # "nccl" is RCCL on ROCm
     if os.environ.get("EAMRL_BENCH_SINGLE_DEVICE") == "1":      # rehearse N ranks on a 1-GPU box (with gloo)
         local_rank = 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if kind == "selftest":
+        if world > 1:
+            dist.init_process_group(backend)
+        run_selftest(args, torch, dist, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -170,8 +307,8 @@ def main():
         from eam_rl4co_amd import _lib
         _lib.load().eamrl_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
 
-    env_name, num_loc, batch, decode_type = WORKLOADS[args.workload]
     batch = args.batch or batch
+    global_batch = batch if args.strong else batch * world
     if args.strong:
         if batch % world:
             raise SystemExit(f"--strong: global batch {batch} is not divisible by {world} ranks")
@@ -184,113 +321,170 @@ def main():
     M = td0["locs"].shape[1]
     S = num_loc if "multistart" in decode_type else 1
     dkw = dict(num_starts=S) if S > 1 else {}
+    train = kind == "train"
+    stepper = None
+    if train:
+        from eam_rl4co_amd.train import PolicyGradientStep
 
-    # time the decode-loop kernel with HIP events on the launch stream (torch's current stream)
-    kernel_ms, decode_steps = [], []
-    orig_rollout = ops.rollout
+        policy.train()
+        stepper = PolicyGradientStep(policy, env, num_starts=S)       # Adam(1e-4, wd 1e-6), clip 1.0, shared baseline
 
-    def timed_rollout(*a, **k):
+    def make_step(td, graph=True):
+        if train:
+            return lambda: stepper(td)
+        g = None if (args.no_graph or not graph) else ea.GraphedRollout(policy, env, td, decode_type=decode_type, **dkw)
+        if g is not None:
+            return lambda: g(td)                      # copy inputs into the captured buffers + one graph replay
+        return lambda: policy(td.clone(), env, phase="test", decode_type=decode_type, **dkw)
+
+    one_step = make_step(td0)
+
+    # per launch family: HIP events around the calls on the launch stream, in eager passes before the timed region
+    ft = FamilyTimer(torch)
+    orig = {n: getattr(ops, n) for n in ("rollout", "linear", "matmul_right", "mha_encoder")}
+    ops.rollout = ft.wrap("decode", orig["rollout"])
+    ops.linear = ft.wrap("gemm", orig["linear"], lambda a, r: 2.0 * a[0].numel() * r.shape[-1])
+    ops.matmul_right = ft.wrap("gemm", orig["matmul_right"], lambda a, r: 2.0 * a[0].numel() * r.shape[-1])
+    ops.mha_encoder = ft.wrap("attention", orig["mha_encoder"],
+                              lambda a, r: 4.0 * r.shape[0] * r.shape[1] * r.shape[1] * r.shape[2])
+    n_pass, skip = (3, 1) if train else (5, 2)
+    rollout_ms = []
+    for i in range(n_pass):
+        if i == skip:
+            ft.clear()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        r = orig_rollout(*a, **k)
+        with torch.no_grad():
+            policy(td0.clone(), env, phase="train" if train else "test", decode_type=decode_type, **dkw)
         e1.record()
-        kernel_ms.append((e0, e1))
-        return r
-
-    graphed = None if args.no_graph else ea.GraphedRollout(policy, env, td0, decode_type=decode_type, **dkw)
-
-    def one_step():
-        if graphed is not None:
-            return graphed(td0)                      # copy inputs into the captured buffers + one graph replay
-        return policy(td0.clone(), env, phase="test", decode_type=decode_type, **dkw)
-
-    # duration of the decode-loop launch, and of all nn.Linear launches (the encoder / cache GEMMs): HIP events around
-    # them on the launch stream, in eager passes before the timed region
-    gemm_ev, gemm_flops = [], []
-    orig_linear, orig_mmr = ops.linear, ops.matmul_right
-
-    def timed(fn, flops_of):
-        def wrapper(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = fn(*a, **k)
-            e1.record()
-            gemm_ev.append((e0, e1))
-            gemm_flops.append(flops_of(a, r))
-            return r
-        return wrapper
-
-    ops.rollout = timed_rollout
-    ops.linear = timed(orig_linear, lambda a, r: 2.0 * a[0].numel() * r.shape[-1])
-    ops.matmul_right = timed(orig_mmr, lambda a, r: 2.0 * a[0].numel() * r.shape[-1])
-    n_pass = 5
-    for i in range(n_pass):
-        if i == 2:
-            gemm_ev.clear(); gemm_flops.clear()
-        policy(td0.clone(), env, phase="test", decode_type=decode_type, **dkw)
+        rollout_ms.append((e0, e1))
     torch.cuda.synchronize()
-    ops.rollout, ops.linear, ops.matmul_right = orig_rollout, orig_linear, orig_mmr
-    kernel_ms = kernel_ms[2:]
-    gemm_ms_per_rollout = sum(a.elapsed_time(b) for a, b in gemm_ev) / (n_pass - 2)
-    gemm_tflops = sum(gemm_flops) / (n_pass - 2) / (gemm_ms_per_rollout * 1e-3) / 1e12 if gemm_ev else 0.0
-    for _ in range(args.warmup):
-        out = one_step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_step()
-        decode_steps.append(out["actions"].shape[1])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:      # the slowest rank defines the step time
-        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    for n, f in orig.items():
+        setattr(ops, n, f)
+    passes = n_pass - skip
+    rollout_only_ms = float(np.mean([a.elapsed_time(b) for a, b in rollout_ms[skip:]]))
+    fam_ms = {f: ft.ms(f, passes) for f in ("gemm", "attention", "decode")}
+
+    def timed(step_fn, steps, warmup):
+        out = None
+        for _ in range(warmup):
+            out = step_fn()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nsteps = []
+        for _ in range(steps):
+            out = step_fn()
+            nsteps.append(out["actions"].shape[1])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:      # the slowest rank defines the step time
+            tt = torch.tensor([el], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, out, nsteps
+
+    elapsed, out, decode_steps = timed(one_step, args.steps, args.warmup)
+
+    strong = None
+    if world > 1 and not args.strong and not train and batch % world == 0:
+        # the same GLOBAL batch as the 1-GPU run, split over the ranks (north_star: strong scaling)
+        td_s = td0[: batch // world]
+        el_s, _, _ = timed(make_step(td_s), args.steps, max(1, args.warmup))
+        strong = {"global_batch": batch, "batch_per_gpu": batch // world, "ms_per_step": round(el_s / args.steps * 1e3, 4),
+                  "value": round(batch * S * num_loc * args.steps / el_s, 1), "unit": "env-steps/s"}
+
+    identical = None
+    if train:
+        cs = params_checksum(policy, torch)
+        lo, hi = cs.clone(), cs.clone()
+        if world > 1:
+            if backend != "nccl":
+                lo, hi = lo.cpu(), hi.cpu()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        identical = bool(lo.item() == hi.item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * batch * S * num_loc * args.steps / elapsed
-        kern = float(np.mean([a.elapsed_time(b) for a, b in kernel_ms]))
-        T = float(np.mean(decode_steps))
-        alg_bytes = algorithmic_bytes_per_decode_step(env_name, M, S=S) * batch * T
-        achieved = alg_bytes / (kern * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, batch),
-                    "kernel": "decode loop (eamrl_am_rollout)", "kernel_ms": round(kern, 4),
-                    "algorithmic_bytes_per_launch": int(alg_bytes)}
-        if S > 1:
-            # S queries share one K/V/L tile: 63 flop/B, beyond the fp32 ridge -> priced against the fp32 peak
-            # (SURVEY.md 8d); the HBM view is kept next to it
+        kern = fam_ms["decode"]
+        T = float(np.mean(decode_steps)) - (1 if S > 1 else 0)
+        # ---- decode loop: the bound it sits on ----------------------------------------------------------------
+        step_api_bytes = algorithmic_bytes_per_decode_step(env_name, M, S=S) * batch * T
+        step_api = {"achieved_GBs": round(step_api_bytes / (kern * 1e-3) / 1e9, 1),
+                    "frac_of_hbm_peak": round(step_api_bytes / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "step-at-a-time API bytes (SURVEY 8d: K, V, L re-read every step); > 1 means the kernel does not "
+                            "re-read them"}
+        traffic = measured_traffic(args.workload.replace("_train", ""), batch)
+        if M <= 128:
+            rb = resident_bytes_per_rollout(env_name, M, T, S=S, sampling="sampling" in decode_type) * batch
             flops = algorithmic_flops_per_query_step(M) * batch * S * T
             tf = flops / (kern * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / F32_PEAK_TFLOPS, 4), "traffic": None,
-                        "kernel": "decode loop (eamrl_am_rollout), fp32 VALU: one workgroup per row, starts of an "
-                                  "instance looped on register-resident K/V/L",
-                        "kernel_ms": round(kern, 4), "algorithmic_flops_per_launch": int(flops),
-                        "hbm_view": {"achieved_GBs": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4)}}
+            roofline_decode = {
+                "kernel": "k_rollout_resident (decode loop, K/V/Lp read once per rollout into VGPRs)",
+                "bound": "hbm", "achieved": round(rb / (kern * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(rb / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(rb), "kernel_ms": round(kern, 4),
+                "issue_bound": {"bound": "fp32 valu issue", "achieved": round(tf, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(tf / F32_PEAK_TFLOPS, 4),
+                                "note": "the kernel is instruction-issue / latency bound, not HBM bound (DESIGN.md 4): useful "
+                                        "flops 6*M*E + 6*E*E per row-step against the fp32 peak"},
+                "step_api_view": step_api}
+        else:
+            ach = (traffic or step_api_bytes) / (kern * 1e-3) / 1e9
+            roofline_decode = {
+                "kernel": "k_rollout_stream (decode loop, K/V/Lp re-read every step; masked rows skipped)",
+                "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel_ms": round(kern, 4),
+                "basis": "measured HBM traffic (PMC)" if traffic else "algorithmic bytes (no PMC pass for this workload)",
+                "algorithmic_bytes_per_launch": int(step_api_bytes), "step_api_view": step_api}
+        # ---- the family with the largest share of the step ------------------------------------------------------
+        gemm_tf = ft.flops.get("gemm", 0.0) / passes / (fam_ms["gemm"] * 1e-3) / 1e12 if fam_ms["gemm"] else 0.0
+        att_tf = ft.flops.get("attention", 0.0) / passes / (fam_ms["attention"] * 1e-3) / 1e12 if fam_ms["attention"] else 0.0
+        roofline_gemm = {"kernel": "k_linear_mfma (encoder + cache nn.Linear launches, v_mfma_f32_32x32x2_f32)",
+                         "bound": "mfma", "achieved": round(gemm_tf, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(gemm_tf / F32_PEAK_TFLOPS, 4), "traffic": None,
+                         "ms_per_step": round(fam_ms["gemm"], 4), "launches_per_step": ft.launches("gemm", passes),
+                         "algorithmic_flops_per_step": int(ft.flops.get("gemm", 0.0) / passes)}
+        roofline_att = {"kernel": "k_mha_encoder (encoder self-attention)", "bound": "mfma", "achieved": round(att_tf, 2),
+                        "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(att_tf / F32_PEAK_TFLOPS, 4),
+                        "ms_per_step": round(fam_ms["attention"], 4), "launches_per_step": ft.launches("attention", passes)}
+        dominant = max(fam_ms, key=lambda f: fam_ms[f])
+        roofline = dict(roofline_gemm if dominant == "gemm" else
+                        roofline_decode["issue_bound"] | {"kernel": roofline_decode["kernel"], "kernel_ms": round(kern, 4)}
+                        if (dominant == "decode" and M <= 128) else roofline_decode if dominant == "decode" else roofline_att)
+        roofline["share_of_step"] = {f: round(v / rollout_only_ms, 3) for f, v in fam_ms.items()}
+        roofline["dominant_family"] = dominant
+        cfg = {"workload": f"{env_name.upper()} num_loc={num_loc} batch={batch}/GPU "
+                           + (f"x {S} starts POMO" if pomo else "AM") + f" {decode_type} "
+                           + ("REINFORCE training step (rollout + re-evaluation + backward + flat all-reduce + clip + Adam)"
+                              if train else "rollout (encoder + cache + decode loop + reward)"),
+               "decode_steps": T, "reward_mean": round(float(out["reward"].mean()), 4),
+               "global_batch": global_batch,
+               "launch": "eager" if (args.no_graph or train) else "hipGraph replay"}
+        if train:
+            cfg["rollout_ms"] = round(rollout_only_ms, 3)
+            cfg["gradient_side_ms"] = round(ms_per_step - rollout_only_ms, 3)
         line = {
             "metric": "env-steps/sec (batch x num_loc / s), AttentionModel construction rollout",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{env_name.upper()} num_loc={num_loc} batch={batch}/GPU "
-                                   + (f"x {S} starts POMO" if pomo else "AM") + f" {decode_type} rollout "
-                                   f"(encoder + cache + decode loop + reward)",
-                       "decode_steps": T, "reward_mean": round(float(out["reward"].mean()), 4),
-                       "launch": "eager" if args.no_graph else "hipGraph replay"},
-            "roofline": roofline,
-            # the launches that take the largest share of the step time: the one-shot encoder / cache Linears on fp32 MFMA
-            "roofline_gemm": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(gemm_tflops / F32_PEAK_TFLOPS, 4), "kernel": "encoder + cache nn.Linear launches",
-                              "ms_per_step": round(gemm_ms_per_rollout, 4), "launches_per_step": len(gemm_ev) // (n_pass - 2)},
+            "config": cfg, "roofline": roofline, "roofline_decode": roofline_decode, "roofline_gemm": roofline_gemm,
+            "roofline_attention": roofline_att,
         }
+        if strong is not None:
+            line["strong_scaling"] = strong
+        if identical is not None:
+            line["params_identical"] = identical
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(env_name, num_loc, decode_type, num_starts=S if S > 1 else 0, pomo=pomo)
+            if train:
+                line["cpu_baseline"]["sample"] += " -- rollout part only (the oracle has no backward)"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -25,6 +25,9 @@ def init_distributed(backend: str | None = None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
         dist.init_process_group(backend, **kw)
+    if torch.cuda.is_available() and torch.cuda.device_count() > local_rank:
+        # one process per GPU: tensors created on "cuda" and the library's launches go to this rank's device
+        torch.cuda.set_device(local_rank)
     return rank, world, local_rank
 
 
@@ -62,31 +65,89 @@ def gather_rows(x: torch.Tensor, total: int | None = None):
     return torch.cat([o[:s] for o, s in zip(out, sizes)], 0)
 
 
+class FlatGradBuffer:
+    """All gradients of a module in ONE pre-allocated flat fp32 buffer; every `p.grad` is a view into it.
+
+    The reference gets its collective from DDP(gradient_as_bucket_view=True) (rl4co/utils/trainer.py:72-89); here the
+    whole policy (<= 5.2 MB for POMO) is one bucket, so a training step has exactly one all-reduce and no copy kernels
+    around it: autograd accumulates into the views in place, `allreduce` reduces the buffer, `clip_` scales it, the
+    optimizer reads the views.  Parameters that receive no gradient keep their zeros (DDP with
+    find_unused_parameters=True behaves the same).  Use `zero_()` instead of `optimizer.zero_grad()` (which would
+    drop the views with set_to_none=True)."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradBuffer: the module has no trainable parameters")
+        dev = self.params[0].device
+        if any(p.dtype != torch.float32 or p.device != dev for p in self.params):
+            raise TypeError("FlatGradBuffer: fp32 parameters on one device required")
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def attached(self) -> bool:
+        """True while every p.grad still is its view (e.g. optimizer.zero_grad(set_to_none=True) detaches them)."""
+        off = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
+                return False
+            off += p.numel()
+        return True
+
+    @torch.no_grad()
+    def zero_(self):
+        self.flat.zero_()
+
+    @torch.no_grad()
+    def allreduce(self, average: bool = True) -> int:
+        """One collective over the whole buffer; returns the number of elements reduced."""
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if average:
+                self.flat.div_(dist.get_world_size())
+        return self.flat.numel()
+
+    @torch.no_grad()
+    def clip_(self, max_norm: float) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_ on the buffer (global 2-norm AFTER the reduce, as DDP + Lightning's
+        gradient_clip_val do, rl4co/utils/trainer.py:55): returns the norm before clipping."""
+        total = torch.linalg.vector_norm(self.flat)
+        self.flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+        return total
+
+
 @torch.no_grad()
 def allreduce_gradients(module: torch.nn.Module, average: bool = True):
-    """Sum (mean) gradients across ranks with one flat all-reduce; returns the number of elements reduced."""
+    """Sum (mean) gradients across ranks with one flat all-reduce; returns the number of elements reduced.
+    With a `FlatGradBuffer` attached to the module (`module._flat_grads`) this is the buffer's zero-copy all-reduce;
+    otherwise the gradients are packed into a temporary flat buffer and copied back."""
+    buf = getattr(module, "_flat_grads", None)
+    if isinstance(buf, FlatGradBuffer) and buf.attached():
+        return buf.allreduce(average)
     params = [p for p in module.parameters() if p.requires_grad]
     if not params:
         return 0
     dev = params[0].device
     flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=torch.float32)
-    off = 0
+    views, off = [], 0
     for p in params:
-        if p.grad is not None:
-            flat[off:off + p.numel()] = p.grad.reshape(-1).to(torch.float32)
+        views.append(flat[off:off + p.numel()].view_as(p))
         off += p.numel()
+    have = [(v, p.grad) for v, p in zip(views, params) if p.grad is not None]
+    if have:
+        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         if average:
             flat /= dist.get_world_size()
-    off = 0
-    for p in params:
-        g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
+    for v, p in zip(views, params):
         if p.grad is None:
-            p.grad = g.clone()
+            p.grad = v.clone()
         else:
-            p.grad.copy_(g)
-        off += p.numel()
+            p.grad.copy_(v)
     return flat.numel()
 
 
@@ -96,7 +157,7 @@ def allreduce_scalars(values: dict, average: bool = True) -> dict:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return dict(values)
     keys = sorted(values)
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([float(values[k]) for k in keys], dtype=torch.float64, device=dev)
     dist.all_reduce(t)
     if average:

@@ -458,3 +458,38 @@ def eam_loss(policy, env, td, ea, num_starts: int, improve: bool = True, draws=N
     adv = r_all - r_all.mean(1, keepdim=True)
     res["loss"] = -(adv * ll_all).mean()
     return res
+
+
+class PolicyGradientStep:
+    """One optimizer step of the reference's REINFORCE / POMO training, data-parallel (BASELINE.json configs[3]):
+
+        out = policy(td, env, phase="train"[, num_starts=S])            # POMO.shared_step, pomo/model.py:89-112
+        loss = -((reward - baseline) * log_likelihood).mean()            # reinforce.py:103-106, baselines.py:57-61
+        loss.backward() -> ONE flat all-reduce (mean over ranks) -> clip_grad_norm 1.0 -> Adam(lr 1e-4, wd 1e-6)
+                                                                         # utils/trainer.py:55,72-89; configs/experiment/routing/pomo.yaml
+
+    Each rank owns its own instances (all starts of an instance on one GPU); the gradient buffer is the only thing
+    exchanged (dist.FlatGradBuffer: p.grad are views, no copy kernels around the collective).  Every rank ends the step
+    with bit-identical parameters: the reduced buffer is identical on all ranks and the update is deterministic."""
+
+    def __init__(self, policy, env, num_starts: int = 0, baseline: str = None, lr: float = 1e-4, weight_decay: float = 1e-6,
+                 max_grad_norm: float = 1.0, optimizer=None):
+        from .dist import FlatGradBuffer
+
+        self.policy, self.env, self.S = policy, env, int(num_starts)
+        self.baseline = baseline or ("shared" if self.S > 1 else "mean")
+        self.max_grad_norm = max_grad_norm
+        self.grads = FlatGradBuffer(policy)
+        policy._flat_grads = self.grads
+        self.optimizer = optimizer or torch.optim.Adam(policy.parameters(), lr=lr, weight_decay=weight_decay)
+
+    def __call__(self, td, **rollout_kwargs) -> dict:
+        self.grads.zero_()
+        out = reinforce_loss(self.policy, self.env, td, baseline=self.baseline, num_starts=self.S, **rollout_kwargs)
+        out["loss"].backward()
+        if not self.grads.attached():
+            raise RuntimeError("PolicyGradientStep: p.grad is no longer a view of the flat buffer (zero_grad(set_to_none)?)")
+        self.grads.allreduce(average=True)
+        out["grad_norm"] = self.grads.clip_(self.max_grad_norm) if self.max_grad_norm else None
+        self.optimizer.step()
+        return out

@@ -70,3 +70,76 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _flat_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import dist as ed
+
+    ed.init_distributed("gloo")
+    torch.manual_seed(0)                                   # same initial weights on both ranks
+    pol = ea.AttentionModelPolicy(env_name="cvrp", num_encoder_layers=2)
+    buf = ed.FlatGradBuffer(pol)
+    pol._flat_grads = buf
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-3)
+    ptrs = [p.grad.data_ptr() for p in pol.parameters()]
+    for it in range(3):
+        buf.zero_()
+        g = torch.Generator().manual_seed(100 * rank + it)
+        loss = sum((p * torch.randn(p.shape, generator=g)).sum() for i, p in enumerate(pol.parameters()) if i % 4 != 3)
+        loss.backward()                                    # autograd accumulates INTO the views
+        assert buf.attached() and [p.grad.data_ptr() for p in pol.parameters()] == ptrs
+        n = ed.allreduce_gradients(pol)                    # dispatches to the buffer: one collective, no copies
+        assert n == buf.flat.numel()
+        norm = buf.clip_(1.0)
+        assert float(torch.linalg.vector_norm(buf.flat)) <= 1.0 + 1e-5 < float(norm)
+        opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1]), "ranks hold different parameters after the training steps"
+    for i, p in enumerate(pol.parameters()):               # every fourth parameter never had a gradient: zeros, unchanged
+        if i % 4 == 3:
+            assert float(p.grad.abs().max()) == 0.0
+    dist.barrier()
+    dist.destroy_process_group()
+    out.put(rank)
+
+
+def test_flat_grad_buffer_two_ranks_end_with_identical_parameters():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    assert sorted(out.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE): the parent spawns two ranks before touching any GPU;
+    rank 0 prints ONE JSON line with n_gpus == 2.  The selftest workload runs the collective half of the training step
+    (flat all-reduce -> clip -> Adam) over gloo and reports whether both ranks ended with identical parameters."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "dist_selftest",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["params_identical"] is True
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "dist_selftest", "--steps", "2",
+                             "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    one = json.loads([l for l in single.stdout.splitlines() if l.startswith("{")][0])
+    assert one["n_gpus"] == 1 and one["params_checksum"] != line["params_checksum"]    # two ranks averaged different gradients
