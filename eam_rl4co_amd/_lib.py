@@ -53,6 +53,7 @@ PROTOTYPES = {
     "eamrl_mha_encoder": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "eamrl_normalize": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp],
     "eamrl_batchnorm_train": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i64, _vp],
+    "eamrl_pointer_attention": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     "eamrl_mean_nodes": [_vp, _vp, _i64, _i32, _i32, _vp],
     "eamrl_am_decode_step": [_i32, C.POINTER(Cache), C.POINTER(State), _i64, _i32, _vp, _vp, _f32, _f32, _i32, _f32, _i32,
                              _vp, _vp, _vp, _vp, _vp, _vp],

@@ -240,6 +240,19 @@ __attribute__((visibility("default"))) int eamrl_batchnorm_train(float* x, int64
                                            save_var, ws, (hipStream_t)stream), "eamrl_batchnorm_train");
 }
 
+__attribute__((visibility("default"))) int eamrl_pointer_attention(const float* query, const float* key, const float* value,
+                                                                  const float* logit_key, int64_t ld, const uint8_t* mask,
+                                                                  int mask_per_query, const float* Wout, const float* bout,
+                                                                  float* logits, int64_t B, int L, int M, int E, int H,
+                                                                  int mask_inner, void* stream)
+{
+    REQUIRE(query && key && value && logit_key && Wout && logits, "eamrl_pointer_attention");
+    REQUIRE(B >= 0 && L > 0 && M > 0 && E > 0 && H > 0 && E % H == 0 && E / H <= 32 && ld >= E, "eamrl_pointer_attention");
+    REQUIRE((3 * (int64_t)E + (int64_t)H * M) * 4 <= 64 * 1024, "eamrl_pointer_attention");
+    return launched(launch_pointer_attention(query, key, value, logit_key, ld, mask, mask_per_query, Wout, bout, logits, B, L, M,
+                                             E, H, mask_inner, (hipStream_t)stream), "eamrl_pointer_attention");
+}
+
 __attribute__((visibility("default"))) int eamrl_mean_nodes(const float* emb, float* out, int64_t B, int M, int E,
                                                            void* stream)
 {

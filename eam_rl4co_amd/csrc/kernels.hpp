@@ -29,6 +29,9 @@ int launch_normalize(float* x, int64_t B, int N, int E, int kind, const float* g
 int launch_batchnorm_train(float* x, int64_t rows, int E, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float momentum, float eps, float* save_mean, float* save_var, float* ws,
                            hipStream_t st);
+int launch_pointer_attention(const float* q, const float* K, const float* V, const float* Lk, int64_t ld, const uint8_t* mask,
+                             int mask_per_query, const float* Wout, const float* bout, float* logits, int64_t B, int L, int M,
+                             int E, int H, int mask_inner, hipStream_t st);
 int launch_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, hipStream_t st);
 int launch_tsp_step(uint8_t* mask, int64_t* first, int64_t* cur, int64_t* istep, const int64_t* action,
                     uint8_t* done, int64_t R, int N, hipStream_t st);

@@ -173,6 +173,38 @@ def mean_nodes(emb):
     return out
 
 
+def pointer_attention(query, key, value, logit_key, attn_mask, Wout, bout=None, num_heads=8, mask_inner=True):
+    """PointerAttention.forward (nn/attention.py:282-306) in one launch.  query [B, L, E] (or [B, E]); key / value /
+    logit_key [B, M, E] (views with a common row stride are fine, e.g. the chunks of one projection);
+    attn_mask [B, M] or [B, L, M] bool (True = feasible) or None.  -> logits [B, L, M] ([B, M] when L == 1, as the
+    reference's `.squeeze(-2)` gives)."""
+    lib = _lib.load()
+    if query.dim() == 2:
+        query = query[:, None, :]
+    _chk(query, "query", torch.float32)
+    B, L, E = query.shape
+    M = key.shape[-2]
+    ld = key.stride(-2)
+    for nm, t in (("key", key), ("value", value), ("logit_key", logit_key)):
+        _need_gpu(t, nm)
+        if (t.dtype != torch.float32 or t.dim() != 3 or tuple(t.shape) != (B, M, E) or t.stride(-1) != 1 or t.stride(-2) != ld
+                or t.stride(0) != M * ld):
+            raise ValueError(f"pointer_attention: {nm} must be fp32 [B, M, E] with unit inner stride and a common row stride")
+    _chk(Wout, "project_out.weight", torch.float32, (E, E))
+    if bout is not None:
+        _chk(bout, "project_out.bias", torch.float32, (E,))
+    per_query = 0
+    if attn_mask is not None:
+        per_query = int(attn_mask.dim() == 3)
+        _chk(attn_mask, "attn_mask", torch.bool, (B, L, M) if per_query else (B, M))
+    out = torch.empty(B, L, M, device=query.device, dtype=torch.float32)
+    _lib.check(lib.eamrl_pointer_attention(_ptr(query), _ptr(key), _ptr(value), _ptr(logit_key), ld,
+                                           _ptr(None if attn_mask is None else _bytes(attn_mask)), per_query, _ptr(Wout),
+                                           _ptr(bout), _ptr(out), B, L, M, E, int(num_heads), int(bool(mask_inner)),
+                                           _stream(query)), "eamrl_pointer_attention")
+    return out.squeeze(-2) if L == 1 else out
+
+
 # ------------------------------------------------------------------------------------------------------
 # environment transitions
 # ------------------------------------------------------------------------------------------------------

@@ -273,16 +273,24 @@ class AttentionModelDecoder(nn.Module):
                  check_nan=True, sdpa_fn=None, pointer=None, moe_kwargs=None):
         super().__init__()
         env_name = _kind(env_name)
-        if any(x is not None for x in (context_embedding, dynamic_embedding, sdpa_fn, pointer, moe_kwargs)) or linear_bias:
-            raise NotImplementedError("custom context/dynamic embeddings, pointer, sdpa_fn, MoE and decoder biases are "
-                                      "outside the MI355X rollout path (TSP / CVRP / SDVRP AttentionModel only)")
+        from .attention import PointerAttention
+
+        if pointer is not None and not (isinstance(pointer, PointerAttention) and pointer.project_out.bias is None
+                                        and pointer.mask_inner and pointer.num_heads == num_heads):
+            raise NotImplementedError("pointer=: only eam_rl4co_amd.PointerAttention (mask_inner, no output bias, the decoder's "
+                                      "head count) can replace the built-in pointer; its project_out is what the fused "
+                                      "kernels fold into the logit key")
+        if any(x is not None for x in (context_embedding, dynamic_embedding, sdpa_fn, moe_kwargs)) or linear_bias:
+            raise NotImplementedError("custom context/dynamic embeddings, sdpa_fn, MoE and decoder biases are "
+                                      "outside the MI355X rollout path (the routing AttentionModel family only)")
         assert embed_dim % num_heads == 0
         self.env_name, self.embed_dim, self.num_heads = env_name, embed_dim, num_heads
         ctx_dim = {"tsp": 2 * embed_dim, "cvrptw": embed_dim + 2}.get(env_name, embed_dim + 1)   # node(s) + state columns
         self.context_embedding = _ContextParams(embed_dim, ctx_dim, placeholder=(env_name == "tsp"))
         self.dynamic_embedding = SDVRPDynamicEmbedding(embed_dim) if env_name == "sdvrp" else StaticEmbedding()
         self.is_dynamic_embedding = env_name == "sdvrp"
-        self.pointer = _PointerParams(embed_dim, num_heads, mask_inner, out_bias_pointer_attn, check_nan)
+        self.pointer = pointer if pointer is not None else _PointerParams(embed_dim, num_heads, mask_inner,
+                                                                          out_bias_pointer_attn, check_nan)
         self.project_node_embeddings = nn.Linear(embed_dim, 3 * embed_dim, bias=False)
         self.project_fixed_context = nn.Linear(embed_dim, embed_dim, bias=False)
         self.use_graph_context = use_graph_context
@@ -342,10 +350,21 @@ class AttentionModelDecoder(nn.Module):
                 Wb = None
                 # state columns: capacity (CVRP-like), prize / length left (PCTSP / OP); CVRPTW: capacity | time -> [2E]
                 cvec = Wctx[:, E:].t().reshape(-1).contiguous() if self.env_name == "cvrptw" else Wctx[:, E].contiguous()
-            self._wc, self._wc_key = (Wa.detach(), None if Wb is None else Wb.detach(), cvec.detach()), key
             # slot-major cache: K | V | L | Pa (| Pb) are adjacent slots, so one GEMM with the stacked weights writes them all
             # (each output element is the same k-ordered chain as with separate launches)
-            self._w_cache = torch.cat([Wkvl.detach(), Wa.detach()] + ([Wb.detach()] if Wb is not None else []), 0).contiguous()
+            w_cache = torch.cat([Wkvl.detach(), Wa.detach()] + ([Wb.detach()] if Wb is not None else []), 0).contiguous()
+            new = (Wa.detach(), None if Wb is None else Wb.detach(), cvec.detach())
+            old = getattr(self, "_wc", None)
+            if old is not None and all((a is None) == (b is None) and (a is None or (a.shape == b.shape and a.device == b.device))
+                                       for a, b in zip(old, new)) and self._w_cache.shape == w_cache.shape:
+                # refresh IN PLACE: a captured HIP graph (GraphedRollout) holds pointers to these buffers
+                for a, b in zip(old, new):
+                    if a is not None:
+                        a.copy_(b)
+                self._w_cache.copy_(w_cache)
+            else:
+                self._wc, self._w_cache = new, w_cache
+            self._wc_key = key
         return self._wc
 
     def pre_decoder_hook(self, td, env, embeddings, num_starts: int = 0):
@@ -600,6 +619,7 @@ class AttentionModelPolicy(nn.Module):
         multisample = decoding_kwargs.pop("multisample", False)
         select_best = decoding_kwargs.pop("select_best", False)
         select_start_nodes_fn = decoding_kwargs.pop("select_start_nodes_fn", None)
+        decoding_kwargs.pop("softmax_temp", None)       # passed by SamplingEval; the reference's strategy ignores it too
         noise = decoding_kwargs.pop("noise", None)      # [R, T, M] Exp(1) draws replacing torch.multinomial's
         top_k = int(decoding_kwargs.pop("top_k", 0) or 0)          # process_logits filtering (decoding.py:170-176)
         top_p = float(decoding_kwargs.pop("top_p", 0.0) or 0.0)
@@ -945,6 +965,7 @@ class GraphedRollout:
                        return_init_embeds=False, return_sum_log_likelihood=True, actions=None, max_steps=1_000_000)
         self.kw.update(forward_kwargs)
         self.static_td = td_example.clone()
+        self._training = policy.training
         self._keys = [k for k, v in self.static_td.items() if isinstance(v, torch.Tensor)]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -958,6 +979,11 @@ class GraphedRollout:
 
     @torch.no_grad()
     def __call__(self, td) -> dict:
+        if self.policy.training != self._training:
+            raise RuntimeError("GraphedRollout: policy.train() / .eval() changed since capture (different launches)")
+        # weight-derived constants live in persistent buffers that the graph reads: refresh them in place when a
+        # parameter changed (optimizer step, load_state_dict); everything else the graph reads are the live parameters
+        self.policy.decoder._weight_constants()
         for k in self._keys:
             src = td[k]
             dst = self.static_td[k]

@@ -169,6 +169,17 @@ int eamrl_batchnorm_train(float* x, int64_t rows, int E, const float* gamma, con
 /* out[b][e] = (sum_n emb[b][n][e]) / M   (embeddings.mean(1), zoo/am/decoder.py:225-227) */
 int eamrl_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, void* stream);
 
+/* PointerAttention.forward in one launch -- the module the reference's decoder accepts through its constructor
+ * injection point `AttentionModelDecoder(pointer=...)`  [zoo/am/decoder.py:82,109-124; nn/attention.py:282-328]:
+ * logits[b][l][n] = (project_out(MHA(query, key, value, mask))[b][l] . logit_key[b][n]) / sqrt(E).
+ * query [B][L][E]; key / value / logit_key [B][M][.] with row stride ld (>= E); mask (may be NULL) [B][M] bytes, or
+ * [B][L][M] when mask_per_query, non-zero = may attend (applied when mask_inner); Wout [E][E] = project_out.weight
+ * (y = x W^T), bout [E] or NULL; logits [B][L][M] (masked nodes keep their finite raw logit, as in the reference;
+ * a row with no feasible node yields NaN, which the reference's check_nan assert reports). */
+int eamrl_pointer_attention(const float* query, const float* key, const float* value, const float* logit_key, int64_t ld,
+                            const uint8_t* mask, int mask_per_query, const float* Wout, const float* bout, float* logits,
+                            int64_t B, int L, int M, int E, int H, int mask_inner, void* stream);
+
 /* ---- per-step decode ------------------------------------------------------------------------------ */
 
 /* The decoder cache of one batch (AttentionModelDecoder._precompute_cache, zoo/am/decoder.py:206-235),

@@ -20,6 +20,7 @@
  *   orc_instancenorm .......... rl4co/models/nn/ops.py:48-49  (InstanceNorm1d, affine)
  *   orc_batchnorm_train ....... rl4co/models/nn/ops.py:45-47  (BatchNorm1d, training mode: batch statistics)
  *   orc_init_embed_* .......... rl4co/models/nn/env_embeddings/init.py:55-68,115-138
+ *   orc_pointer_attention ..... rl4co/models/nn/attention.py:282-328 (PointerAttention.forward; the pointer= injection point)
  *   orc_mean_nodes ............ rl4co/models/zoo/am/decoder.py:225-227 (embeddings.mean(1))
  *   orc_decode_step ........... rl4co/models/zoo/am/decoder.py:133-198 (_compute_q/_compute_kvl/forward),
  *                               rl4co/models/nn/env_embeddings/context.py:50-74,105-157,
@@ -247,6 +248,63 @@ ORC_API void orc_mha_encoder(const float* qkv, float* out, long B, int N, int E,
                 }
             }
         free(s);
+    }
+}
+
+/* PointerAttention.forward (rl4co/models/nn/attention.py:282-328) in the order of k_pointer_attention (csrc/pointer.hip):
+ * per head, lane l of a 64-wide wavefront owns the nodes l, l+64, ...; its partial sums are combined by the lane tree. */
+ORC_API void orc_pointer_attention(const float* q, const float* K, const float* V, const float* Lk, const uint8_t* mask,
+                                   int mask_per_query, const float* Wout, const float* bout, float* logits, long B, int L,
+                                   int M, int E, int H, int mask_inner)
+{
+    const int D = E / H;
+    const float scale = 1.0f / sqrtf((float)D);
+#pragma omp parallel for schedule(static)
+    for (long row = 0; row < B * L; ++row) {
+        const long b = row / L;
+        const float* qr = q + row * E;
+        const uint8_t* mr = mask ? mask + (mask_per_query ? row : b) * (long)M : NULL;
+        float* s = (float*)malloc(sizeof(float) * M);
+        float* heads = (float*)malloc(sizeof(float) * E);
+        float* gl = (float*)malloc(sizeof(float) * E);
+        for (int h = 0; h < H; ++h) {
+            float m = -INFINITY;
+            for (int n = 0; n < M; ++n) {
+                const float* kr = K + (b * M + n) * (long)E + h * D;
+                float acc = 0.0f;
+                for (int d = 0; d < D; ++d) acc = fmaf(qr[h * D + d], kr[d], acc);
+                acc = acc * scale;
+                if (mask_inner && mr && !mr[n]) acc = -INFINITY;
+                s[n] = acc;
+                if (acc > m) m = acc;
+            }
+            float z[64], a[64];
+            for (int l = 0; l < 64; ++l) {
+                z[l] = 0.0f;
+                for (int n = l; n < M; n += 64) { s[n] = (s[n] == -INFINITY) ? 0.0f : d_expf(s[n] - m); z[l] = z[l] + s[n]; }
+            }
+            const float Z = lane_tree(z, 64);
+            for (int d = 0; d < D; ++d) {
+                for (int l = 0; l < 64; ++l) {
+                    a[l] = 0.0f;
+                    for (int n = l; n < M; n += 64) a[l] = fmaf(s[n], V[(b * M + n) * (long)E + h * D + d], a[l]);
+                }
+                heads[h * D + d] = lane_tree(a, 64) / Z;
+            }
+        }
+        for (int o = 0; o < E; ++o) {
+            float acc = bout ? bout[o] : 0.0f;
+            for (int i = 0; i < E; ++i) acc = fmaf(heads[i], Wout[(long)o * E + i], acc);
+            gl[o] = acc;
+        }
+        const float inv = sqrtf((float)E);
+        for (int n = 0; n < M; ++n) {
+            const float* lr = Lk + (b * M + n) * (long)E;
+            float acc = 0.0f;
+            for (int o = 0; o < E; ++o) acc = fmaf(gl[o], lr[o], acc);
+            logits[row * M + n] = acc / inv;
+        }
+        free(s); free(heads); free(gl);
     }
 }
 

@@ -167,6 +167,20 @@ def instancenorm(x, gamma, beta, eps=1e-5):
     return x
 
 
+def pointer_attention(query, key, value, logit_key, mask, Wout, bout=None, num_heads=8, mask_inner=True):
+    """query [B, L, E]; key / value / logit_key [B, M, E]; mask [B, M] or [B, L, M] (True = feasible) or None -> [B, L, M]."""
+    query, key, value, logit_key = (_f32(x) for x in (query, key, value, logit_key))
+    B, L, E = query.shape
+    M = key.shape[1]
+    out = np.empty((B, L, M), np.float32)
+    mk = None if mask is None else _u8(np.asarray(mask).astype(np.uint8))
+    lib().orc_pointer_attention(_p(query), _p(key), _p(value), _p(logit_key), _p(mk),
+                                C.c_int(int(mask is not None and np.asarray(mask).ndim == 3)), _p(_f32(Wout)),
+                                _p(None if bout is None else _f32(bout)), _p(out), C.c_long(B), C.c_int(L), C.c_int(M),
+                                C.c_int(E), C.c_int(num_heads), C.c_int(int(mask_inner)))
+    return out
+
+
 def mean_nodes(emb):
     emb = _f32(emb)
     B, M, E = emb.shape

@@ -135,6 +135,22 @@ class TensorDict:
         new_bs = torch.Size([self._bs[d] for d in dims])
         return self._map(lambda v: v.permute(*dims, *range(nb, v.dim())), new_bs)
 
+    def gather(self, dim, index):
+        """tensordict's gather along batch dim `dim`: `index` has the batch rank, trailing feature dims are broadcast."""
+        nb = len(self._bs)
+
+        def g(v):
+            idx = index.view(*index.shape, *([1] * (v.dim() - nb))).expand(*index.shape, *v.shape[nb:])
+            return v.gather(dim, idx)
+
+        return self._map(g, index.shape)
+
+    def squeeze(self, dim):
+        nb = len(self._bs)
+        d = dim if dim >= 0 else dim + nb
+        new_bs = torch.Size([s for i, s in enumerate(self._bs) if not (i == d and s == 1)])
+        return self._map(lambda v: v.squeeze(d) if v.shape[d] == 1 else v, new_bs)
+
 
 class EnvBase:
     """Stand-in for torchrl.envs.EnvBase: only the reset plumbing RL4COEnvBase relies on."""

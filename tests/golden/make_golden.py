@@ -3,7 +3,7 @@
 
 Run only in the build container (the reference never travels to the GPU box):
 
-    python tests/golden/make_golden.py [extra | beam | filtering | sdvrp | pctsp | op | cvrptw | train | eval]
+    python tests/golden/make_golden.py [extra | beam | filtering | sdvrp | pctsp | op | cvrptw | train | eval | inject]
 
 (no argument: the first batch, TSP / CVRP / POMO; `extra`: larger graphs and decoding options; `beam`: beam search;
 `filtering`: top-k / top-p; `sdvrp`, `pctsp` (incl. SPCTSP), `op`, `cvrptw`: the sibling envs and their state_dict
@@ -63,7 +63,7 @@ class Recorder:
 
     def __init__(self, policy):
         self.policy = policy
-        self.logits, self.masks, self.logprobs, self.noise = [], [], [], []
+        self.logits, self.masks, self.logprobs, self.noise, self.starts = [], [], [], [], []
 
     def __enter__(self):
         dec = self.policy.decoder
@@ -89,6 +89,10 @@ class Recorder:
         self._mn = torch.multinomial
 
         def mn(probs, num_samples, *a, **k):
+            if num_samples != 1:        # sample_n_random_actions (SamplingEval's random start nodes): record, do not replay
+                res = self._mn(probs, num_samples, *a, **k)
+                self.starts.append(res.clone())
+                return res
             state = torch.get_rng_state()
             res = self._mn(probs, num_samples, *a, **k)
             after = torch.get_rng_state()
@@ -440,6 +444,103 @@ def run_train_case(name, env_name, num_loc, batch, policy_kw=None, num_starts=No
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def run_eval_case(name, env_name, num_loc, batch, method, policy_kw=None, data_seed=1234, rng_seed=77, **eval_kw):
+    """The reference's evaluators (rl4co/tasks/eval.py:88-297) on one batch: eval_fn(policy, [batch]) exactly as
+    evaluate_policy drives them.  Stored: the generator's batch, the best actions and rewards, and what the run drew
+    at random (rotation angles of the 'symmetric' augmentation; start nodes and Exp(1) noise of SamplingEval)."""
+    import math
+
+    import rl4co.data.transforms as ref_tf
+    import rl4co.tasks.eval as ref_eval
+
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv}[env_name]
+    env = Env(generator_params=gen_params(env_name, num_loc), seed=data_seed)
+    torch.manual_seed(data_seed)
+    data = env.generator(batch_size=[batch])
+    policy = make_policy(env_name, **(policy_kw or {}))
+    phis = []
+    orig_sym = ref_tf.symmetric_augmentation
+
+    def rec_sym(xy, num_augment=8, first_augment=False):
+        state = torch.get_rng_state()
+        phis.append(torch.rand(xy.shape[0]) * 4 * math.pi)        # the draw symmetric_augmentation is about to make
+        torch.set_rng_state(state)
+        return orig_sym(xy, num_augment, first_augment)
+
+    ref_tf.symmetric_augmentation = rec_sym
+    try:
+        cls = {"greedy": ref_eval.GreedyEval, "augment": ref_eval.AugmentationEval, "sampling": ref_eval.SamplingEval,
+               "multistart_greedy": ref_eval.GreedyMultiStartEval,
+               "multistart_greedy_augment": ref_eval.GreedyMultiStartAugmentEval}[method]
+        eval_fn = cls(env, progress=False, **eval_kw)
+        torch.manual_seed(rng_seed)
+        with Recorder(policy) as rec:
+            res = eval_fn(policy, [data.clone()])
+    finally:
+        ref_tf.symmetric_augmentation = orig_sym
+    fx = {"torch_version": np.array(torch.__version__), "env_name": np.array(env_name), "method": np.array(method),
+          "actions": np_(res["actions"]), "rewards": np_(res["rewards"])}
+    for k, v in data.items():
+        fx["gen_" + k] = np_(v)
+    for k, v in eval_kw.items():
+        fx["eval_kw_" + k] = np.array(v)
+    for k, v in (policy_kw or {}).items():
+        fx["policy_kw_" + k] = np.array(v)
+    if phis:
+        fx["phi"] = np_(phis[0])
+    if rec.starts:
+        fx["start_nodes"] = np_(rec.starts[0])                      # [B, samples] as torch.multinomial returned them
+    if rec.noise:
+        fx["noise"] = np.stack([np_(q) for q in rec.noise], 1)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"{name}: rewards[:3]={fx['rewards'][:3]} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def eval_batch():
+    """Tenth batch (python make_golden.py eval): the evaluation harness."""
+    pomo = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False)
+    for env_name, seed in (("tsp", 501), ("cvrp", 502)):
+        run_eval_case(f"eval_{env_name}20_greedy", env_name, 20, 6, "greedy", data_seed=seed)
+        run_eval_case(f"eval_{env_name}20_augment_dihedral8", env_name, 20, 6, "augment", data_seed=seed, num_augment=8,
+                      force_dihedral_8=True)
+        run_eval_case(f"eval_{env_name}20_augment_symmetric", env_name, 20, 6, "augment", data_seed=seed, num_augment=8)
+        run_eval_case(f"eval_{env_name}20_multistart", env_name, 20, 6, "multistart_greedy", data_seed=seed, num_starts=20)
+        run_eval_case(f"eval_{env_name}20_multistart_augment_dihedral8", env_name, 20, 4, "multistart_greedy_augment",
+                      data_seed=seed, num_starts=20, num_augment=8, force_dihedral_8=True)
+        run_eval_case(f"eval_{env_name}20_sampling", env_name, 20, 5, "sampling", data_seed=seed, samples=6)
+    run_eval_case("eval_pomo_tsp20_multistart_augment_symmetric", "tsp", 20, 4, "multistart_greedy_augment", policy_kw=pomo,
+                  data_seed=503, num_starts=20, num_augment=4)
+
+
+def inject():
+    """Eleventh batch (python make_golden.py inject): the reference's PointerAttention module (nn/attention.py:224-328) on
+    recorded inputs -- what a `pointer=` replacement must reproduce."""
+    from rl4co.models.nn.attention import PointerAttention
+
+    fx = {"torch_version": np.array(torch.__version__)}
+    E, H = 128, 8
+    pa = PointerAttention(E, H, mask_inner=True, out_bias=False, check_nan=True)
+    w = goldweights.tensor_for("decoder.pointer.project_out.weight", (E, E))
+    with torch.no_grad():
+        pa.project_out.weight.copy_(torch.from_numpy(w))
+    g = torch.Generator().manual_seed(2024)
+    for tag, (B, L, M) in {"single": (3, 1, 20), "multi": (2, 5, 33), "wide": (2, 1, 150)}.items():
+        q = torch.randn(B, L, E, generator=g)
+        kvl = torch.randn(B, M, 3 * E, generator=g)
+        k, v, lk = kvl.chunk(3, dim=-1)                      # strided views, as the decoder's cache chunks are
+        mask = torch.rand(B, L, M, generator=g) > 0.3
+        mask[..., 0] = True
+        if L == 1:
+            mask = mask[:, 0]
+        with torch.inference_mode():
+            logits = pa(q, k, v, lk, mask)
+        fx.update({f"{tag}_q": np_(q), f"{tag}_kvl": np_(kvl), f"{tag}_mask": np_(mask), f"{tag}_logits": np_(logits)})
+    path = os.path.join(HERE, "pointer_attention.npz")
+    np.savez_compressed(path, **fx)
+    print(f"pointer_attention -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def train():
     """Ninth batch (python make_golden.py train): training forward / backward of the reference policy."""
     pomo = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False)
@@ -452,6 +553,10 @@ def train():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         train()
+    elif len(sys.argv) > 1 and sys.argv[1] == "eval":
+        eval_batch()
+    elif len(sys.argv) > 1 and sys.argv[1] == "inject":
+        inject()
     elif len(sys.argv) > 1 and sys.argv[1] == "cvrptw":
         cvrptw()
     elif len(sys.argv) > 1 and sys.argv[1] == "op":

@@ -331,6 +331,37 @@ def test_graphed_rollout_equals_eager(env_name, mode):
         assert_bits_equal(a["log_likelihood"], b["log_likelihood"], "ll")
 
 
+@pytest.mark.parametrize("env_name", ["tsp", "cvrp"])
+def test_graphed_rollout_follows_weight_updates(env_name):
+    """ADVICE r1 (policy.py:924): the graph reads weight-derived constants (folded context halves, stacked cache
+    weights) from persistent buffers that are refreshed in place, so a replay after an optimizer step / load_state_dict
+    -- with eager forwards in between -- equals the eager rollout."""
+    import eam_rl4co_amd as ea
+
+    pol = make_policy("am_" + env_name)
+    env = ea.get_env(env_name, generator_params=dict(num_loc=20), seed=4)
+    td = env.reset(batch_size=[16]).to(DEV)
+    g = ea.GraphedRollout(pol, env, td, decode_type="greedy")
+    before = g(td)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    for it in range(2):
+        with torch.no_grad():
+            for p in pol.parameters():          # an "optimizer step"
+                p.add_(0.05 * torch.randn(p.shape, device=DEV, generator=gen))
+        if it == 1:
+            pol(td.clone(), env, phase="test", decode_type="greedy")      # eager forward between update and replay
+            junk = [torch.randn(1 << 16, device=DEV) for _ in range(8)]  # churn the allocator
+            del junk
+        a = g(td)
+        b = pol(td.clone(), env, phase="test", decode_type="greedy")
+        assert_bits_equal(a["actions"], b["actions"], "actions")
+        assert_bits_equal(a["log_likelihood"], b["log_likelihood"], "ll")
+    assert not torch.equal(before["log_likelihood"], a["log_likelihood"])
+    pol.train()
+    with pytest.raises(RuntimeError):
+        g(td)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # N3: evolutionary operators on the GPU (eamrl_ea_tsp_run) against the oracle and the reference's outputs
 # ---------------------------------------------------------------------------------------------------------
@@ -584,3 +615,72 @@ def test_beam_search_reproduces_reference_tours(oracle, name):
     # the reference's own shape test (tests/test_policy.py:61-76)
     B = fx["locs"].shape[0]
     assert out["reward"].shape == ((B,) if kw["select_best"] else (B * kw.get("beam_width", fx["locs"].shape[1]),))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the reference's injection points: AttentionModelDecoder(pointer=...), MultiHeadAttention(sdpa_fn=...)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["single", "multi", "wide"])
+def test_pointer_attention_module_is_a_drop_in(oracle, tag):
+    """eam_rl4co_amd.PointerAttention with the reference module's signature: bit-equal to the oracle, 2e-5 from the
+    reference's PointerAttention.forward on its recorded inputs (strided key / value / logit-key chunk views)."""
+    import eam_rl4co_amd as ea
+    import goldweights
+
+    fx = golden("pointer_attention")
+    E, H = 128, 8
+    pa = ea.PointerAttention(E, H, mask_inner=True, out_bias=False, check_nan=True).to(DEV)
+    w = goldweights.tensor_for("decoder.pointer.project_out.weight", (E, E))
+    with torch.no_grad():
+        pa.project_out.weight.copy_(torch.from_numpy(w))
+    assert list(pa.state_dict()) == ["project_out.weight"]              # the reference's parameter name
+    kvl = t(fx[f"{tag}_kvl"])
+    k, v, lk = kvl.chunk(3, dim=-1)
+    q, mask = t(fx[f"{tag}_q"]), t(fx[f"{tag}_mask"])
+    logits = pa(q, k, v, lk, mask)
+    assert logits.shape == fx[f"{tag}_logits"].shape
+    np.testing.assert_allclose(logits.cpu().numpy(), fx[f"{tag}_logits"], rtol=0, atol=2e-5)
+    kk, vv, ll = (np.ascontiguousarray(fx[f"{tag}_kvl"][..., i * E:(i + 1) * E]) for i in range(3))
+    o = oracle.pointer_attention(fx[f"{tag}_q"], kk, vv, ll, fx[f"{tag}_mask"], w)
+    assert_bits_equal(logits.reshape(o.shape), o, "logits")
+    all_masked = torch.zeros_like(mask)
+    with pytest.raises(AssertionError, match="Logits contain NaNs"):
+        pa(q, k, v, lk, all_masked)
+
+
+def test_pointer_attention_equals_the_fused_decoder_step():
+    """The injected module on (query, cached K / V / L) gives the logits the fused decode step computes."""
+    import eam_rl4co_amd as ea
+
+    fx = golden("cvrp20_greedy")
+    pol = make_policy("am_cvrp")
+    env, td = make_td("cvrp", fx["locs"], fx["demand"])
+    hidden, _ = pol.encoder(td)
+    cache = pol.decoder._precompute_cache(hidden)
+    fused, mask = pol.decoder(td, cache)
+    dec = pol.decoder
+    cur = td["current_node"].reshape(-1)
+    emb_cur = hidden[torch.arange(hidden.shape[0], device=DEV), cur]
+    state = (td["vehicle_capacity"] - td["used_capacity"]).reshape(-1, 1)
+    q = torch.nn.functional.linear(torch.cat((emb_cur, state), -1), dec.context_embedding.project_context.weight) + cache.graph_context
+    pa = ea.PointerAttention(dec.embed_dim, dec.num_heads).to(DEV)
+    pa.load_state_dict(dec.pointer.state_dict())
+    logits = pa(q[:, None, :], cache.glimpse_key, cache.glimpse_val, cache.logit_key, mask)
+    feas = mask.cpu().numpy()
+    np.testing.assert_allclose(logits.cpu().numpy()[feas], fused.cpu().numpy()[feas], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,H,N,D", [(3, 8, 20, 16), (2, 8, 101, 16), (1, 4, 150, 32)])
+def test_sdpa_fn_for_the_reference_encoder(B, H, N, D):
+    """sdpa_fn(q, k, v) on head views of a packed Wqkv output (nn/attention.py:112-135) vs torch's fp32 SDPA."""
+    import eam_rl4co_amd as ea
+
+    torch.manual_seed(B * 100 + N)
+    qkv = torch.randn(B, N, 3 * H * D, device=DEV)
+    q, k, v = qkv.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4).unbind(0)        # "b s (three h d) -> three b h s d"
+    out = ea.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0)
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v)
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-6)
+    with pytest.raises(NotImplementedError):
+        ea.scaled_dot_product_attention(q, k, v, attn_mask=torch.ones(B, 1, 1, N, dtype=torch.bool, device=DEV))

@@ -387,3 +387,19 @@ def test_batchnorm_train_is_the_defined_order(oracle):
     np.testing.assert_allclose(v, x.astype(np.float64).var(0), rtol=2e-6, atol=0)
     np.testing.assert_allclose(rm, trm.numpy(), rtol=0, atol=1e-6)
     np.testing.assert_allclose(rv, trv.numpy(), rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["single", "multi", "wide"])
+def test_pointer_attention_matches_reference_module(oracle, tag):
+    """orc_pointer_attention against the reference's PointerAttention.forward on recorded inputs (`make_golden.py inject`)."""
+    import goldweights
+
+    fx = golden("pointer_attention")
+    E = 128
+    kvl = fx[f"{tag}_kvl"]
+    k, v, lk = (np.ascontiguousarray(kvl[..., i * E:(i + 1) * E]) for i in range(3))
+    w = goldweights.tensor_for("decoder.pointer.project_out.weight", (E, E))
+    q = fx[f"{tag}_q"]
+    out = oracle.pointer_attention(q, k, v, lk, fx[f"{tag}_mask"], w)
+    want = fx[f"{tag}_logits"].reshape(out.shape)
+    np.testing.assert_allclose(out, want, rtol=0, atol=2e-5)
