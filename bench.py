@@ -196,7 +196,7 @@ class FamilyTimer:
             e1.record()
             self.ev.setdefault(fam, []).append((e0, e1))
             if flops_of is not None:
-                self.flops[fam] = self.flops.get(fam, 0.0) + flops_of(a, r)
+                self.flops[fam] = self.flops.get(fam, 0.0) + (flops_of(a, r, k) if flops_of.__code__.co_argcount == 3 else flops_of(a, r))
             return r
         return wrapper
 
@@ -341,7 +341,17 @@ def main():
 
     # per launch family: HIP events around the calls on the launch stream, in eager passes before the timed region
     ft = FamilyTimer(torch)
-    orig = {n: getattr(ops, n) for n in ("rollout", "linear", "matmul_right", "mha_encoder")}
+    orig = {n: getattr(ops, n) for n in ("rollout", "linear", "matmul_right", "mha_encoder", "encoder_fused")}
+
+    def fused_flops(a, r, k):   # per instance and layer: qkv + QK^T + PV + out_proj + FFN (algorithmic, unpadded)
+        Bq, Mq, Eq = a[0].shape
+        per = 2.0 * Mq * Eq * 3 * Eq + 4.0 * Mq * Mq * Eq + 2.0 * Mq * Eq * Eq + 4.0 * Mq * Eq * a[3]
+        tot = per * Bq * len(a[1])
+        if k.get("cache") is not None:      # + the decoder cache projections done from LDS: (nproj + 1) x [M, E] x [E, E]
+            tot += 2.0 * Mq * Eq * Eq * (k["cache"][3] + 1) * Bq
+        return tot
+
+    ops.encoder_fused = ft.wrap("encoder_fused", orig["encoder_fused"], fused_flops)
     ops.rollout = ft.wrap("decode", orig["rollout"])
     ops.linear = ft.wrap("gemm", orig["linear"], lambda a, r: 2.0 * a[0].numel() * r.shape[-1])
     ops.matmul_right = ft.wrap("gemm", orig["matmul_right"], lambda a, r: 2.0 * a[0].numel() * r.shape[-1])
@@ -363,7 +373,7 @@ def main():
         setattr(ops, n, f)
     passes = n_pass - skip
     rollout_only_ms = float(np.mean([a.elapsed_time(b) for a, b in rollout_ms[skip:]]))
-    fam_ms = {f: ft.ms(f, passes) for f in ("gemm", "attention", "decode")}
+    fam_ms = {f: ft.ms(f, passes) for f in ("gemm", "attention", "decode", "encoder_fused")}
 
     def timed(step_fn, steps, warmup):
         out = None
@@ -453,8 +463,15 @@ def main():
         roofline_att = {"kernel": "k_mha_encoder (encoder self-attention)", "bound": "mfma", "achieved": round(att_tf, 2),
                         "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(att_tf / F32_PEAK_TFLOPS, 4),
                         "ms_per_step": round(fam_ms["attention"], 4), "launches_per_step": ft.launches("attention", passes)}
+        enc_tf = (ft.flops.get("encoder_fused", 0.0) / passes / (fam_ms["encoder_fused"] * 1e-3) / 1e12
+                  if fam_ms["encoder_fused"] else 0.0)
+        roofline_enc = {"kernel": "k_encoder_fused (all encoder layers of an instance in one workgroup, v_mfma_f32_16x16x4_f32)",
+                        "bound": "mfma", "achieved": round(enc_tf, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(enc_tf / F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "kernel_ms": round(fam_ms["encoder_fused"], 4), "launches_per_step": ft.launches("encoder_fused", passes),
+                        "algorithmic_flops_per_launch": int(ft.flops.get("encoder_fused", 0.0) / passes)}
         dominant = max(fam_ms, key=lambda f: fam_ms[f])
-        roofline = dict(roofline_gemm if dominant == "gemm" else
+        roofline = dict(roofline_enc if dominant == "encoder_fused" else roofline_gemm if dominant == "gemm" else
                         roofline_decode["issue_bound"] | {"kernel": roofline_decode["kernel"], "kernel_ms": round(kern, 4)}
                         if (dominant == "decode" and M <= 128) else roofline_decode if dominant == "decode" else roofline_att)
         roofline["share_of_step"] = {f: round(v / rollout_only_ms, 3) for f, v in fam_ms.items()}
@@ -475,7 +492,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": cfg, "roofline": roofline, "roofline_decode": roofline_decode, "roofline_gemm": roofline_gemm,
-            "roofline_attention": roofline_att,
+            "roofline_attention": roofline_att, "roofline_encoder_fused": roofline_enc,
         }
         if strong is not None:
             line["strong_scaling"] = strong

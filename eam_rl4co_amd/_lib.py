@@ -24,6 +24,17 @@ class Cache(C.Structure):
                 ("dyn", _vp)]
 
 
+class EncoderLayer(C.Structure):
+    """struct eamrl_encoder_layer"""
+    _fields_ = [(n, _vp) for n in ("Wqkv", "bqkv", "Wo", "bo", "W1", "b1", "W2", "b2", "n1_gamma", "n1_beta", "n1_mean",
+                                   "n1_var", "n2_gamma", "n2_beta", "n2_mean", "n2_var")]
+
+
+class EncoderCache(C.Structure):
+    """struct eamrl_encoder_cache"""
+    _fields_ = [("Wc", _vp), ("WoutT", _vp), ("out", _vp), ("ld", _i64), ("nproj", C.c_int32)]
+
+
 class State(C.Structure):
     """struct eamrl_state"""
     _fields_ = [("first", _vp), ("cur", _vp), ("istep", _vp), ("used", _vp), ("vcap", _vp), ("demand", _vp),
@@ -54,6 +65,9 @@ PROTOTYPES = {
     "eamrl_normalize": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp],
     "eamrl_batchnorm_train": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i64, _vp],
     "eamrl_pointer_attention": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
+    "eamrl_pack_linear_weight": [_vp, _vp, _i32, _i32, _vp],
+    "eamrl_encoder_fused_supported": [_i32, _i32, _i32, _i32, _i32],
+    "eamrl_encoder_fused": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "eamrl_mean_nodes": [_vp, _vp, _i64, _i32, _i32, _vp],
     "eamrl_am_decode_step": [_i32, C.POINTER(Cache), C.POINTER(State), _i64, _i32, _vp, _vp, _f32, _f32, _i32, _f32, _i32,
                              _vp, _vp, _vp, _vp, _vp, _vp],

@@ -253,6 +253,44 @@ __attribute__((visibility("default"))) int eamrl_pointer_attention(const float* 
                                              E, H, mask_inner, (hipStream_t)stream), "eamrl_pointer_attention");
 }
 
+__attribute__((visibility("default"))) int eamrl_pack_linear_weight(const float* W, float* Wp, int out_dim, int in_dim,
+                                                                   void* stream)
+{
+    REQUIRE(W && Wp && out_dim > 0 && in_dim > 0 && out_dim % 16 == 0 && in_dim % 16 == 0, "eamrl_pack_linear_weight");
+    return launched(launch_pack_mfma_b(W, Wp, out_dim, in_dim, (hipStream_t)stream), "eamrl_pack_linear_weight");
+}
+
+__attribute__((visibility("default"))) int eamrl_encoder_fused_supported(int M, int E, int H, int ff_hidden, int nlayers)
+{
+    return encoder_fused_supports(M, E, H, ff_hidden, nlayers) ? 1 : 0;
+}
+
+__attribute__((visibility("default"))) int eamrl_encoder_fused(const float* h_in, float* h_out, int64_t B, int M, int E, int H,
+                                                              int ff_hidden, int nlayers, int norm, float eps,
+                                                              const eamrl_encoder_layer* layers,
+                                                              const eamrl_encoder_cache* cache, void* stream)
+{
+    if (cache) {
+        REQUIRE(cache->Wc && cache->WoutT && cache->out && cache->nproj >= 3 && cache->nproj <= 5, "eamrl_encoder_fused");
+        REQUIRE(cache->ld >= (int64_t)(cache->nproj + 1) * E && cache->ld % 4 == 0 && ((uintptr_t)cache->out % 16 == 0) &&
+                    ((uintptr_t)cache->Wc % 16 == 0) && ((uintptr_t)cache->WoutT % 16 == 0), "eamrl_encoder_fused");
+    }
+    REQUIRE(h_in && h_out && layers && B >= 0, "eamrl_encoder_fused");
+    REQUIRE(encoder_fused_supports(M, E, H, ff_hidden, nlayers), "eamrl_encoder_fused");
+    REQUIRE(norm == EAMRL_NORM_BATCH_EVAL || norm == EAMRL_NORM_INSTANCE, "eamrl_encoder_fused");
+    REQUIRE(((uintptr_t)h_in % 16 == 0) && ((uintptr_t)h_out % 16 == 0), "eamrl_encoder_fused");
+    for (int l = 0; l < nlayers; ++l) {
+        const eamrl_encoder_layer& s = layers[l];
+        REQUIRE(s.Wqkv && s.bqkv && s.Wo && s.bo && s.W1 && s.b1 && s.W2 && s.b2 && s.n1_gamma && s.n1_beta && s.n2_gamma &&
+                    s.n2_beta, "eamrl_encoder_fused");
+        REQUIRE(((uintptr_t)s.Wqkv % 16 == 0) && ((uintptr_t)s.Wo % 16 == 0) && ((uintptr_t)s.W1 % 16 == 0) &&
+                    ((uintptr_t)s.W2 % 16 == 0), "eamrl_encoder_fused");
+        if (norm == EAMRL_NORM_BATCH_EVAL) REQUIRE(s.n1_mean && s.n1_var && s.n2_mean && s.n2_var, "eamrl_encoder_fused");
+    }
+    return launched(launch_encoder_fused(h_in, h_out, B, M, nlayers, norm, eps, layers, cache, (hipStream_t)stream),
+                    "eamrl_encoder_fused");
+}
+
 __attribute__((visibility("default"))) int eamrl_mean_nodes(const float* emb, float* out, int64_t B, int M, int E,
                                                            void* stream)
 {

@@ -32,6 +32,10 @@ int launch_batchnorm_train(float* x, int64_t rows, int E, const float* gamma, co
 int launch_pointer_attention(const float* q, const float* K, const float* V, const float* Lk, int64_t ld, const uint8_t* mask,
                              int mask_per_query, const float* Wout, const float* bout, float* logits, int64_t B, int L, int M,
                              int E, int H, int mask_inner, hipStream_t st);
+bool encoder_fused_supports(int M, int E, int H, int FFdim, int nlayers);
+int launch_encoder_fused(const float* h_in, float* h_out, int64_t B, int M, int nlayers, int norm, float eps,
+                         const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache, hipStream_t st);
+int launch_pack_mfma_b(const float* W, float* Wp, int N, int K, hipStream_t st);
 int launch_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, hipStream_t st);
 int launch_tsp_step(uint8_t* mask, int64_t* first, int64_t* cur, int64_t* istep, const int64_t* action,
                     uint8_t* done, int64_t R, int N, hipStream_t st);

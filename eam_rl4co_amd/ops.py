@@ -173,6 +173,56 @@ def mean_nodes(emb):
     return out
 
 
+def pack_linear_weight(W, out=None):
+    """torch.nn.Linear.weight [out, in] -> the packed MFMA fragment order the fused encoder reads (eamrl_pack_linear_weight)."""
+    lib = _lib.load()
+    _chk(W, "weight", torch.float32)
+    N, K = W.shape
+    if out is None:
+        out = torch.empty(N * K, device=W.device, dtype=torch.float32)
+    _chk(out, "packed weight", torch.float32, (N * K,))
+    _lib.check(lib.eamrl_pack_linear_weight(_ptr(W), _ptr(out), N, K, _stream(W)), "eamrl_pack_linear_weight")
+    return out
+
+
+def encoder_fused_supported(M, E, H, ff_hidden, nlayers) -> bool:
+    return bool(_lib.load().eamrl_encoder_fused_supported(int(M), int(E), int(H), int(ff_hidden), int(nlayers)))
+
+
+def encoder_fused(h, layers, num_heads, ff_hidden, norm, eps, cache=None):
+    """All encoder layers of every instance in one launch.  h [B, M, E]; layers: list of dicts with the 16 fields of
+    struct eamrl_encoder_layer (packed weights, biases, norm parameters; running stats may be None for instance norm).
+    cache = (Wc_packed, WoutT_packed, out [B, M, ld], nproj): also fill the slot-major decoder cache (struct
+    eamrl_encoder_cache)."""
+    lib = _lib.load()
+    _chk(h, "h", torch.float32)
+    B, M, E = h.shape
+    arr = (_lib.EncoderLayer * len(layers))()
+    for i, d in enumerate(layers):
+        for name, _ in _lib.EncoderLayer._fields_:
+            t = d.get(name)
+            if t is not None:
+                _need_gpu(t, name)
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise TypeError(f"encoder_fused: {name} must be contiguous fp32")
+            setattr(arr[i], name, _ptr(t))
+    out = torch.empty_like(h)
+    cstruct = None
+    if cache is not None:
+        Wc, WoT, buf, nproj = cache
+        _chk(Wc, "packed cache weights", torch.float32, (nproj * E * E,))
+        _chk(WoT, "packed project_out^T", torch.float32, (E * E,))
+        _chk(buf, "decoder cache", torch.float32)
+        if buf.dim() != 3 or buf.shape[0] != B or buf.shape[1] != M or buf.shape[2] < (nproj + 1) * E:
+            raise ValueError("encoder_fused: cache buffer must be [B, M, >= (nproj + 1) * E]")
+        cs = _lib.EncoderCache()
+        cs.Wc, cs.WoutT, cs.out, cs.ld, cs.nproj = _ptr(Wc), _ptr(WoT), _ptr(buf), buf.shape[2], int(nproj)
+        cstruct = C.byref(cs)
+    _lib.check(lib.eamrl_encoder_fused(_ptr(h), _ptr(out), B, M, E, int(num_heads), int(ff_hidden), len(layers), int(norm),
+                                       float(eps), C.cast(arr, C.c_void_p), cstruct, _stream(h)), "eamrl_encoder_fused")
+    return out
+
+
 def pointer_attention(query, key, value, logit_key, attn_mask, Wout, bout=None, num_heads=8, mask_inner=True):
     """PointerAttention.forward (nn/attention.py:282-306) in one launch.  query [B, L, E] (or [B, E]); key / value /
     logit_key [B, M, E] (views with a common row stride are fine, e.g. the chunks of one projection);

@@ -202,11 +202,68 @@ class GraphAttentionNetwork(nn.Module):
         self.layers = nn.Sequential(*(MultiHeadAttentionLayer(embed_dim, num_heads, feedforward_hidden, normalization)
                                       for _ in range(num_layers)))
 
-    def forward(self, x, mask=None):
+    def forward(self, x, mask=None, cache_spec=None):
+        """cache_spec (optional, from AttentionModelDecoder._fused_cache_spec): the fused kernel also fills the decoder cache
+        from the embeddings it still holds in LDS and sets cache_spec["filled"]."""
         assert mask is None, "Mask not yet supported!"
+        fused = self._fused_layers(x)
+        if fused is not None:       # all layers of an instance in one workgroup, activations resident in LDS
+            layers, H, ff, norm, eps = fused
+            cache = None
+            if cache_spec is not None:
+                cache = (cache_spec["Wc"], cache_spec["WoT"], cache_spec["buf"], cache_spec["nproj"])
+            out = ops.encoder_fused(x.contiguous(), layers, H, ff, norm, eps, cache=cache)
+            if cache_spec is not None:
+                cache_spec["filled"] = True
+            return out
         for layer in self.layers:
             x = layer(x)
         return x
+
+    def _fused_layers(self, x):
+        """Arguments of `ops.encoder_fused` when the fused kernel covers this network (eval-mode batch norm or instance
+        norm, E = 128, 8 heads, one hidden layer of 512, graphs up to 112 nodes), else None.  The packed weights live in
+        persistent buffers refreshed in place when a parameter changes (a captured HIP graph keeps reading them)."""
+        if os.environ.get("EAMRL_FUSED_ENCODER", "1") == "0" or len(self.layers) == 0:
+            return None
+        first = self.layers[0]
+        mha0, ffn0 = first[0].module, first[2].module
+        if len(ffn0.lins) != 2:
+            return None
+        E, H, ff = mha0.embed_dim, mha0.num_heads, ffn0.lins[0].out_features
+        if x.dim() != 3 or x.shape[-1] != E or not ops.encoder_fused_supported(x.shape[1], E, H, ff, len(self.layers)):
+            return None
+        n0 = first[1].normalizer
+        if isinstance(n0, nn.BatchNorm1d):
+            if first[1].training:
+                return None             # batch statistics: a reduction across instances (unfused path)
+            norm = ops.NORM_BATCH_EVAL
+        else:
+            norm = ops.NORM_INSTANCE
+        packed = self.__dict__.setdefault("_packed", {})
+        out = []
+        for li, layer in enumerate(self.layers):
+            mha, ffn = layer[0].module, layer[2].module
+            n1, n2 = layer[1].normalizer, layer[3].normalizer
+            if (type(n1) is not type(n0) or type(n2) is not type(n0) or mha.num_heads != H or len(ffn.lins) != 2
+                    or ffn.lins[0].out_features != ff or mha.Wqkv.bias is None or n1.eps != n0.eps or n2.eps != n0.eps):
+                return None
+            d = {}
+            for name, lin in (("Wqkv", mha.Wqkv), ("Wo", mha.out_proj), ("W1", ffn.lins[0]), ("W2", ffn.lins[1])):
+                w = lin.weight
+                key = (w.data_ptr(), w._version, w.device)
+                slot = packed.get((li, name))
+                if slot is None or slot[0] != key:
+                    buf = None if slot is None or slot[1].device != w.device else slot[1]
+                    packed[(li, name)] = slot = (key, ops.pack_linear_weight(w.detach().contiguous(), out=buf))
+                d[name] = slot[1]
+            d.update(bqkv=mha.Wqkv.bias.detach(), bo=mha.out_proj.bias.detach(), b1=ffn.lins[0].bias.detach(),
+                     b2=ffn.lins[1].bias.detach(), n1_gamma=n1.weight.detach(), n1_beta=n1.bias.detach(),
+                     n2_gamma=n2.weight.detach(), n2_beta=n2.bias.detach())
+            if norm == ops.NORM_BATCH_EVAL:
+                d.update(n1_mean=n1.running_mean, n1_var=n1.running_var, n2_mean=n2.running_mean, n2_var=n2.running_var)
+            out.append(d)
+        return out, H, ff, norm, n0.eps
 
 
 class AttentionModelEncoder(nn.Module):
@@ -225,9 +282,9 @@ class AttentionModelEncoder(nn.Module):
         self.net = GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden) \
             if net is None else net
 
-    def forward(self, td, mask=None):
+    def forward(self, td, mask=None, cache_spec=None):
         init_h = self.init_embedding(td)
-        h = self.net(init_h, mask)
+        h = self.net(init_h, mask, cache_spec=cache_spec) if cache_spec is not None else self.net(init_h, mask)
         return h, init_h
 
 
@@ -295,15 +352,38 @@ class AttentionModelDecoder(nn.Module):
         self.project_fixed_context = nn.Linear(embed_dim, embed_dim, bias=False)
         self.use_graph_context = use_graph_context
 
-    def _precompute_cache(self, embeddings: torch.Tensor, num_starts: int = 0) -> ops.DecodeCache:
-        """K | V | L (+ folded context / logit projections) in one slot-major buffer (ops.DecodeCache)."""
+    def _fused_cache_spec(self, B: int, M: int, device):
+        """What the fused encoder kernel needs to fill the slot-major cache itself (K | V | L | Pa (| Pb) projections of the
+        final embeddings + Lp = L Wout), or None where that layout is not used (graphs above 128 nodes: plane-major)."""
+        if M > 128 or os.environ.get("EAMRL_FUSED_CACHE", "1") == "0":
+            return None
+        E = self.embed_dim
+        self._weight_constants()
+        slots = ops.slot_map(self.env_name)
+        nproj = 5 if self.env_name == "tsp" else 4
+        Wout = self.pointer.project_out.weight
+        key = (self._wc_key, Wout.data_ptr(), Wout._version)
+        if getattr(self, "_fc_key", None) != key:
+            old = getattr(self, "_fc", None)
+            keep = old is not None and old[0].device == self._w_cache.device and old[0].numel() == self._w_cache.numel()
+            Wc = ops.pack_linear_weight(self._w_cache, out=old[0] if keep else None)
+            WoT = ops.pack_linear_weight(Wout.detach().t().contiguous(), out=old[1] if keep else None)
+            self._fc, self._fc_key = (Wc, WoT), key
+        buf = torch.empty(B, M, len(slots) * E, device=device, dtype=torch.float32)
+        return {"buf": buf, "Wc": self._fc[0], "WoT": self._fc[1], "nproj": nproj, "filled": False}
+
+    def _precompute_cache(self, embeddings: torch.Tensor, num_starts: int = 0, prefilled=None) -> ops.DecodeCache:
+        """K | V | L (+ folded context / logit projections) in one slot-major buffer (ops.DecodeCache).  prefilled: a
+        `_fused_cache_spec` whose buffer the fused encoder kernel has already filled (only the graph context is left)."""
         E = self.embed_dim
         emb = embeddings.contiguous()
         B, M, _ = emb.shape
         slots = ops.slot_map(self.env_name)
         Wa, Wb, cvec = self._weight_constants()
         Wkvl = self.project_node_embeddings.weight
-        if M > 128 and os.environ.get("EAMRL_CACHE_PLANES", "1") != "0":     # streaming-kernel territory: one dense
+        if prefilled is not None and prefilled.get("filled"):
+            buf = prefilled["buf"]
+        elif M > 128 and os.environ.get("EAMRL_CACHE_PLANES", "1") != "0":     # streaming-kernel territory: one dense
             # plane per kind of row (ops.DecodeCache); the variable exists for A/B measurements only
             buf = torch.empty(len(slots), B, M, E, device=emb.device, dtype=torch.float32)
             plane = lambda n: buf[slots[n]].view(B * M, E)
@@ -638,9 +718,13 @@ class AttentionModelPolicy(nn.Module):
                 S = env.get_num_starts(td)
         mode = "evaluate" if actions is not None else ("greedy" if "greedy" in decode_type else "sampling")
 
-        # encoder + cache (one-shot)
-        hidden, init_embeds = self.encoder(td)
-        cache = self.decoder._precompute_cache(hidden, num_starts=S)
+        # encoder + cache (one-shot); where the fused encoder kernel runs it also fills the cache from LDS
+        spec = None
+        if isinstance(self.encoder, AttentionModelEncoder) and isinstance(self.decoder, AttentionModelDecoder):
+            Bq, Mq = td["action_mask"].shape
+            spec = self.decoder._fused_cache_spec(Bq, Mq, td["action_mask"].device)
+        hidden, init_embeds = self.encoder(td, cache_spec=spec) if spec is not None else self.encoder(td)
+        cache = self.decoder._precompute_cache(hidden, num_starts=S, prefilled=spec)
 
         # pre-decoder hook (decoding.py:284-332): multistart picks the first node, state replicated S times
         st = state_from_td(self.env_name, td, S)
@@ -966,6 +1050,8 @@ class GraphedRollout:
         self.kw.update(forward_kwargs)
         self.static_td = td_example.clone()
         self._training = policy.training
+        M = td_example["action_mask"].shape[1]
+        self._embed_probe = torch.empty(1, M, policy.decoder.embed_dim, device=td_example["action_mask"].device)
         self._keys = [k for k, v in self.static_td.items() if isinstance(v, torch.Tensor)]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -984,6 +1070,12 @@ class GraphedRollout:
         # weight-derived constants live in persistent buffers that the graph reads: refresh them in place when a
         # parameter changed (optimizer step, load_state_dict); everything else the graph reads are the live parameters
         self.policy.decoder._weight_constants()
+        if hasattr(self.policy.decoder, "_fused_cache_spec") and getattr(self.policy.decoder, "_fc", None) is not None:
+            M = self._embed_probe.shape[1]
+            self.policy.decoder._fused_cache_spec(0, M, self._embed_probe.device)     # re-packs in place when weights changed
+        net = getattr(self.policy.encoder, "net", None)
+        if hasattr(net, "_fused_layers"):
+            net._fused_layers(self._embed_probe)          # re-packs changed encoder weights into the buffers the graph reads
         for k in self._keys:
             src = td[k]
             dst = self.static_td[k]

@@ -166,6 +166,55 @@ int eamrl_batchnorm_train(float* x, int64_t rows, int E, const float* gamma, con
                           float* running_var, float momentum, float eps, float* save_mean, float* save_var, float* ws,
                           int64_t ws_floats, void* stream);
 
+/* ---- fused encoder: all MultiHeadAttentionLayers of an instance in one workgroup ------------------ */
+
+/* Weights of one MultiHeadAttentionLayer  [nn/graph/attnnet.py:16-57]: the four Linear weights in the packed MFMA
+ * fragment order produced by eamrl_pack_linear_weight, biases and normalisation parameters as they are.  The running
+ * statistics are read for EAMRL_NORM_BATCH_EVAL only. */
+typedef struct eamrl_encoder_layer {
+    const float* Wqkv;     /* packed [3E][E]  (MultiHeadAttention.Wqkv.weight, "(three h d)" rows) */
+    const float* bqkv;     /* [3E] */
+    const float* Wo;       /* packed [E][E]   (out_proj.weight) */
+    const float* bo;       /* [E] */
+    const float* W1;       /* packed [F][E]   (MLP lins.0.weight) */
+    const float* b1;       /* [F] */
+    const float* W2;       /* packed [E][F]   (MLP lins.1.weight) */
+    const float* b2;       /* [E] */
+    const float *n1_gamma, *n1_beta, *n1_mean, *n1_var;     /* Normalization after the attention sub-layer */
+    const float *n2_gamma, *n2_beta, *n2_mean, *n2_var;     /* Normalization after the feed-forward sub-layer */
+} eamrl_encoder_layer;
+
+/* Optional tail of eamrl_encoder_fused: AttentionModelDecoder._precompute_cache  [zoo/am/decoder.py:206-235] computed from
+ * the final embeddings while they are still in LDS.  Wc: the stacked projection weights [nproj * E][E], packed --
+ * glimpse key | glimpse value | logit key (project_node_embeddings) | first context half (| second context half), i.e.
+ * slots 0 .. nproj-1 of the slot-major decoder cache; WoutT: project_out.weight TRANSPOSED ([E][E], packed), for the
+ * folded logit key Lp = L Wout written to slot nproj.  out [B][M][ld] (ld >= (nproj + 1) E floats).  Same values as
+ * eamrl_linear(h, Wc) followed by eamrl_matmul_right(L, Wout). */
+typedef struct eamrl_encoder_cache {
+    const float* Wc;
+    const float* WoutT;
+    float* out;
+    int64_t ld;
+    int nproj;          /* 4 (depot envs: K V L Pa) or 5 (TSP: K V L Pa Pb) */
+} eamrl_encoder_cache;
+
+/* Wp = W [out_dim][in_dim] (torch.nn.Linear.weight) re-ordered for the fused encoder: block (ct, u) of 256 floats holds,
+ * for lane l = 16 g + j of a wavefront, the float4 { W[16 ct + j][16 u + 4 q + g] : q = 0..3 } -- the B operand of four
+ * consecutive v_mfma_f32_16x16x4_f32 k-steps.  out_dim, in_dim multiples of 16.  Redo after every weight update. */
+int eamrl_pack_linear_weight(const float* W, float* Wp, int out_dim, int in_dim, void* stream);
+
+/* 1 if eamrl_encoder_fused handles this shape (M <= 112 nodes, E = 128, H = 8, feed-forward 512, <= 8 layers). */
+int eamrl_encoder_fused_supported(int M, int E, int H, int ff_hidden, int nlayers);
+
+/* GraphAttentionNetwork.forward  [nn/graph/attnnet.py:94-103; zoo/am/encoder.py:88-89]: h_out = layers(h_in) for
+ * h_in / h_out [B][M][E] (the init embeddings in, the node embeddings out; may alias), one workgroup per instance,
+ * activations resident in LDS, every Linear on fp32 MFMA.  Bit-identical to the sequence eamrl_linear /
+ * eamrl_mha_encoder / eamrl_linear_bn (or eamrl_normalize) per layer.  norm: EAMRL_NORM_BATCH_EVAL or
+ * EAMRL_NORM_INSTANCE (batch statistics are a cross-instance reduction: use the unfused calls + eamrl_batchnorm_train). */
+int eamrl_encoder_fused(const float* h_in, float* h_out, int64_t B, int M, int E, int H, int ff_hidden, int nlayers, int norm,
+                        float eps, const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache /* may be NULL */,
+                        void* stream);
+
 /* out[b][e] = (sum_n emb[b][n][e]) / M   (embeddings.mean(1), zoo/am/decoder.py:225-227) */
 int eamrl_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, void* stream);
 
