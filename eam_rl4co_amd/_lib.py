@@ -35,6 +35,18 @@ class EncoderCache(C.Structure):
     _fields_ = [("Wc", _vp), ("WoutT", _vp), ("out", _vp), ("ld", _i64), ("nproj", C.c_int32)]
 
 
+class Reeval(C.Structure):
+    """struct eamrl_reeval"""
+    _fields_ = [("K", _vp), ("V", _vp), ("Lp", _vp), ("Pa", _vp), ("Pb", _vp), ("ld", _i64),
+                ("gctx", _vp), ("Cvec", _vp), ("NC", C.c_int32),
+                ("idxA", _vp), ("idxB", _vp), ("sc", _vp), ("maskbits", _vp), ("actions", _vp),
+                ("B", _i64), ("R", _i64), ("S", C.c_int32), ("T", C.c_int32), ("M", C.c_int32), ("tstart", C.c_int32),
+                ("nchunk", C.c_int32), ("clip", _f32), ("temp", _f32),
+                ("logp", _vp), ("lse", _vp), ("glogp", _vp), ("dheads", _vp),
+                ("dK", _vp), ("dV", _vp), ("dLp", _vp), ("dPa", _vp), ("dPb", _vp), ("ldg", _i64),
+                ("dgctx", _vp), ("dCvec", _vp)]
+
+
 class State(C.Structure):
     """struct eamrl_state"""
     _fields_ = [("first", _vp), ("cur", _vp), ("istep", _vp), ("used", _vp), ("vcap", _vp), ("demand", _vp),
@@ -68,6 +80,11 @@ PROTOTYPES = {
     "eamrl_pack_linear_weight": [_vp, _vp, _i32, _i32, _vp],
     "eamrl_encoder_fused_supported": [_i32, _i32, _i32, _i32, _i32],
     "eamrl_encoder_fused": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
+    "eamrl_reeval_supported": [_i32, _i32, _i32],
+    "eamrl_reeval_forward": [_vp, _vp],
+    "eamrl_reeval_backward": [_vp, _vp],
+    "eamrl_pack_mask_bits": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "eamrl_tsp_mask_bits": [_vp, _vp, _i64, _i32, _i32, _vp],
     "eamrl_mean_nodes": [_vp, _vp, _i64, _i32, _i32, _vp],
     "eamrl_am_decode_step": [_i32, C.POINTER(Cache), C.POINTER(State), _i64, _i32, _vp, _vp, _f32, _f32, _i32, _f32, _i32,
                              _vp, _vp, _vp, _vp, _vp, _vp],

@@ -291,6 +291,53 @@ __attribute__((visibility("default"))) int eamrl_encoder_fused(const float* h_in
                     "eamrl_encoder_fused");
 }
 
+static int check_reeval(const eamrl_reeval* p, const char* what, bool bwd)
+{
+    REQUIRE(p, what);
+    REQUIRE(reeval_supports(p->M, 128, 8), what);
+    REQUIRE(p->K && p->V && p->Lp && p->Pa && p->idxA && p->maskbits && p->actions && p->logp && p->lse, what);
+    REQUIRE((p->idxB == nullptr) == (p->Pb == nullptr) || p->Pb, what);
+    REQUIRE(p->B > 0 && p->S > 0 && p->T > 0 && p->R == p->B * p->S && p->nchunk >= 1 && p->nchunk <= p->S, what);
+    REQUIRE(p->ld >= 128 && p->ld % 4 == 0 && p->NC >= 0 && p->NC <= 4 && (p->NC == 0 || (p->Cvec && p->sc)), what);
+    REQUIRE(p->temp > 0.0f && p->tstart >= 0, what);
+    REQUIRE(((uintptr_t)p->Pa % 16 == 0) && (!p->Pb || (uintptr_t)p->Pb % 16 == 0) && (!p->gctx || (uintptr_t)p->gctx % 16 == 0) &&
+                (!p->Cvec || (uintptr_t)p->Cvec % 16 == 0) && ((uintptr_t)p->maskbits % 16 == 0), what);
+    if (bwd) {
+        REQUIRE(p->glogp && p->dheads && p->dK && p->dV && p->dLp && p->dPa && p->ldg >= 128 && p->ldg % 4 == 0, what);
+        REQUIRE((p->Pb == nullptr) == (p->dPb == nullptr) && (p->gctx == nullptr) == (p->dgctx == nullptr) &&
+                    (p->NC == 0 || p->dCvec) && ((uintptr_t)p->dheads % 16 == 0), what);
+    }
+    return 0;
+}
+
+__attribute__((visibility("default"))) int eamrl_reeval_supported(int M, int E, int H) { return reeval_supports(M, E, H) ? 1 : 0; }
+
+__attribute__((visibility("default"))) int eamrl_reeval_forward(const eamrl_reeval* p, void* stream)
+{
+    if (int rc = check_reeval(p, "eamrl_reeval_forward", false)) return rc;
+    return launched(launch_reeval_fwd(*p, (hipStream_t)stream), "eamrl_reeval_forward");
+}
+
+__attribute__((visibility("default"))) int eamrl_reeval_backward(const eamrl_reeval* p, void* stream)
+{
+    if (int rc = check_reeval(p, "eamrl_reeval_backward", true)) return rc;
+    return launched(launch_reeval_bwd(*p, (hipStream_t)stream), "eamrl_reeval_backward");
+}
+
+__attribute__((visibility("default"))) int eamrl_pack_mask_bits(const uint8_t* mask, uint32_t* bits, int64_t R, int M, int T,
+                                                               int t, void* stream)
+{
+    REQUIRE(mask && bits && R >= 0 && M > 0 && M <= 128 && T > 0 && t >= 0 && t < T, "eamrl_pack_mask_bits");
+    return launched(launch_pack_mask_bits(mask, bits, R, M, T, t, (hipStream_t)stream), "eamrl_pack_mask_bits");
+}
+
+__attribute__((visibility("default"))) int eamrl_tsp_mask_bits(const int64_t* actions, uint32_t* bits, int64_t R, int M, int T,
+                                                              void* stream)
+{
+    REQUIRE(actions && bits && R >= 0 && M > 0 && M <= 128 && T > 0 && ((uintptr_t)bits % 16 == 0), "eamrl_tsp_mask_bits");
+    return launched(launch_tsp_mask_bits(actions, bits, R, M, T, (hipStream_t)stream), "eamrl_tsp_mask_bits");
+}
+
 __attribute__((visibility("default"))) int eamrl_mean_nodes(const float* emb, float* out, int64_t B, int M, int E,
                                                            void* stream)
 {

@@ -36,6 +36,13 @@ bool encoder_fused_supports(int M, int E, int H, int FFdim, int nlayers);
 int launch_encoder_fused(const float* h_in, float* h_out, int64_t B, int M, int nlayers, int norm, float eps,
                          const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache, hipStream_t st);
 int launch_pack_mfma_b(const float* W, float* Wp, int N, int K, hipStream_t st);
+// teacher-forced re-evaluation (reeval.hip)
+typedef eamrl_reeval ReevalArgs;
+bool reeval_supports(int M, int E, int H);
+int launch_reeval_fwd(const ReevalArgs& a, hipStream_t st);
+int launch_reeval_bwd(const ReevalArgs& a, hipStream_t st);
+int launch_pack_mask_bits(const uint8_t* mask, uint32_t* bits, int64_t R, int M, int T, int t, hipStream_t st);
+int launch_tsp_mask_bits(const int64_t* actions, uint32_t* bits, int64_t R, int M, int T, hipStream_t st);
 int launch_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, hipStream_t st);
 int launch_tsp_step(uint8_t* mask, int64_t* first, int64_t* cur, int64_t* istep, const int64_t* action,
                     uint8_t* done, int64_t R, int N, hipStream_t st);

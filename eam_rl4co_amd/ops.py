@@ -256,6 +256,108 @@ def pointer_attention(query, key, value, logit_key, attn_mask, Wout, bout=None, 
 
 
 # ------------------------------------------------------------------------------------------------------
+# teacher-forced re-evaluation (training gradient path)
+# ------------------------------------------------------------------------------------------------------
+def reeval_supported(M, E, H) -> bool:
+    return bool(_lib.load().eamrl_reeval_supported(int(M), int(E), int(H)))
+
+
+def pack_mask_bits_(mask, bits, t):
+    """bits[:, t] <- the bit set of mask [R, M] (bool / uint8); bits [R, T, 4] int32."""
+    lib = _lib.load()
+    R, M = mask.shape
+    _chk(_bytes(mask), "action_mask", torch.uint8, (R, M))
+    _chk(bits, "mask bits", torch.int32)
+    if bits.dim() != 3 or bits.shape[0] != R or bits.shape[2] != 4:
+        raise ValueError("pack_mask_bits: bits must be [R, T, 4] int32")
+    _lib.check(lib.eamrl_pack_mask_bits(_ptr(_bytes(mask)), _ptr(bits), R, M, bits.shape[1], int(t), _stream(mask)),
+               "eamrl_pack_mask_bits")
+
+
+def tsp_mask_bits(actions, M):
+    lib = _lib.load()
+    _chk(actions, "actions", torch.int64)
+    R, T = actions.shape
+    bits = torch.empty(R, T, 4, dtype=torch.int32, device=actions.device)
+    _lib.check(lib.eamrl_tsp_mask_bits(_ptr(actions), _ptr(bits), R, int(M), T, _stream(actions)), "eamrl_tsp_mask_bits")
+    return bits
+
+
+class ReevalPlan:
+    """Arguments of eamrl_reeval_forward / _backward (struct eamrl_reeval) kept alive between the two calls.
+
+    buf [B, M, P*E]: the instance operands side by side -- K | V | Lp | Pa (| Pb); gctx [B, E] or None; cvec [NC, E] or
+    None; idxA / idxB int32 [R, T]; sc [NC, R, T]; maskbits int32 [R, T, 4]; actions int64 [R, T]."""
+
+    def __init__(self, buf, has_pb, gctx, cvec, idxA, idxB, sc, maskbits, actions, S, tstart, clip, temp):
+        _chk(buf, "operands", torch.float32)
+        self.B, self.M, width = buf.shape
+        self.E = width // (5 if has_pb else 4)
+        self.buf, self.has_pb, self.gctx, self.cvec = buf, has_pb, gctx, cvec
+        R, T = actions.shape
+        if R != S * self.B:
+            raise ValueError("reeval: rows must be S * B")
+        _chk(actions, "actions", torch.int64, (R, T))
+        _chk(idxA, "idxA", torch.int32, (R, T))
+        if has_pb:
+            _chk(idxB, "idxB", torch.int32, (R, T))
+        _chk(maskbits, "mask bits", torch.int32, (R, T, 4))
+        self.NC = 0 if cvec is None else cvec.shape[0]
+        if self.NC:
+            _chk(cvec, "state columns", torch.float32, (self.NC, self.E))
+            _chk(sc, "state scalars", torch.float32, (self.NC, R, T))
+        if gctx is not None:
+            _chk(gctx, "graph context", torch.float32, (self.B, self.E))
+        self.idxA, self.idxB, self.sc, self.maskbits, self.actions = idxA, idxB, sc, maskbits, actions
+        self.R, self.T, self.S, self.tstart, self.clip, self.temp = R, T, int(S), int(tstart), float(clip), float(temp)
+        self.nchunk = max(1, min(self.S, -(-512 // self.B)))
+        self.logp = torch.empty(R, T, dtype=torch.float32, device=buf.device)
+        self.lse = torch.empty(R, T, dtype=torch.float32, device=buf.device)
+
+    def _struct(self):
+        s = _lib.Reeval()
+        E4 = self.E * 4
+        base = self.buf.data_ptr()
+        s.K, s.V, s.Lp, s.Pa = (C.c_void_p(base + i * E4) for i in range(4))
+        s.Pb = C.c_void_p(base + 4 * E4) if self.has_pb else None
+        s.ld = self.buf.shape[2]
+        s.gctx, s.Cvec, s.NC = _ptr(self.gctx), _ptr(self.cvec), self.NC
+        s.idxA, s.idxB, s.sc = _ptr(self.idxA), _ptr(self.idxB if self.has_pb else None), _ptr(self.sc if self.NC else None)
+        s.maskbits, s.actions = _ptr(self.maskbits), _ptr(self.actions)
+        s.B, s.R, s.S, s.T, s.M, s.tstart, s.nchunk = self.B, self.R, self.S, self.T, self.M, self.tstart, self.nchunk
+        s.clip, s.temp = self.clip, self.temp
+        s.logp, s.lse = _ptr(self.logp), _ptr(self.lse)
+        return s
+
+    def forward(self):
+        lib = _lib.load()
+        s = self._struct()
+        _lib.check(lib.eamrl_reeval_forward(C.byref(s), _stream(self.buf)), "eamrl_reeval_forward")
+        return self.logp
+
+    def backward(self, glogp):
+        """-> (dbuf [B, M, P*E], dgctx or None, dcvec or None)"""
+        lib = _lib.load()
+        glogp = glogp.contiguous()
+        _chk(glogp, "grad of logp", torch.float32, (self.R, self.T))
+        dev = self.buf.device
+        dbuf = torch.zeros_like(self.buf)
+        dheads = torch.empty(self.R, self.T, self.E, dtype=torch.float32, device=dev)
+        dg = torch.zeros_like(self.gctx) if self.gctx is not None else None
+        dc = torch.zeros_like(self.cvec) if self.NC else None
+        s = self._struct()
+        E4 = self.E * 4
+        base = dbuf.data_ptr()
+        s.glogp, s.dheads = _ptr(glogp), _ptr(dheads)
+        s.dK, s.dV, s.dLp, s.dPa = (C.c_void_p(base + i * E4) for i in range(4))
+        s.dPb = C.c_void_p(base + 4 * E4) if self.has_pb else None
+        s.ldg = dbuf.shape[2]
+        s.dgctx, s.dCvec = _ptr(dg), _ptr(dc)
+        _lib.check(lib.eamrl_reeval_backward(C.byref(s), _stream(self.buf)), "eamrl_reeval_backward")
+        return dbuf, dg, dc
+
+
+# ------------------------------------------------------------------------------------------------------
 # environment transitions
 # ------------------------------------------------------------------------------------------------------
 def tsp_step_(mask, first, cur, istep, action, done):

@@ -347,9 +347,117 @@ class _ChunkedReeval(torch.autograd.Function):
         return (None, None) + tuple(next(it) if x.requires_grad else None for x in leaves)
 
 
+# ------------------------------------------------------------------------------------------------------------
+# native (HIP) re-evaluation: forward and backward of all decode steps on fp32 MFMA (csrc/reeval.hip)
+# ------------------------------------------------------------------------------------------------------------
+_NATIVE_ENVS = ("tsp", "cvrp", "pctsp", "op", "cvrptw")
+
+
+def native_reeval_supported(policy, M: int) -> bool:
+    import os
+
+    from . import ops
+
+    dec = policy.decoder
+    return (os.environ.get("EAMRL_NATIVE_REEVAL", "1") != "0" and policy.env_name in _NATIVE_ENVS
+            and ops.reeval_supported(M, dec.embed_dim, dec.num_heads))
+
+
+@torch.no_grad()
+def replay_states(policy, td, actions, S: int, multistart: bool):
+    """What the env state is before every decode step of the given action rows, in the form the re-evaluation kernels
+    read it: mask bits [R, T, 4], the node(s) whose folded context rows enter the query (idxA / idxB [R, T], -1 = none) and
+    the state scalars sc [NC, R, T] multiplying the state columns of project_context.  TSP is closed-form in the
+    actions; the other envs replay their transition kernels step by step (eamrl_*_step_mask + eamrl_pack_mask_bits).
+    -> dict(maskbits, idxA, idxB, sc, tstart, placeholder)"""
+    from . import ops
+    from .policy import _env_step_, state_from_td
+
+    env_name = policy.env_name
+    R, T = actions.shape
+    dev = actions.device
+    actions = actions.contiguous()
+    if env_name == "tsp":
+        M = td["locs"].shape[1]
+        bits = ops.tsp_mask_bits(actions, M)
+        a32 = actions.to(torch.int32)
+        prev = torch.cat((torch.full((R, 1), -1, dtype=torch.int32, device=dev), a32[:, :-1]), 1)       # a_{t-1}
+        first = a32[:, :1].expand(R, T).contiguous()
+        sc, placeholder = None, False
+        if not multistart:       # step 0: the learned placeholder replaces both gathered rows (context.py:118-131)
+            first = first.clone()
+            first[:, 0] = -1
+            sc = torch.zeros(1, R, T, dtype=torch.float32, device=dev)
+            sc[0, :, 0] = 1.0
+            placeholder = True
+        return dict(maskbits=bits, idxA=first, idxB=prev.contiguous(), sc=sc, tstart=1 if multistart else 0,
+                    placeholder=placeholder)
+    st = state_from_td(env_name, td, S)
+    NC = 2 if env_name == "cvrptw" else 1
+    bits = torch.empty(R, T, 4, dtype=torch.int32, device=dev)
+    idxA = torch.empty(R, T, dtype=torch.int32, device=dev)
+    sc = torch.empty(NC, R, T, dtype=torch.float32, device=dev)
+    for t in range(T):
+        ops.pack_mask_bits_(st.mask, bits, t)
+        idxA[:, t] = st.cur
+        if env_name == "pctsp":          # prize still to collect, clamped at 0 (context.py:194-208)
+            sc[0, :, t] = (st.vcap - st.used).clamp_(min=0)
+        else:                            # free capacity (cvrp, cvrptw) / length still allowed (op: vcap = max_length[:, 0])
+            sc[0, :, t] = st.vcap - st.used
+        if env_name == "cvrptw":
+            sc[1, :, t] = st.time
+        _env_step_(st, actions[:, t].contiguous())
+    return dict(maskbits=bits, idxA=idxA, idxB=None, sc=sc, tstart=1 if multistart else 0, placeholder=False)
+
+
+class _NativeReeval(torch.autograd.Function):
+    """logp [R, T] = eamrl_reeval_forward(K, V, Lp, Pa, Pb, gctx, cvec | replayed states); backward = eamrl_reeval_backward."""
+
+    @staticmethod
+    def forward(ctx, K, V, Lp, Pa, Pb, gctx, cvec, meta):
+        from . import ops
+
+        parts = [K, V, Lp, Pa] + ([Pb] if Pb is not None else [])
+        buf = torch.cat([x.detach() for x in parts], -1).contiguous()
+        plan = ops.ReevalPlan(buf, Pb is not None, None if gctx is None else gctx.detach().contiguous(),
+                              None if cvec is None else cvec.detach().contiguous(), meta["idxA"], meta["idxB"], meta["sc"],
+                              meta["maskbits"], meta["actions"], meta["S"], meta["tstart"], meta["clip"], meta["temp"])
+        ctx.plan = plan
+        ctx.has = (Pb is not None, gctx is not None, cvec is not None)
+        return plan.forward()
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        dbuf, dg, dc = plan.backward(g)
+        E = plan.E
+        sl = [dbuf[..., i * E:(i + 1) * E] for i in range(5 if ctx.has[0] else 4)]
+        return (sl[0], sl[1], sl[2], sl[3], sl[4] if ctx.has[0] else None, dg if ctx.has[1] else None,
+                dc if ctx.has[2] else None, None)
+
+
+def _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip):
+    """Differentiable log-probs [R, T]: the weight folds (Lp = L Wout, Pa / Pb = emb x halves of project_context, state
+    columns) as small autograd GEMMs on the decoder tensors `t`, everything per (row, step) in the HIP kernels."""
+    E = t["emb"].shape[-1]
+    Wctx = t["Wctx"]
+    Lp = torch.matmul(t["L"], t["Wout"])
+    Pa = F.linear(t["emb"], Wctx[:, :E])
+    Pb = F.linear(t["emb"], Wctx[:, E:2 * E]) if policy.env_name == "tsp" else None
+    meta = replay_states(policy, td, actions, S, multistart)
+    if policy.env_name == "tsp":
+        cvec = F.linear(t["placeholder"][None], Wctx) if meta["placeholder"] else None            # [1, E]
+    else:
+        cvec = Wctx[:, E:].t()                                                                      # [NC, E] state columns
+    meta.update(actions=actions.contiguous(), S=S, clip=float(clip), temp=float(temperature))
+    return _NativeReeval.apply(t["K"], t["V"], Lp, Pa, Pb, t.get("gctx"), cvec, meta)
+
+
 def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, temperature=None, tanh_clipping=None,
-                            chunk_rows: int = 4096, multistart=None, checkpoint=None):
-    """Differentiable per-step log-probabilities of `actions` [R, T] (R = B or S*B rows in (s b) order).  multistart
+                            chunk_rows: int = 4096, multistart=None, checkpoint=None, native=None):
+    """Differentiable per-step log-probabilities of `actions` [R, T] (R = B or S*B rows in (s b) order).  native
+    (default: where supported -- TSP / CVRP / PCTSP / OP / CVRPTW, graphs up to 112 nodes): forward and backward of the
+    decode steps run in the HIP re-evaluation kernels; otherwise (and as the cross-check) PyTorch autograd ops.  multistart
     (default: num_starts > 1): the first column is the start node and gets log-prob 0; False with num_starts > 1 is
     the multi-sample layout (every column a decision).  checkpoint (default: by size): keep no activations in the
     forward and recompute chunk by chunk in the backward.  Returns logp [R, T]."""
@@ -364,6 +472,10 @@ def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, tempe
     if multistart is None:
         multistart = S > 1
     env_name = policy.env_name
+    if native is None:
+        native = native_reeval_supported(policy, M)
+    if native:
+        return _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip)
     static = {k: td[k] for k in _STATE_KEYS[env_name]}
     # rows are processed in chunks of whole start-groups so that memory stays bounded ([rows, H, T, M] scores)
     starts_per_chunk = max(1, chunk_rows // B)

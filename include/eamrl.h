@@ -229,6 +229,39 @@ int eamrl_pointer_attention(const float* query, const float* key, const float* v
                             const uint8_t* mask, int mask_per_query, const float* Wout, const float* bout, float* logits,
                             int64_t B, int L, int M, int E, int H, int mask_inner, void* stream);
 
+/* ---- teacher-forced re-evaluation: the gradient path of training ------------------------------------- */
+
+/* All decode steps of finished rollouts at once, `policy(td, env, actions=...)` with decode type "evaluate"
+ * [models/common/constructive/base.py:203-229, utils/decoding.py:452-465], forward and backward.  Rows are the rollout's
+ * R = S * B rows in "(s b)" order (row r belongs to instance r % B); per (row, step) the caller supplies what the env state
+ * would be (obtained by replaying the env transitions: eamrl_*_step_mask + eamrl_pack_mask_bits, or eamrl_tsp_mask_bits):
+ *   maskbits [R][T][4]   bit n of the 128-bit word = node n feasible at that step (graphs up to 112 nodes)
+ *   idxA / idxB [R][T]   node whose Pa / Pb row enters the context query, -1 = none (idxB may be NULL)
+ *   sc [NC][R][T]        state scalars multiplying the state columns Cvec [NC][E] (free capacity, time, placeholder switch)
+ * query = Pa[idxA] + Pb[idxB] + gctx + sum_k sc_k Cvec_k; the rest is the decode step of eamrl_am_decode_step with the same
+ * weight folds (Lp = logit key times project_out).  Steps t < tstart (the multistart start column) get log-prob 0.
+ * Not bit-exact by contract: hardware exp / log, tile-order sums; log-probs within 1e-5 of the rollout's. */
+typedef struct eamrl_reeval {
+    const float *K, *V, *Lp, *Pa, *Pb; int64_t ld;          /* [B][M][.] fp32, common row stride ld (floats), 16-byte aligned rows */
+    const float* gctx; const float* Cvec; int NC;           /* [B][E] or NULL; [NC][E] (NC <= 4) */
+    const int32_t* idxA; const int32_t* idxB; const float* sc;
+    const uint32_t* maskbits; const int64_t* actions;       /* actions [R][T] */
+    int64_t B, R; int S, T, M, tstart, nchunk; float clip, temp;      /* nchunk: workgroups per instance (rows split) */
+    float* logp; float* lse;                                /* [R][T]: forward writes both; backward reads lse */
+    const float* glogp; float* dheads;                      /* backward: dL/dlogp [R][T]; scratch [R][T][E] */
+    float *dK, *dV, *dLp, *dPa, *dPb; int64_t ldg;          /* gradients [B][M][.] (row stride ldg), ACCUMULATED into (+=) */
+    float *dgctx, *dCvec;                                   /* [B][E] or NULL, [NC][E]; accumulated */
+} eamrl_reeval;
+
+int eamrl_reeval_supported(int M, int E, int H);                  /* 1 for M <= 112, E = 128, H = 8 */
+int eamrl_reeval_forward(const eamrl_reeval* p, void* stream);    /* -> logp, lse */
+int eamrl_reeval_backward(const eamrl_reeval* p, void* stream);   /* glogp, lse -> dK dV dLp dPa dPb dgctx dCvec */
+
+/* bits[(r * T + t) * 4 + n / 32] bit (n % 32) = mask[r][n] for step t (call after every replayed env transition). */
+int eamrl_pack_mask_bits(const uint8_t* mask, uint32_t* bits, int64_t R, int M, int T, int t, void* stream);
+/* TSP: all T steps from the action rows (node n feasible at step t iff not among a_0 .. a_{t-1})  [tsp/env.py:62-88]. */
+int eamrl_tsp_mask_bits(const int64_t* actions, uint32_t* bits, int64_t R, int M, int T, void* stream);
+
 /* ---- per-step decode ------------------------------------------------------------------------------ */
 
 /* The decoder cache of one batch (AttentionModelDecoder._precompute_cache, zoo/am/decoder.py:206-235),
