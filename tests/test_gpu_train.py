@@ -228,7 +228,7 @@ def test_native_reevaluation_matches_autograd(cfg, env_name, N, B, ns, ms):
     # gradient 0 -- are measured against the global gradient norm), and no element further than 5e-4 of the tensor's scale
     gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in res[1][1].values())))
     top = max(float(g.abs().max()) for g in res[1][1].values())
-    loose = 50.0 if env_name == "cvrptw" else 1.0     # cvrptw: unscaled inputs, an ill-conditioned network (see the oracle tests)
+    loose = 300.0 if env_name == "cvrptw" else 1.0    # cvrptw: unscaled inputs, an ill-conditioned network (see the oracle tests)
     for k in res[1][1]:
         ref, got = res[1][1][k].double(), res[0][1][k].double()
         rel = float((got - ref).norm()) / max(float(ref.norm()), 1e-2 * gnorm)
