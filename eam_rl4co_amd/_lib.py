@@ -90,6 +90,10 @@ PROTOTYPES = {
                              _vp, _vp, _vp, _vp, _vp, _vp],
     "eamrl_am_rollout": [_i32, C.POINTER(Cache), C.POINTER(State), _i64, _i32, _vp, _vp, _i32, _f32, _f32, _i32, _f32, _i32,
                          _vp, _vp, _vp, _vp, _vp],
+    "eamrl_exp1_noise": [C.c_uint64, _vp, _vp, _i64, _i32, _i32, _vp],
+    "eamrl_rollout_rng_native": [_i32, C.POINTER(Cache), _i64],
+    "eamrl_am_rollout_seeded": [_i32, C.POINTER(Cache), C.POINTER(State), _i64, C.c_uint64, _vp, _vp, _f32, _f32, _i32,
+                                _vp, _vp, _vp, _vp, _vp],
     "eamrl_tour_length": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
     "eamrl_sum_logp": [_vp, _i64, _vp, _i64, _i32, _vp],
     "eamrl_check_solution": [_i32, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp],

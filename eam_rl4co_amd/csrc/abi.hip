@@ -347,7 +347,7 @@ __attribute__((visibility("default"))) int eamrl_mean_nodes(const float* emb, fl
 
 static int fill_args(const char* what, int env, const eamrl_cache* c, const eamrl_state* s, int64_t R, int mode,
                      const float* noise, const int64_t* given, float clip, float temp, int top_k, float top_p,
-                     uint32_t* status, DecArgs& a)
+                     uint32_t* status, DecArgs& a, bool seeded = false)
 {
     REQUIRE(c && s, what);
     REQUIRE(env >= EAMRL_ENV_TSP && env <= EAMRL_ENV_CVRPTW, what);
@@ -366,7 +366,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
     if (env == EAMRL_ENV_PCTSP) REQUIRE(s->used && s->vcap && c->M >= 2, what);
     if (env == EAMRL_ENV_OP) REQUIRE(s->used && s->vcap && c->M >= 2, what);
     if (env == EAMRL_ENV_CVRPTW) REQUIRE(s->used && s->vcap && s->time && c->M >= 2, what);
-    if (mode == EAMRL_SAMPLE) REQUIRE(noise != nullptr, what);
+    if (mode == EAMRL_SAMPLE) REQUIRE(noise != nullptr || seeded, what);
     if (mode == EAMRL_EVALUATE) REQUIRE(given != nullptr, what);
     a = DecArgs{};
     a.K = c->K; a.V = c->V; a.Lp = c->Lp; a.Pa = c->Pa; a.Pb = c->Pb; a.cvec = c->cvec; a.gctx = c->gctx;
@@ -374,6 +374,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
     a.first = s->first; a.cur = s->cur; a.istep = s->istep; a.used = s->used; a.vcap = s->vcap; a.demand = s->demand;
     a.mask = s->mask; a.visited = s->visited; a.done = s->done;
     a.rem = s->rem; a.dyn = c->dyn; a.locs = s->locs; a.time = s->time; a.tw = s->tw; a.dur = s->dur;
+    a.seed = 0; a.seed_dev = nullptr; a.use_rng = 0;
     a.R = R; a.mode = mode; a.noise = noise; a.given = given; a.clip = clip; a.temp = temp; a.top_k = top_k; a.top_p = top_p; a.status = status;
     return 0;
 }
@@ -423,9 +424,52 @@ __attribute__((visibility("default"))) int eamrl_am_rollout(int env, const eamrl
     a.fuse_env = 1; a.t_max = t_max; a.t_given = t_given;
     a.action = actions; a.logp = logps; a.steps_out = steps_out;
     const bool filtering = top_k > 0 || (top_p > 0.0f && top_p < 1.0f);        // only the streaming kernel filters
+    if (!g_debug[11] && !filtering && rollout_ms_mfma_supports(env, a))
+        return launched(launch_rollout_ms_mfma(a, (hipStream_t)stream), "eamrl_am_rollout");
     if (!g_debug[1] && !filtering && rollout_resident_supports(env, a))
         return launched(launch_rollout_resident(env, a, (hipStream_t)stream), "eamrl_am_rollout");
     return launched(launch_rollout_stream(env, a, (hipStream_t)stream), "eamrl_am_rollout");
+}
+
+__attribute__((visibility("default"))) int eamrl_exp1_noise(uint64_t seed, const uint64_t* seed_dev, float* noise, int64_t R,
+                                                           int T, int M, void* stream)
+{
+    REQUIRE(noise && R >= 0 && T > 0 && M > 0, "eamrl_exp1_noise");
+    return launched(launch_exp1_noise(seed, seed_dev, noise, R, T, M, (hipStream_t)stream), "eamrl_exp1_noise");
+}
+
+__attribute__((visibility("default"))) int eamrl_rollout_rng_native(int env, const eamrl_cache* cache_host, int64_t R)
+{
+    if (!cache_host || R <= 0 || g_debug[11]) return 0;
+    DecArgs a{};
+    a.B = cache_host->B; a.M = cache_host->M; a.E = cache_host->E; a.H = cache_host->H; a.ld = cache_host->ld; a.R = R;
+    return rollout_ms_mfma_supports(env, a) ? 1 : 0;
+}
+
+__attribute__((visibility("default"))) int eamrl_am_rollout_seeded(int env, const eamrl_cache* cache_host,
+                                                                  const eamrl_state* state_host, int64_t R, uint64_t seed,
+                                                                  const uint64_t* seed_dev, float* noise_scratch,
+                                                                  float tanh_clip, float temperature,
+                                                                  int t_max, int64_t* actions, float* logps,
+                                                                  int32_t* steps_out, uint32_t* status, void* stream)
+{
+    DecArgs a;
+    int rc = fill_args("eamrl_am_rollout_seeded", env, cache_host, state_host, R, EAMRL_SAMPLE, nullptr, nullptr, tanh_clip,
+                       temperature, 0, 0.0f, status, a, true);
+    if (rc) return rc;
+    REQUIRE(actions && logps && steps_out && a.done && t_max > 0, "eamrl_am_rollout_seeded");
+    a.fuse_env = 1; a.t_max = t_max; a.t_given = 0;
+    a.action = actions; a.logp = logps; a.steps_out = steps_out;
+    if (!g_debug[11] && rollout_ms_mfma_supports(env, a)) {
+        a.seed = seed; a.seed_dev = seed_dev; a.use_rng = 1;
+        return launched(launch_rollout_ms_mfma(a, (hipStream_t)stream), "eamrl_am_rollout_seeded");
+    }
+    // kernels without in-place noise: the same draws as a tensor in the caller's scratch
+    REQUIRE(noise_scratch != nullptr, "eamrl_am_rollout_seeded (noise_scratch [R][t_max][M] needed for this shape)");
+    rc = launch_exp1_noise(seed, seed_dev, noise_scratch, R, t_max, a.M, (hipStream_t)stream);
+    if (rc) return launched(rc, "eamrl_am_rollout_seeded");
+    return eamrl_am_rollout(env, cache_host, state_host, R, EAMRL_SAMPLE, noise_scratch, nullptr, 0, tanh_clip, temperature, 0,
+                            0.0f, t_max, actions, logps, steps_out, status, stream);
 }
 
 __attribute__((visibility("default"))) int eamrl_tour_length(const float* locs, const int64_t* actions, float* reward,

@@ -19,6 +19,8 @@ struct DecArgs {
     float* time; const float* tw; const float* dur;   // CVRPTW: clock [R], windows [B][M][2], service times [B][M]
     // call
     int64_t R; int mode; const float* noise; const int64_t* given; int t_given;
+    uint64_t seed; const uint64_t* seed_dev; int use_rng;   // SAMPLE without a noise tensor: exp1_noise4(seed ^ *seed_dev, row,
+                                                            // step, node / 4) (dmath.hpp); seed_dev may be null
     float clip, temp; int fuse_env; int t_max;
     int top_k; float top_p;      // process_logits filtering (0 = off); handled by the step / streaming kernels
     int64_t* action; float* logp; float* logprobs_all; float* logits_raw;

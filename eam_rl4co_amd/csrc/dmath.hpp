@@ -109,6 +109,40 @@ __device__ __forceinline__ f32x2 d_expf2_nonpos(f32x2 x)
     return res;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Counter-based Exp(1) noise for sampling without a noise tensor (the reference draws inside the step: torch.multinomial ==
+// argmax(p / q), q ~ Exp(1), utils/decoding.py:403-417).  Philox4x32-10 on the counter (node / 4, step, row) with the call's
+// 64-bit seed as key gives the four 32-bit words of nodes 4 i .. 4 i + 3; word x -> u = (2 (x >> 9) + 1) 2^-24 in (0, 1)
+// (exact in fp32) -> q = -d_logf(u).  Integer arithmetic and the defined log only: the CPU oracle (orc_exp1_noise) and every
+// kernel produce the same bits, so a rollout with in-kernel noise equals the rollout fed with eamrl_exp1_noise's tensor.
+// ---------------------------------------------------------------------------------------------------------------------
+struct u32x4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float d_logf(float x);
+__device__ __forceinline__ float exp1_from_bits(uint32_t x)
+{
+    const float u = (float)(2u * (x >> 9) + 1u) * 5.9604644775390625e-8f;      // * 2^-24, exact
+    return 0.0f - d_logf(u);
+}
+// noise of nodes 4 quad .. 4 quad + 3 of (row, step)
+__device__ __forceinline__ void exp1_noise4(uint64_t seed, int64_t row, int step, int quad, float (&out)[4])
+{
+    const u32x4 r = philox4x32_10((uint32_t)quad, (uint32_t)step, (uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)seed,
+                                  (uint32_t)(seed >> 32));
+    out[0] = exp1_from_bits(r.x); out[1] = exp1_from_bits(r.y); out[2] = exp1_from_bits(r.z); out[3] = exp1_from_bits(r.w);
+}
+
 // log(x), x a normal positive number.
 __device__ __forceinline__ float d_logf(float x)
 {

@@ -1,0 +1,457 @@
+// Start-sharing whole-rollout kernel on fp32 MFMA for multistart batches (POMO: R = S * B rows in "(s b)" order, TSP).
+//
+// One workgroup of 8 wavefronts owns ONE INSTANCE and rolls out all its S starts together: at every decode step the S
+// context queries go against the instance's glimpse keys / values / folded logit keys as dense [S,16]x[16,M], [S,M]x[M,16]
+// and [S,128]x[128,M] products on v_mfma_f32_16x16x4_f32 (S queries sharing one K/V/L tile is the fp32-FLOP
+// bound case).  K, V and Lp live in registers as MFMA fragments for the whole episode; LDS holds the per-start state (mask
+// bit sets, current / first node) and the 16-query tiles being processed.
+//
+// The arithmetic is the canonical order of DESIGN.md 2, bit for bit what k_rollout_resident / k_decode_step / the oracle
+// compute -- the MFMA accumulates its k dimension as an ordered fma chain, so only the tiling had to be arranged:
+//   scores   s = chain_d(q, K[n]) / 4: q is pre-scaled by the power of two; S^T = K Q^T tiles (lane = query, registers = keys)
+//   glimpse  four node chunks of ceil(M / 4): one accumulator per chunk for A_g = chain_n(w, V) and one (against a row of
+//            ones) for Z_g = sequential sum of w; a k-step that straddles a chunk boundary is issued for both chunks with
+//            the other chunk's weights zeroed (fma(0, v, acc) == acc);  heads = (((A0+A1)+A2)+A3) / (((Z0+Z1)+Z2)+Z3)
+//   logits   four column chunks of 32: one accumulator per chunk (8 k-steps each), u = ((c0+c1)+c2)+c3
+//   finish   u / sqrt(E), 10 tanh, mask, / temperature, log-softmax with the lane tree (keys of a tile sit 4 per lane in
+//            natural order: the tree's levels are two in-lane adds, two cross-lane adds, then the tile sums pairwise),
+//            greedy = first node equal to the maximum, sampling = first node with the largest p / noise
+// Noise: the caller's [R][t_max][M] tensor, or computed in place from (seed, row, step, node) (exp1_noise4, dmath.hpp).
+//
+// Reference loop replaced: rl4co/models/common/constructive/base.py:236-250 with the multistart layout of
+// rl4co/utils/decoding.py:284-344 and rl4co/models/zoo/am/decoder.py:183-198 (K/V/L shared by the S queries of an instance).
+#include "kernels.hpp"
+
+namespace eamrl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int ME = 128, MH = 8;
+constexpr int TS = 140, TG = 34;      // A-layout tile buffers [16][TS]: element (j, c) at j * TS + (c & 3) * TG + (c >> 2)
+constexpr int SMAX = 128;             // starts per instance
+
+__device__ __forceinline__ f32x4 mf(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 z4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+// combine over the four lane groups (lanes l, l^16, l^32, l^48): first the ^16 partner, then the ^32 one -- the order of the
+// lane tree's levels 4 and 8 for keys laid out 4 per lane
+__device__ __forceinline__ float group_max(float v)
+{
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = vmax_raw(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmax_raw(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float group_sum(float v)
+{
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ int group_min(int v)
+{
+    auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = min((int)a[0], (int)a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return min((int)b[0], (int)b[1]);
+}
+
+// CC: the node-chunk length ceil(M / 4) as a compile-time value (0: run time).  With it every "does k-step t touch chunk g"
+// decision folds away; left to run time the ~100 uniform conditions are hoisted out of the loops into SGPRs that spill
+// (measured: 256 VGPRs + scratch vs 167 VGPRs), so the common sizes get their own instantiation.
+template <int RTT, int CC>
+__global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
+{
+    __shared__ __attribute__((aligned(16))) float QT[16 * TS];
+    __shared__ __attribute__((aligned(16))) float HT[16 * TS];
+    __shared__ float RED[8][16], RED2[8][16], LPS[16];
+    __shared__ int REDI[8][16], SEL[16];
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[SMAX][4];
+    __shared__ int s_cur[SMAX], s_first[SMAX], s_istep[SMAX], s_cnt[SMAX], s_done[SMAX];
+    __shared__ uint32_t s_flags;
+    extern __shared__ __attribute__((aligned(16))) float LPF[];    // [RTT waves][32 k-steps][64 lanes]: the logit-key (Lp) A fragments
+                                                                    // (kept in LDS, lane-linear: 32 VGPRs fewer per wave)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, G = lane >> 4, pi = 4 * (j & 3) + (j >> 2);
+    const int M = a.M;
+    const int64_t b = blockIdx.x;
+    const int64_t ld = a.ld;
+    const int C = CC > 0 ? CC : (M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
+    const float sqrtE = __builtin_sqrtf((float)ME);
+    const uint64_t seed = a.seed ^ ((a.use_rng && a.seed_dev) ? *a.seed_dev : 0ull);
+    const int b1 = C, b2 = 2 * C, b3 = 3 * C;      // node chunk boundaries
+    uint64_t cgbits = 0;                            // chunk id (2 bits) of this lane's node 4 t + G, t = 0 .. 4 RTT - 1
+#pragma unroll
+    for (int t = 0; t < 4 * RTT; ++t) {
+        const int n = 4 * t + G;
+        cgbits |= (uint64_t)((n >= b1) + (n >= b2) + (n >= b3)) << (2 * t);
+    }
+
+    // ---- instance operands as MFMA fragments (once) ------------------------------------------------------------------------
+    // wave h: kf[kt][t'] = K[16 kt + pi(j)][16 h + 4 t' + G] (scores A operand, keys in pi order so that accumulator register r
+    //         of lane group G is key 16 kt + 4 r + G = the B operand of value k-step 4 kt + r);  vtf[t] = V[4 t + G][16 h + j]
+    // wave w < RTT: lpf[t] = Lp[16 w + j][4 t + G] (logit A operand, keys in natural order)
+    float kf[RTT][4], vtf[4 * RTT];
+#pragma unroll
+    for (int kt = 0; kt < RTT; ++kt) {
+        const int n = 16 * kt + pi;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) kf[kt][t] = n < M ? a.K[(b * M + n) * ld + 16 * wv + 4 * t + G] : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < 4 * RTT; ++t) {
+        const int n = 4 * t + G;
+        vtf[t] = n < M ? a.V[(b * M + n) * ld + 16 * wv + j] : 0.0f;
+    }
+    float* lpf = LPF + wv * 32 * 64 + lane;       // lpf[64 * t]
+    if (wv < RTT) {
+        const int n = 16 * wv + j;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) lpf[64 * t] = n < M ? a.Lp[(b * M + n) * ld + 4 * t + G] : 0.0f;
+    }
+    // ---- per-start state ----------------------------------------------------------------------------------------------------
+    for (int s = tid; s < S; s += blockDim.x) {
+        const int64_t r = (int64_t)s * a.B + b;
+        uint32_t w[4] = {0, 0, 0, 0};
+        int cnt = 0;
+        for (int n = 0; n < M; ++n)
+            if (a.mask[r * M + n]) { w[n >> 5] |= 1u << (n & 31); ++cnt; }
+        s_bits[s][0] = w[0]; s_bits[s][1] = w[1]; s_bits[s][2] = w[2]; s_bits[s][3] = w[3];
+        s_cur[s] = (int)a.cur[r];
+        s_first[s] = (int)a.first[r];
+        s_istep[s] = (int)a.istep[r];
+        s_cnt[s] = cnt;
+        s_done[s] = a.done[r] != 0;
+    }
+    if (tid == 0) s_flags = 0;
+    __syncthreads();
+
+    const int nqt = (S + 15) >> 4;
+    int t = 0;
+    for (;;) {
+        int active = 0;
+        for (int s = tid; s < S; s += blockDim.x) active |= !s_done[s];
+        if (!__syncthreads_or(active) || t >= a.t_max) break;
+        for (int qt = 0; qt < nqt; ++qt) {
+            // ---- q~ tile: 0.25 * ((Pa[first] + Pb[cur]) + gctx), or 0.25 * (c0 + gctx) before the first node is chosen ----------
+            {
+                const int jq = tid >> 5, e4 = tid & 31, s = 16 * qt + jq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (s < S && !s_done[s]) {
+                    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.gctx) g4 = *reinterpret_cast<const float4*>(a.gctx + b * ME + 4 * e4);
+                    if (s_istep[s] == 0) {
+                        const float4 c4 = *reinterpret_cast<const float4*>(a.cvec + 4 * e4);
+                        v = make_float4(c4.x + g4.x, c4.y + g4.y, c4.z + g4.z, c4.w + g4.w);
+                    } else {
+                        const float4 p = *reinterpret_cast<const float4*>(a.Pa + (b * M + s_first[s]) * ld + 4 * e4);
+                        const float4 c4 = *reinterpret_cast<const float4*>(a.Pb + (b * M + s_cur[s]) * ld + 4 * e4);
+                        v = make_float4((p.x + c4.x) + g4.x, (p.y + c4.y) + g4.y, (p.z + c4.z) + g4.z, (p.w + c4.w) + g4.w);
+                    }
+                }
+                float* p = QT + jq * TS + e4;
+                p[0] = 0.25f * v.x; p[TG] = 0.25f * v.y; p[2 * TG] = 0.25f * v.z; p[3 * TG] = 0.25f * v.w;
+            }
+            const int sq = 16 * qt + j;                           // this lane's start (query j of the tile)
+            const bool live = sq < S && !s_done[sq];
+            uint4 mb = make_uint4(0, 0, 0, 0);
+            if (live) mb = *reinterpret_cast<const uint4*>(&s_bits[sq][0]);
+            __syncthreads();
+            // ---- glimpse of head wv ------------------------------------------------------------------------------------------
+            {
+                const float* qp = QT + j * TS + G * TG + 4 * wv;
+                const float2 qlo = *reinterpret_cast<const float2*>(qp), qhi = *reinterpret_cast<const float2*>(qp + 2);
+                f32x4 s[RTT];
+#pragma unroll
+                for (int kt = 0; kt < RTT; ++kt) s[kt] = mf(kf[kt][0], qlo.x, z4());
+#pragma unroll
+                for (int kt = 0; kt < RTT; ++kt) s[kt] = mf(kf[kt][1], qlo.y, s[kt]);
+#pragma unroll
+                for (int kt = 0; kt < RTT; ++kt) s[kt] = mf(kf[kt][2], qhi.x, s[kt]);
+#pragma unroll
+                for (int kt = 0; kt < RTT; ++kt) s[kt] = mf(kf[kt][3], qhi.y, s[kt]);
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < RTT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n0 = 16 * kt + 4 * r;              // + G: the same 32-bit word
+                        const uint32_t w = (n0 >> 5) == 0 ? mb.x : (n0 >> 5) == 1 ? mb.y : (n0 >> 5) == 2 ? mb.z : mb.w;
+                        s[kt][r] = ((w >> ((n0 & 31) + G)) & 1u) ? s[kt][r] : -INFINITY;
+                        m = vmax_raw(m, s[kt][r]);
+                    }
+                m = group_max(m);
+                // softmax weights; a masked node has s = -inf and d_expf2_nonpos gives it exactly 0 (as the canonical select does)
+#pragma unroll
+                for (int kt = 0; kt < RTT; ++kt) {
+                    const f32x2 e01 = d_expf2_nonpos((f32x2){s[kt][0] - m, s[kt][1] - m});
+                    const f32x2 e23 = d_expf2_nonpos((f32x2){s[kt][2] - m, s[kt][3] - m});
+                    s[kt] = (f32x4){e01.x, e01.y, e23.x, e23.y};
+                }
+                // Value product per node chunk g = [g C, (g+1) C), chunks in ascending order: `cur` accumulates the chunk in
+                // progress (A_g against V^T, Z_g against a row of ones), `tot` the finished ones as ((A0 + A1) + A2) + A3.
+                // K-step t holds nodes 4 t .. 4 t + 3 (this lane: 4 t + G); where it straddles a chunk boundary it is issued
+                // once per chunk with the other chunk's weights zeroed.
+                f32x4 cur_o = z4(), cur_z = z4(), tot_o = z4(), tot_z = z4();
+                int curc = 0;
+                bool first = true;
+#pragma unroll
+                for (int t4 = 0; t4 < 4 * RTT; ++t4) {
+                    if (4 * t4 < M) {
+                        const float w = s[t4 >> 2][t4 & 3];
+                        const int cme = (int)((cgbits >> (2 * t4)) & 3ull);            // chunk of this lane's node 4 t4 + G
+                        // CC > 0: node slots beyond M carry zero weights and zero values, so the k-step's last slot decides
+                        const int nlast = (CC > 0 || 4 * t4 + 3 < M) ? 4 * t4 + 3 : M - 1;
+                        const int cA = (4 * t4 >= b1) + (4 * t4 >= b2) + (4 * t4 >= b3);
+                        const int cB = (nlast >= b1) + (nlast >= b2) + (nlast >= b3);
+#pragma unroll
+                        for (int sub = 0; sub < 4; ++sub) {
+                            const int c = cA + sub;
+                            if (c <= cB) {                                                // (uniform)
+                                if (c != curc) {                                          // chunk curc is complete
+                                    tot_o = first ? cur_o : tot_o + cur_o;
+                                    tot_z = first ? cur_z : tot_z + cur_z;
+                                    first = false; curc = c; cur_o = z4(); cur_z = z4();
+                                }
+                                const float wg = (cme == c) ? w : 0.0f;
+                                cur_o = mf(vtf[t4], wg, cur_o);
+                                cur_z = mf(1.0f, wg, cur_z);
+                            }
+                        }
+                    }
+                }
+                tot_o = first ? cur_o : tot_o + cur_o;
+                tot_z = first ? cur_z : tot_z + cur_z;
+                // lane (query j, G), register r -> head column e = 4 G + r -> A layout (g = r, t = 4 wv + G)
+                float* hp = HT + j * TS + 4 * wv + G;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hp[r * TG] = tot_o[r] / tot_z[r];
+            }
+            __syncthreads();
+            // ---- logits of key tile wv, finish ----------------------------------------------------------------------------
+            float x[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            bool fe[4] = {false, false, false, false};
+            float nz[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+            const int nbase = 16 * wv + 4 * G;                       // this lane's keys: nbase + r
+            bool nan_seen = false;
+            if (wv < RTT) {
+                const float* hp = HT + j * TS + G * TG;
+                f32x4 c[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    c[g] = z4();
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const float2 lo = *reinterpret_cast<const float2*>(hp + 8 * g + 4 * u);
+                        const float2 hi = *reinterpret_cast<const float2*>(hp + 8 * g + 4 * u + 2);
+                        c[g] = mf(lpf[64 * (8 * g + 4 * u + 0)], lo.x, c[g]);
+                        c[g] = mf(lpf[64 * (8 * g + 4 * u + 1)], lo.y, c[g]);
+                        c[g] = mf(lpf[64 * (8 * g + 4 * u + 2)], hi.x, c[g]);
+                        c[g] = mf(lpf[64 * (8 * g + 4 * u + 3)], hi.y, c[g]);
+                    }
+                }
+                if (a.mode == EAMRL_SAMPLE && live) {
+                    const int64_t r = (int64_t)sq * a.B + b;
+                    if (a.use_rng) {
+                        exp1_noise4(seed, r, t, nbase >> 2, nz);
+                    } else {
+                        const float* np_ = a.noise + (r * a.t_max + t) * (int64_t)M;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                            if (nbase + rr < M) nz[rr] = np_[nbase + rr];
+                    }
+                }
+                f32x2 v01, v23;
+                {
+                    const f32x4 u = ((c[0] + c[1]) + c[2]) + c[3];
+                    const f32x2 l01 = (f32x2){u[0], u[1]} / splat2(sqrtE), l23 = (f32x2){u[2], u[3]} / splat2(sqrtE);
+                    const uint32_t w = (nbase >> 5) == 0 ? mb.x : (nbase >> 5) == 1 ? mb.y : (nbase >> 5) == 2 ? mb.z : mb.w;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fe[r] = (w >> ((nbase & 31) + r)) & 1u;
+                    nan_seen = (fe[0] && l01.x != l01.x) || (fe[1] && l01.y != l01.y) || (fe[2] && l23.x != l23.x) ||
+                               (fe[3] && l23.y != l23.y);
+                    v01 = (a.clip > 0.0f) ? d_tanhf2(l01) * splat2(a.clip) : l01;
+                    v23 = (a.clip > 0.0f) ? d_tanhf2(l23) * splat2(a.clip) : l23;
+                    v01.x = fe[0] ? v01.x : -INFINITY; v01.y = fe[1] ? v01.y : -INFINITY;
+                    v23.x = fe[2] ? v23.x : -INFINITY; v23.y = fe[3] ? v23.y : -INFINITY;
+                    if (a.temp != 1.0f) {
+                        asm volatile("" ::: "memory");
+                        v01 = v01 / splat2(a.temp);
+                        v23 = v23 / splat2(a.temp);
+                    }
+                }
+                x[0] = v01.x; x[1] = v01.y; x[2] = v23.x; x[3] = v23.y;
+                const float mx = group_max(vmax_raw(vmax_raw(x[0], x[1]), vmax_raw(x[2], x[3])));
+                if (G == 0) RED[wv][j] = mx;
+            }
+            __syncthreads();
+            float mq = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < RTT; ++w) mq = vmax_raw(mq, RED[w][j]);
+            float d[4] = {0.f, 0.f, 0.f, 0.f};                       // x - max
+            if (wv < RTT) {
+                const f32x2 d01 = (f32x2){x[0], x[1]} - splat2(mq), d23 = (f32x2){x[2], x[3]} - splat2(mq);
+                const f32x2 e01 = d_expf2_nonpos(d01), e23 = d_expf2_nonpos(d23);
+                d[0] = d01.x; d[1] = d01.y; d[2] = d23.x; d[3] = d23.y;
+                const float e0 = fe[0] ? e01.x : 0.0f, e1 = fe[1] ? e01.y : 0.0f, e2 = fe[2] ? e23.x : 0.0f, e3 = fe[3] ? e23.y : 0.0f;
+                const float ts = group_sum((e0 + e1) + (e2 + e3));      // lane tree levels 1, 2 (in lane), 4, 8 (lane groups)
+                if (G == 0) RED2[wv][j] = ts;
+            }
+            __syncthreads();
+            float lse, lp[4];
+            {
+                float T[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) T[w] = w < RTT ? RED2[w][j] : 0.0f;
+                const float Zl = ((T[0] + T[1]) + (T[2] + T[3])) + ((T[4] + T[5]) + (T[6] + T[7]));   // levels 16, 32; 64-blocks ascending
+                lse = d_logf(Zl);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lp[r] = fe[r] ? d[r] - lse : -INFINITY;
+            }
+            // ---- selection -------------------------------------------------------------------------------------------------
+            float key[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            float top = 0.0f - lse;                                   // greedy: the maximum log-prob is (mx - mx) - lse
+            if (a.mode == EAMRL_SAMPLE) {
+                if (wv < RTT) {
+                    const f32x2 k01 = d_expf2_nonpos((f32x2){lp[0], lp[1]}) / (f32x2){nz[0], nz[1]};
+                    const f32x2 k23 = d_expf2_nonpos((f32x2){lp[2], lp[3]}) / (f32x2){nz[2], nz[3]};
+                    key[0] = nbase + 0 < M ? k01.x : -INFINITY; key[1] = nbase + 1 < M ? k01.y : -INFINITY;
+                    key[2] = nbase + 2 < M ? k23.x : -INFINITY; key[3] = nbase + 3 < M ? k23.y : -INFINITY;
+                    const float km = group_max(vmax_raw(vmax_raw(key[0], key[1]), vmax_raw(key[2], key[3])));
+                    if (G == 0) RED[wv][j] = km;                      // (RED was last read before the previous barrier)
+                }
+                __syncthreads();
+                top = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < RTT; ++w) top = vmax_raw(top, RED[w][j]);
+            }
+            if (wv < RTT) {
+                int cand = 1 << 20;
+#pragma unroll
+                for (int r = 3; r >= 0; --r) {
+                    const bool hit = (a.mode == EAMRL_SAMPLE) ? (key[r] == top) : (nbase + r < M && lp[r] == top);
+                    if (hit) cand = nbase + r;
+                }
+                cand = group_min(cand);
+                if (G == 0) REDI[wv][j] = cand;
+            }
+            __syncthreads();
+            int sel = 1 << 20;
+#pragma unroll
+            for (int w = 0; w < RTT; ++w) sel = min(sel, REDI[w][j]);
+            if (a.mode == EAMRL_EVALUATE && live)
+                sel = (t < a.t_given) ? (int)a.given[((int64_t)sq * a.B + b) * a.t_given + t] : 0;
+            uint32_t fl = 0;
+            if (live) {
+                if (nan_seen) fl |= EAMRL_ST_NAN_LOGITS;
+                if (sel < 0 || sel >= M) { fl |= EAMRL_ST_INFEASIBLE; sel = 0; }
+                if (wv < RTT && sel >= nbase && sel < nbase + 4) LPS[j] = lp[sel - nbase];
+            }
+            if (wv == 0 && G == 0) SEL[j] = sel;
+            if (fl) atomicOr(&s_flags, fl);
+            __syncthreads();
+            // ---- env transition (TSPEnv._step, tsp/env.py:62-88) of the tile's 16 starts -------------------------------------
+            if (tid < 16) {
+                const int s = 16 * qt + tid;
+                if (s < S && !s_done[s]) {
+                    const int sl = SEL[tid];
+                    const int64_t r = (int64_t)s * a.B + b;
+                    a.action[r * a.t_max + t] = sl;
+                    a.logp[r * a.t_max + t] = LPS[tid];
+                    const uint32_t bit = 1u << (sl & 31);
+                    const uint32_t wd = s_bits[s][sl >> 5];
+                    if (!(wd & bit)) atomicOr(&s_flags, EAMRL_ST_INFEASIBLE);
+                    s_bits[s][sl >> 5] = wd & ~bit;
+                    if (s_istep[s] == 0) s_first[s] = sl;
+                    s_cur[s] = sl;
+                    s_istep[s] += 1;
+                    s_cnt[s] -= (wd & bit) != 0;
+                    s_done[s] = s_cnt[s] == 0;
+                }
+            }
+            // (the next tile's first barrier orders this against its readers; the tile buffers are rewritten only after it)
+        }
+        ++t;
+    }
+    // ---- final state -------------------------------------------------------------------------------------------------------------
+    __syncthreads();
+    for (int s = tid; s < S; s += blockDim.x) {
+        const int64_t r = (int64_t)s * a.B + b;
+        for (int n = 0; n < M; ++n) a.mask[r * M + n] = (s_bits[s][n >> 5] >> (n & 31)) & 1u;
+        a.cur[r] = s_cur[s];
+        a.first[r] = s_first[s];
+        a.istep[r] = s_istep[s];
+        a.done[r] = s_done[s] ? 1 : 0;
+        if (!s_done[s]) atomicOr(&s_flags, EAMRL_ST_STEP_OVERRUN);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        atomicMax(a.steps_out, t);
+        if (s_flags) atomicOr(a.status, s_flags);
+    }
+}
+
+template <int RTT, int CC>
+int launch_t(const DecArgs& a, int S, hipStream_t st)
+{
+    const size_t lds = (size_t)RTT * 32 * 64 * sizeof(float);
+    auto k = k_rollout_ms_mfma<RTT, CC>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 32 * 1024)) !=
+        hipSuccess)
+        return EAMRL_E_LAUNCH;
+    hipLaunchKernelGGL(k, dim3((unsigned)a.B), dim3(512), lds, st, a, S);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+}  // namespace
+
+bool rollout_ms_mfma_supports(int env, const DecArgs& a)
+{
+    if (env != EAMRL_ENV_TSP || a.E != ME || a.H != MH || a.M < 2 || a.M > 112 || a.ld % 4 != 0) return false;
+    if (a.R % a.B != 0) return false;
+    const int64_t S = a.R / a.B;
+    return S >= 2 && S <= SMAX && a.top_k == 0 && !(a.top_p > 0.0f && a.top_p < 1.0f);
+}
+
+int launch_rollout_ms_mfma(const DecArgs& a, hipStream_t st)
+{
+    const int S = (int)(a.R / a.B);
+    const int C = (a.M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
+    if (a.M <= 32) return C == 5 ? launch_t<2, 5>(a, S, st) : launch_t<2, 0>(a, S, st);
+    if (a.M <= 64) return C == 13 ? launch_t<4, 13>(a, S, st) : launch_t<4, 0>(a, S, st);
+    return C == 25 ? launch_t<7, 25>(a, S, st) : C == 26 ? launch_t<7, 26>(a, S, st) : launch_t<7, 0>(a, S, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the same Exp(1) draws as a tensor (for kernels without in-place noise, and to pin the in-place path)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void k_exp1_noise(uint64_t seed0, const uint64_t* __restrict__ seed_dev, float* __restrict__ noise, int64_t R, int T,
+                             int M)
+{
+    const uint64_t seed = seed0 ^ (seed_dev ? *seed_dev : 0ull);
+    const int nq = (M + 3) >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * T * nq) return;
+    const int q = (int)(idx % nq);
+    const int64_t rt = idx / nq;
+    const int t = (int)(rt % T);
+    const int64_t r = rt / T;
+    float v[4];
+    exp1_noise4(seed, r, t, q, v);
+    for (int i = 0; i < 4 && 4 * q + i < M; ++i) noise[rt * M + 4 * q + i] = v[i];
+}
+
+int launch_exp1_noise(uint64_t seed, const uint64_t* seed_dev, float* noise, int64_t R, int T, int M, hipStream_t st)
+{
+    const int64_t n = R * T * ((M + 3) >> 2);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_exp1_noise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seed, seed_dev, noise, R, T, M);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+}  // namespace eamrl

@@ -890,14 +890,46 @@ def decode_step(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None,
     return action, logp, lps, lgs, status
 
 
+def exp1_noise(seed: int, R: int, T: int, M: int, device="cuda", seed_dev=None):
+    """[R, T, M] Exp(1) draws of the library's counter-based generator (eamrl_exp1_noise): what a seeded rollout uses.
+    seed_dev: optional int64 device tensor [1] XOR-ed into the seed on the device."""
+    lib = _lib.load()
+    out = torch.empty(R, T, M, dtype=torch.float32, device=device)
+    _need_gpu(out, "noise")
+    _lib.check(lib.eamrl_exp1_noise(C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), _ptr(seed_dev), _ptr(out), R, T, M,
+                                    _stream(out)), "eamrl_exp1_noise")
+    return out
+
+
 def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0,
-            t_max=None, top_k=0, top_p=0.0):
-    """Whole decode loop in one launch.  -> (actions [R,t_max], logps [R,t_max], info int32[2] = (steps, status))."""
+            t_max=None, top_k=0, top_p=0.0, seed=None, seed_dev=None):
+    """Whole decode loop in one launch.  -> (actions [R,t_max], logps [R,t_max], info int32[2] = (steps, status)).
+    Sampling takes its Exp(1) noise from `noise` [R, T, M] or, with `seed` (XOR the device word `seed_dev`), from the counter-based
+    generator -- in place where the kernel supports it (TSP multistart), else through a scratch tensor of the same draws."""
     lib = _lib.load()
     _validate_state(st, cache)
     R, M, dev = st.R, st.M, st.mask.device
     if t_max is None:
         t_max = {"tsp": M, "cvrp": 2 * M + 1, "sdvrp": 3 * M + 1, "pctsp": M + 1, "op": M + 1, "cvrptw": 2 * M + 1}[st.env_name]
+    if mode == "sampling" and noise is None:
+        if seed is None:
+            raise ValueError("rollout: sampling needs `noise` or `seed`")
+        if top_k or (0.0 < top_p < 1.0):
+            noise = exp1_noise(seed, R, int(t_max), M, dev, seed_dev)      # the filtering (streaming) kernel reads a tensor
+        else:
+            actions = torch.zeros(R, t_max, dtype=torch.int64, device=dev)
+            logps = torch.zeros(R, t_max, dtype=torch.float32, device=dev)
+            info = torch.zeros(2, dtype=torch.int32, device=dev)
+            cs, ss = cache.struct(), st.struct()
+            native = lib.eamrl_rollout_rng_native(ENVS[st.env_name], C.byref(cs), R)
+            scratch = None if native else torch.empty(R, t_max, M, dtype=torch.float32, device=dev)
+            _lib.check(lib.eamrl_am_rollout_seeded(ENVS[st.env_name], C.byref(cs), C.byref(ss), R,
+                                                   C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), _ptr(seed_dev), _ptr(scratch),
+                                                   float(clip),
+                                                   float(temp), int(t_max), _ptr(actions), _ptr(logps),
+                                                   C.c_void_p(info.data_ptr()), C.c_void_p(info.data_ptr() + 4),
+                                                   _stream(st.mask)), "eamrl_am_rollout_seeded")
+            return actions, logps, info
     t_given = 0
     if noise is not None:
         _chk(noise, "noise", torch.float32)

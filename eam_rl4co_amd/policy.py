@@ -748,8 +748,18 @@ class AttentionModelPolicy(nn.Module):
         if actions is not None:
             given = actions.to(torch.int64).contiguous()
             t_max = min(t_max, given.shape[1]) if given.shape[1] > 0 else t_max
+        seed = seed_dev = None
         if mode == "sampling":
-            if noise is None:
+            if noise is None and not store_all_logp:
+                # no noise tensor: the draws are a function of (seed, row, step, node), computed inside the rollout kernel
+                # where it can (ops.rollout).  Eagerly the seed comes from torch's CPU generator (torch.manual_seed
+                # reproduces it); under HIP-graph capture it is a device word refilled by a captured random_() per replay.
+                if torch.cuda.is_current_stream_capturing():
+                    seed = 0
+                    seed_dev = torch.empty(1, dtype=torch.int64, device=st.mask.device).random_()
+                else:
+                    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            elif noise is None:
                 noise = torch.empty(st.R, t_max, M, dtype=torch.float32, device=st.mask.device).exponential_(1)
             else:
                 noise = noise.to(device=st.mask.device, dtype=torch.float32)
@@ -765,7 +775,7 @@ class AttentionModelPolicy(nn.Module):
             info = None
         else:
             acts, lps, info = ops.rollout(st, cache, mode, noise=noise, given=given, clip=tanh_clipping,
-                                          temp=temperature, t_max=t_max, top_k=top_k, top_p=top_p)
+                                          temp=temperature, t_max=t_max, top_k=top_k, top_p=top_p, seed=seed, seed_dev=seed_dev)
         # Everything below is enqueued on the PADDED [R, t_max] arrays before the rollout's single host sync:
         # padding is depot visits with log-prob 0, which change neither the tour length (zero-length legs, and
         # x + 0 is exact in the lane tree), nor the log-likelihood sum, nor validity.

@@ -63,7 +63,8 @@ const char* eamrl_last_error(void);
  * key 3: 1 = eamrl_mha_encoder uses the one-row-per-thread kernel even where the blocked one applies.
  * key 7: 1 = eamrl_mha_encoder uses the matrix-core kernel (N <= 128; bit-identical, measured slower) instead of the VALU kernels.
  * key 10: 1 = eamrl_linear configures its epilogue at run time even where a compile-time variant applies.
- * key 6: 1 = eamrl_am_rollout does not use the start-sharing kernel for multistart batches (R = S*B rows). */
+ * key 6: 1 = eamrl_am_rollout does not use the start-sharing kernel for multistart batches (R = S*B rows).
+ * key 11: 1 = eamrl_am_rollout does not use the MFMA start-sharing kernel (TSP multistart) but the VALU ones. */
 int eamrl_debug_set(int key, int value);
 
 /* ---- environment state machines ---------------------------------------------------------------- */
@@ -329,6 +330,21 @@ int eamrl_am_rollout(int env, const eamrl_cache* cache_host, const eamrl_state* 
                      const float* noise, const int64_t* given, int t_given, float tanh_clip, float temperature,
                      int top_k, float top_p, int t_max, int64_t* actions, float* logps, int32_t* steps_out,
                      uint32_t* status, void* stream);
+
+/* Sampling without a noise tensor.  The Exp(1) draw of (row r, step t, node n) is a pure function of the call's seed:
+ * Philox4x32-10 on the counter (n / 4, t, r) with the seed as key, word n % 4 -> u = (2 (x >> 9) + 1) 2^-24 -> -log(u)
+ * with the library's defined log (csrc/dmath.hpp; the CPU oracle has the same function).  eamrl_exp1_noise writes the
+ * draws as a [R][T][M] tensor; eamrl_am_rollout_seeded == eamrl_am_rollout(EAMRL_SAMPLE) fed with that tensor, bit for
+ * bit, but the start-sharing kernel computes the draws in place (a POMO batch of 1024 x 100 starts x 100 nodes would need
+ * a 4 GB tensor).  eamrl_rollout_rng_native: 1 if this (env, cache shape, R) runs on a kernel with in-place noise
+ * (noise_scratch may then be NULL); otherwise noise_scratch [R][t_max][M] is filled and the tensor path runs.
+ * seed_dev (may be NULL): a device word XOR-ed into the seed when the kernel starts -- a launch recorded in a HIP graph gets a
+ * fresh seed per replay from memory, since its by-value arguments are frozen at capture. */
+int eamrl_exp1_noise(uint64_t seed, const uint64_t* seed_dev, float* noise, int64_t R, int T, int M, void* stream);
+int eamrl_rollout_rng_native(int env, const eamrl_cache* cache_host, int64_t R);
+int eamrl_am_rollout_seeded(int env, const eamrl_cache* cache_host, const eamrl_state* state_host, int64_t R, uint64_t seed,
+                            const uint64_t* seed_dev, float* noise_scratch, float tanh_clip, float temperature, int t_max, int64_t* actions,
+                            float* logps, int32_t* steps_out, uint32_t* status, void* stream);
 
 /* ---- reward ----------------------------------------------------------------------------------------- */
 

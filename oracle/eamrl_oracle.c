@@ -21,6 +21,7 @@
  *   orc_batchnorm_train ....... rl4co/models/nn/ops.py:45-47  (BatchNorm1d, training mode: batch statistics)
  *   orc_init_embed_* .......... rl4co/models/nn/env_embeddings/init.py:55-68,115-138
  *   orc_pointer_attention ..... rl4co/models/nn/attention.py:282-328 (PointerAttention.forward; the pointer= injection point)
+ *   orc_exp1_noise ............ the counter-based Exp(1) draws of in-kernel sampling (replaces torch.multinomial's, utils/decoding.py:403-417)
  *   orc_mean_nodes ............ rl4co/models/zoo/am/decoder.py:225-227 (embeddings.mean(1))
  *   orc_decode_step ........... rl4co/models/zoo/am/decoder.py:133-198 (_compute_q/_compute_kvl/forward),
  *                               rl4co/models/nn/env_embeddings/context.py:50-74,105-157,
@@ -148,6 +149,34 @@ ORC_API void orc_math_probe(const float* x, float* y_exp, float* y_log, float* y
         y_log[i] = (x[i] > 0.0f) ? d_logf(x[i]) : 0.0f;
         y_tanh[i] = d_tanhf(x[i]);
     }
+}
+
+/* Counter-based Exp(1) noise (csrc/dmath.hpp exp1_noise4): Philox4x32-10, counter (node / 4, step, row), key = seed;
+ * word x -> u = (2 (x >> 9) + 1) 2^-24 -> -d_logf(u).  noise [R][T][M]. */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+ORC_API void orc_exp1_noise(uint64_t seed, float* noise, long R, int T, int M)
+{
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < R; ++r)
+        for (int t = 0; t < T; ++t)
+            for (int q = 0; 4 * q < M; ++q) {
+                uint32_t c[4] = {(uint32_t)q, (uint32_t)t, (uint32_t)r, (uint32_t)((uint64_t)r >> 32)};
+                philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+                for (int i = 0; i < 4 && 4 * q + i < M; ++i) {
+                    const float u = (float)(2u * (c[i] >> 9) + 1u) * 5.9604644775390625e-8f;
+                    noise[((long)r * T + t) * M + 4 * q + i] = 0.0f - d_logf(u);
+                }
+            }
 }
 
 /* adjacent-pair tree inside 64-blocks, blocks ascending */

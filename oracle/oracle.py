@@ -181,6 +181,13 @@ def pointer_attention(query, key, value, logit_key, mask, Wout, bout=None, num_h
     return out
 
 
+def exp1_noise(seed, R, T, M):
+    """[R, T, M] Exp(1) draws of the counter-based generator (what the kernels compute in place for (seed, row, step, node))."""
+    out = np.empty((R, T, M), np.float32)
+    lib().orc_exp1_noise(C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), _p(out), C.c_long(R), C.c_int(T), C.c_int(M))
+    return out
+
+
 def mean_nodes(emb):
     emb = _f32(emb)
     B, M, E = emb.shape

@@ -136,6 +136,8 @@ def test_multistart_sampling_cvrp_and_select_best(oracle):
 
 
 @pytest.mark.parametrize("env_name,N,B,S", [("tsp", 20, 4, 2), ("tsp", 20, 3, 5), ("tsp", 50, 2, 7), ("tsp", 100, 2, 9),
+                                            ("tsp", 5, 3, 5), ("tsp", 16, 2, 16), ("tsp", 17, 2, 17), ("tsp", 33, 2, 33),
+                                            ("tsp", 64, 2, 20), ("tsp", 112, 1, 112), ("tsp", 100, 1, 128),
                                             ("cvrp", 20, 3, 3), ("cvrp", 100, 2, 6), ("cvrp", 127, 1, 5),
                                             ("sdvrp", 20, 3, 4), ("sdvrp", 100, 2, 5), ("pctsp", 20, 3, 4),
                                             ("pctsp", 100, 2, 6), ("cvrptw", 20, 3, 4), ("cvrptw", 100, 2, 5)])
@@ -160,13 +162,16 @@ def test_start_sharing_kernel_matches_oracle_and_single_row_kernel(oracle, env_n
         noise = torch.empty(B * S, 3 * M + 1, M).exponential_(1, generator=torch.Generator().manual_seed(N + S))
         kw["noise"] = noise.to(DEV)
     outs = []
-    for single in (0, 1):
+    # default (TSP: the MFMA start-sharing kernel) | VALU start-sharing kernel | one row per workgroup
+    for single, no_mfma in ((0, 0), (0, 1), (1, 1)):
         _lib.load().eamrl_debug_set(6, single)
+        _lib.load().eamrl_debug_set(11, no_mfma)
         try:
             outs.append(pol(td_cpu.to(DEV), env, phase="test", decode_type="multistart_" + mode,
                             return_sum_log_likelihood=False, **kw))
         finally:
             _lib.load().eamrl_debug_set(6, 0)
+            _lib.load().eamrl_debug_set(11, 0)
     o = oracle.policy_rollout(golden_weights(cfg), env_name, locs, demand, decode_type="multistart_" + mode,
                               num_starts=S, noise=None if noise is None else noise.numpy())
     for out in outs:

@@ -615,3 +615,92 @@ def test_full_size_cvrp500_properties():
     pts = torch.cat([locs[:, :1], locs.gather(1, acts[..., None].expand(-1, -1, 2))], 1)
     length = (pts.roll(-1, 1) - pts).norm(dim=-1).sum(1)
     np.testing.assert_allclose(-a["reward"].cpu().numpy(), length.cpu().numpy(), rtol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# sampling without a noise tensor: the counter-based Exp(1) generator
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,T,M,seed", [(3, 5, 20, 1), (7, 9, 101, 2 ** 40 + 12345), (2, 3, 7, 0), (4, 2, 128, 2 ** 63 + 5)])
+def test_exp1_noise_kernel_equals_oracle(oracle, R, T, M, seed):
+    from eam_rl4co_amd import ops
+
+    got = ops.exp1_noise(seed, R, T, M, DEV)
+    assert_bits_equal(got, oracle.exp1_noise(seed, R, T, M), "Exp(1) draws")
+    sd = torch.tensor([0x1234567], dtype=torch.int64, device=DEV)
+    assert_bits_equal(ops.exp1_noise(seed, R, T, M, DEV, seed_dev=sd), oracle.exp1_noise(seed ^ 0x1234567, R, T, M), "seed word")
+
+
+def test_exp1_noise_distribution():
+    from eam_rl4co_amd import ops
+
+    x = ops.exp1_noise(77, 256, 64, 100, DEV).double()
+    assert float(x.min()) > 0 and torch.isfinite(x).all()
+    assert abs(float(x.mean()) - 1.0) < 5e-3 and abs(float(x.var()) - 1.0) < 2e-2          # Exp(1): mean 1, variance 1
+    assert abs(float((x > 1.0).double().mean()) - np.exp(-1.0)) < 3e-3
+    a, b = ops.exp1_noise(77, 8, 4, 100, DEV), ops.exp1_noise(78, 8, 4, 100, DEV)
+    assert not torch.equal(a, b) and torch.equal(a, x[:8, :4].float())                      # counter-based: prefix-stable
+
+
+@pytest.mark.parametrize("cfg,env_name,N,B,S", [("pomo_tsp", "tsp", 20, 5, 20), ("pomo_tsp", "tsp", 50, 3, 50),
+                                                ("am_tsp", "tsp", 100, 2, 0), ("am_cvrp", "cvrp", 20, 4, 0),
+                                                ("am_cvrp", "cvrp", 50, 3, 6)])
+def test_seeded_sampling_equals_the_noise_tensor_path(cfg, env_name, N, B, S):
+    """policy(..., decode_type=sampling) without `noise`: the draws come from (seed, row, step, node) -- inside the MFMA
+    start-sharing kernel for TSP multistart, through a scratch tensor elsewhere -- and equal, bit for bit, the rollout that is
+    fed the tensor eamrl_exp1_noise writes for the same seed."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import ops
+
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=N)
+    td = env.reset(batch_size=[B]).to(DEV)
+    pol = make_policy(cfg)
+    kw = dict(num_starts=S) if S else {}
+    dt = "multistart_sampling" if S else "sampling"
+    torch.manual_seed(4242)
+    a = pol(td.clone(), env, phase="test", decode_type=dt, return_sum_log_likelihood=False, **kw)
+    torch.manual_seed(4242)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    M = td["locs"].shape[1]
+    R = B * max(S, 1)
+    from eam_rl4co_amd.policy import _max_decode_steps
+
+    # (multistart: the pre-decoder hook takes the start node, so the kernel's step t is output column t + 1)
+    noise = ops.exp1_noise(seed, R, _max_decode_steps(env_name, M, 1 if S else 0), M, DEV)
+    b = pol(td.clone(), env, phase="test", decode_type=dt, return_sum_log_likelihood=False, noise=noise, **kw)
+    assert_bits_equal(a["actions"], b["actions"], "actions")
+    assert_bits_equal(a["log_likelihood"], b["log_likelihood"], "logp")
+    torch.manual_seed(4243)
+    c = pol(td.clone(), env, phase="test", decode_type=dt, **kw)
+    assert not torch.equal(a["actions"], c["actions"])
+
+
+def test_full_size_pomo_1024x100_mfma_kernel_equals_valu_kernel():
+    """BASELINE.json configs[3] at its full per-GPU size (1024 instances x 100 starts, TSP-100, POMO policy, multistart
+    sampling): the MFMA start-sharing kernel with in-place noise against the register-resident VALU kernel fed the 4.1 GB
+    tensor of the same draws -- two independent kernels of the canonical arithmetic, bit-identical tours and log-probs --
+    plus the size-independent properties (permutations, start nodes in (s b) order)."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import _lib, ops
+
+    N, B, S = 100, 1024, 100
+    pol = make_policy("pomo_tsp")
+    env = ea.get_env("tsp", generator_params=dict(num_loc=N), seed=1234)
+    td = env.reset(batch_size=[B]).to(DEV)
+    torch.manual_seed(99)
+    a = pol(td.clone(), env, phase="train", decode_type="multistart_sampling", num_starts=S, return_sum_log_likelihood=False)
+    torch.manual_seed(99)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    noise = ops.exp1_noise(seed, B * S, N - 1, N, DEV)
+    _lib.load().eamrl_debug_set(11, 1)
+    try:
+        b = pol(td.clone(), env, phase="train", decode_type="multistart_sampling", num_starts=S, noise=noise,
+                return_sum_log_likelihood=False)
+    finally:
+        _lib.load().eamrl_debug_set(11, 0)
+    del noise
+    assert torch.equal(a["actions"], b["actions"]), "tours differ between the MFMA and the VALU kernel"
+    assert torch.equal(a["log_likelihood"].view(torch.int32), b["log_likelihood"].view(torch.int32)), "log-probs differ"
+    assert torch.equal(a["reward"], b["reward"])
+    acts = a["actions"]
+    assert (acts.sort(1).values == torch.arange(N, device=DEV)).all()
+    assert (acts[:, 0] == torch.arange(S, device=DEV).repeat_interleave(B)).all()
