@@ -92,14 +92,14 @@ def resident_bytes_per_rollout(env, M, T, E=128, S=1, sampling=False):
     return 12 * M * E + 4 * M * E * g + max(S, 1) * per_row
 
 
-def measured_traffic(workload, batch):
+def measured_traffic(workload, batch, suffix=""):
     """HBM bytes per decode-loop launch from the committed PMC passes (profiles/r0N_traffic.json): rocprofv3 counters
     cannot be collected from inside the timed run, so `traffic` is the separately profiled value for exactly this
     workload, or None."""
     for name in ("r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                t = json.load(f).get(f"{workload}_b{batch}", {}).get("traffic_bytes")
+                t = json.load(f).get(f"{workload}_b{batch}{suffix}", {}).get("traffic_bytes")
             if t is not None:
                 return t
         except (OSError, ValueError):
@@ -467,7 +467,8 @@ def main():
                   if fam_ms["encoder_fused"] else 0.0)
         roofline_enc = {"kernel": "k_encoder_fused (all encoder layers of an instance in one workgroup, v_mfma_f32_16x16x4_f32)",
                         "bound": "mfma", "achieved": round(enc_tf, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(enc_tf / F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "frac": round(enc_tf / F32_PEAK_TFLOPS, 4),
+                        "traffic": measured_traffic(args.workload.replace("_train", ""), batch, "_encoder_fused"),
                         "kernel_ms": round(fam_ms["encoder_fused"], 4), "launches_per_step": ft.launches("encoder_fused", passes),
                         "algorithmic_flops_per_launch": int(ft.flops.get("encoder_fused", 0.0) / passes)}
         dominant = max(fam_ms, key=lambda f: fam_ms[f])
