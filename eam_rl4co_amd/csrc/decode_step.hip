@@ -660,10 +660,8 @@ __global__ __launch_bounds__(BLOCK) void k_decode_step(DecArgs a)
 }
 
 // Whole decode loop for one row per workgroup; K/V/Lp re-read from HBM/L2 each step (works for any M).
-// OCC: workgroups per CU the register allocation must allow (launch bound): 2 = 222 VGPRs and deep load batches,
-// 4 = 128 VGPRs (selected with debug key 12 for A/B measurements).
-template <int ENV, int OCC = 2>
-__global__ __launch_bounds__(BLOCK, OCC) void k_rollout_stream(DecArgs a)
+template <int ENV>
+__global__ __launch_bounds__(BLOCK) void k_rollout_stream(DecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowLds l = carve_row_lds(smem, a.M, a.E, a.H);
@@ -734,9 +732,7 @@ static int launch_decode(int env, const DecArgs& a, bool rollout, hipStream_t st
     if (lds > 160 * 1024) return EAMRL_E_ARG;
     dim3 grid((unsigned)a.R), block(BLOCK);
     void (*k)(DecArgs);
-    if (rollout && g_debug[12] && env == EAMRL_ENV_CVRP)
-        k = k_rollout_stream<EAMRL_ENV_CVRP, 4>;
-    else if (rollout)
+    if (rollout)
         k = env == EAMRL_ENV_TSP ? k_rollout_stream<EAMRL_ENV_TSP>
           : env == EAMRL_ENV_CVRP ? k_rollout_stream<EAMRL_ENV_CVRP>
           : env == EAMRL_ENV_SDVRP ? k_rollout_stream<EAMRL_ENV_SDVRP>
