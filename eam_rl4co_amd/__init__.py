@@ -5,7 +5,7 @@ from .envs import (CVRPEnv, CVRPGenerator, CVRPTWEnv, CVRPTWGenerator, OPEnv, OP
 from .policy import (AttentionModelDecoder, AttentionModelEncoder, AttentionModelPolicy, GraphedRollout,  # noqa: F401
                      load_reference_checkpoint, random_policy, rollout)
 from .attention import PointerAttention, scaled_dot_product_attention  # noqa: F401
-from .evolution import EA, EACvrpDraws, EADraws, evolution_worker, generate_batch_population  # noqa: F401
+from .evolution import EA, EACvrpDraws, EAPrizeDraws, EADraws, evolution_worker, generate_batch_population  # noqa: F401
 from .tensordict_lite import TensorDict  # noqa: F401
 from .utils import batchify, gather_by_index, unbatchify  # noqa: F401
 

@@ -100,6 +100,8 @@ PROTOTYPES = {
     "eamrl_beam_topk": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "eamrl_ea_cvrp_run": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, C.c_double, C.c_double, C.c_double, _i32,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "eamrl_ea_prize_run": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, C.c_double, C.c_double, C.c_double, _i32,
+                           _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eamrl_ea_tsp_run": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"eamrl_last_error": C.c_char_p}

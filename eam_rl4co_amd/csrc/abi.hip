@@ -559,4 +559,28 @@ __attribute__((visibility("default"))) int eamrl_ea_cvrp_run(const float* locs, 
                                    mut_rand, mut_u, (hipStream_t)stream), "eamrl_ea_cvrp_run");
 }
 
+__attribute__((visibility("default"))) int eamrl_ea_prize_run(int env, const float* locs, const float* prize, const float* aux,
+                                                             int64_t* pop, float* fitness, int64_t B, int S, int N, int L,
+                                                             int num_generations, double mutation_rate,
+                                                             double crossover_rate, double selection_rate, int top_k,
+                                                             const double* init_mut_rand, const double* init_mut_u,
+                                                             const double* cross_rand, const double* cross_u,
+                                                             const double* mut_rand, const double* mut_u, void* stream)
+{
+    REQUIRE(env == EAMRL_ENV_PCTSP || env == EAMRL_ENV_OP, "eamrl_ea_prize_run (env: PCTSP or OP)");
+    REQUIRE(locs && prize && aux && pop && fitness && init_mut_rand && init_mut_u, "eamrl_ea_prize_run");
+    REQUIRE(B >= 0 && B <= 0x7fffffffLL && S >= 1 && S <= 128 && N >= 1 && N <= 127 && L >= 2 && L <= 128 &&
+            num_generations >= 0, "eamrl_ea_prize_run (S <= 128, N <= 127 customers, L <= 128)");
+    REQUIRE(mutation_rate == mutation_rate && crossover_rate == crossover_rate && selection_rate >= 0.0,
+            "eamrl_ea_prize_run");
+    int ne = S;
+    if (S > 2) { ne = (int)(selection_rate * (double)S); if (ne <= 0 || ne > S) ne = S; }
+    if (num_generations > 0 && ne / 2 > 0)
+        REQUIRE(cross_rand && mut_rand && mut_u && (cross_u || env == EAMRL_ENV_PCTSP), "eamrl_ea_prize_run (draws)");
+    if (B == 0) return 0;
+    return launched(launch_ea_prize(env, locs, prize, aux, pop, fitness, B, S, N, L, num_generations, mutation_rate,
+                                    crossover_rate, selection_rate, top_k, init_mut_rand, init_mut_u, cross_rand, cross_u,
+                                    mut_rand, mut_u, (hipStream_t)stream), "eamrl_ea_prize_run");
+}
+
 }  // extern "C"

@@ -12,8 +12,10 @@ or supplied by the caller -- the form in which the operators are tested against 
 (tests/golden/ea_*.npz).
 
 Built: TSP (order crossover, inversion mutation, elitism, per-start-node / top-k replacement, single-start
-rotation population) and CVRP (route-prefix crossover with capacity repair, in-route inversion, initial
-mutation pass).  PCTSP / OP / FFSP operators are not built and raise NotImplementedError.
+rotation population), CVRP (route-prefix crossover with capacity repair, in-route inversion, initial
+mutation pass), PCTSP (cycle crossover with prize top-up, prefix inversion) and OP (budget-checked rebuild and
+inversion) -- csrc/evolution_prize.hip for the last two.  FFSP (not a routing env of this path) raises
+NotImplementedError.
 """
 from __future__ import annotations
 
@@ -72,6 +74,27 @@ class EACvrpDraws:
                                                                  self.cross_u, self.mut_rand, self.mut_u)))
 
 
+@dataclass
+class EAPrizeDraws:
+    """Random inputs of one PCTSP / OP EA.run over a batch (eamrl_ea_prize_run): uniforms in [0, 1)."""
+    init_mut_rand: torch.Tensor  # [B, S]
+    init_mut_u: torch.Tensor     # [B, S, 2]
+    cross_rand: torch.Tensor     # [G, B, P]
+    cross_u: torch.Tensor        # [G, B, P]   (OP: the cut point; PCTSP: unused)
+    mut_rand: torch.Tensor       # [G, B, O]
+    mut_u: torch.Tensor          # [G, B, O, 2]
+
+    @staticmethod
+    def sample(G, B, S, selection_rate, device, generator=None):
+        P = ops.ea_num_pairs(selection_rate, S)
+        r = lambda *shape: torch.rand(*shape, dtype=torch.float64, device=device, generator=generator)
+        return EAPrizeDraws(r(B, S), r(B, S, 2), r(G, B, P), r(G, B, P), r(G, B, 2 * P), r(G, B, 2 * P, 2))
+
+    def to(self, device):
+        return EAPrizeDraws(*(t.to(device).contiguous() for t in (self.init_mut_rand, self.init_mut_u, self.cross_rand,
+                                                                  self.cross_u, self.mut_rand, self.mut_u)))
+
+
 def generate_batch_population(routes: torch.Tensor, env_code: int = 1, pop_size: int = SINGLE_START_POP_SIZE):
     """[B, N] single tours -> [B, pop_size, N] (evolution.py:1574-1626): TSP (env_code 1) rotations of the tour --
     member 0 is the tour, member i starts at position i % N (position 1 where that is 0); other codes: copies."""
@@ -95,9 +118,9 @@ class EA:
         self.selection_rate = kwargs.get("selection_rate")
         self.method = kwargs.get("method", None)
         self.env_name = env.name
-        if self.env_name not in ("tsp", "cvrp"):
-            if self.env_name in ("pctsp", "op", "ffsp"):
-                raise NotImplementedError(f"EA operators for {self.env_name} are not built (TSP and CVRP only)")
+        if self.env_name not in ("tsp", "cvrp", "pctsp", "op"):
+            if self.env_name == "ffsp":
+                raise NotImplementedError("EA operators for ffsp are not built (TSP, CVRP, PCTSP and OP only)")
             raise ValueError(f"Unsupported env for EA operators: {self.env_name}")
         assert self.num_generations is not None, "Number of generations must be specified"
         assert self.mutation_rate is not None, "Mutation rate must be specified"
@@ -111,11 +134,17 @@ class EA:
             pop = pop[None]
         B, S, N = pop.shape
         rows = pop.permute(1, 0, 2).reshape(S * B, N).contiguous()      # (s b) order: row r reads instance r % B
-        return -ops.tour_length_reward(td["locs"].contiguous(), rows, with_depot=self.env_name == "cvrp").view(S, B).t()
+        if self.env_name == "pctsp":
+            reward = ops.pctsp_reward(td["locs"].contiguous(), td["penalty"].contiguous(), rows)
+        elif self.env_name == "op":
+            reward = ops.op_reward(td["prize"].contiguous(), rows)
+        else:
+            reward = ops.tour_length_reward(td["locs"].contiguous(), rows, with_depot=self.env_name == "cvrp")
+        return -reward.view(S, B).t()
 
     def get_fitness(self, pop, td):
         size = pop.shape[-1]                                             # chromosome length, as the reference
-        worst = np.float32((1.5 if self.env_name == "tsp" else 2.5) * size)
+        worst = np.float32({"tsp": 1.5 * size, "op": 0.0}.get(self.env_name, 2.5 * size))
         return torch.tensor(worst, device=pop.device) - self.get_cost(pop, td)
 
     # -- the run ----------------------------------------------------------------------------------------------
@@ -134,6 +163,17 @@ class EA:
                                    float(self.mutation_rate), float(self.crossover_rate), float(self.selection_rate),
                                    self.method == "am", draws.init_mut_rand, draws.init_mut_u, draws.cross_rand,
                                    draws.cross_u, draws.mut_rand, draws.mut_u)
+            return (pop[0], fit[0]) if squeeze else (pop, fit)
+        if self.env_name in ("pctsp", "op"):
+            draws = (EAPrizeDraws.sample(G, B, S, self.selection_rate, pop.device, generator) if draws is None
+                     else draws.to(pop.device))
+            pctsp = self.env_name == "pctsp"
+            fit = ops.ea_prize_run_(self.env_name, td["locs"].contiguous(),
+                                    td["real_prize" if pctsp else "prize"].to(torch.float32).contiguous(),
+                                    td["penalty" if pctsp else "max_length"].to(torch.float32).contiguous(), pop, G,
+                                    float(self.mutation_rate), float(self.crossover_rate), float(self.selection_rate),
+                                    self.method == "am", draws.init_mut_rand, draws.init_mut_u, draws.cross_rand,
+                                    draws.cross_u, draws.mut_rand, draws.mut_u)
             return (pop[0], fit[0]) if squeeze else (pop, fit)
         if draws is None:
             draws = EADraws.sample(G, B, S, N, self.selection_rate, pop.device, generator)

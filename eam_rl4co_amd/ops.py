@@ -713,6 +713,38 @@ def ea_cvrp_run_(locs, demand, vcap, pop, num_generations, mutation_rate, crosso
     return fitness
 
 
+def ea_prize_run_(env_name, locs, prize, aux, pop, num_generations, mutation_rate, crossover_rate, selection_rate, top_k,
+                  init_mut_rand, init_mut_u, cross_rand, cross_u, mut_rand, mut_u):
+    """PCTSP / OP EA.run, in place on pop [B, S, L] (int64 action rows, 0 = depot); returns fitness [B, S].
+    prize / aux [B, N+1] with the depot first (aux: PCTSP penalty, OP max_length).  See include/eamrl.h."""
+    lib = _lib.load()
+    if env_name not in ("pctsp", "op"):
+        raise ValueError("ea_prize_run: env must be pctsp or op")
+    _chk(pop, "pop", torch.int64)
+    B, S, L = pop.shape
+    M = locs.shape[1]
+    _chk(locs, "locs", torch.float32, (B, M, 2))
+    _chk(prize, "prize", torch.float32, (B, M))
+    _chk(aux, "penalty / max_length", torch.float32, (B, M))
+    P = ea_num_pairs(selection_rate, S)
+    G = int(num_generations)
+    _chk(init_mut_rand, "init_mut_rand", torch.float64, (B, S))
+    _chk(init_mut_u, "init_mut_u", torch.float64, (B, S, 2))
+    if G > 0 and P > 0:
+        _chk(cross_rand, "cross_rand", torch.float64, (G, B, P))
+        if env_name == "op":
+            _chk(cross_u, "cross_u", torch.float64, (G, B, P))
+        _chk(mut_rand, "mut_rand", torch.float64, (G, B, 2 * P))
+        _chk(mut_u, "mut_u", torch.float64, (G, B, 2 * P, 2))
+    fitness = torch.empty(B, S, device=pop.device, dtype=torch.float32)
+    nul = lambda t: _ptr(t) if (G > 0 and P > 0 and t is not None) else None
+    _lib.check(lib.eamrl_ea_prize_run(ENVS[env_name], _ptr(locs), _ptr(prize), _ptr(aux), _ptr(pop), _ptr(fitness), B, S,
+                                      M - 1, L, G, float(mutation_rate), float(crossover_rate), float(selection_rate),
+                                      int(bool(top_k)), _ptr(init_mut_rand), _ptr(init_mut_u), nul(cross_rand),
+                                      nul(cross_u), nul(mut_rand), nul(mut_u), _stream(pop)), "eamrl_ea_prize_run")
+    return fitness
+
+
 class DecodeCache:
     """Device-resident decoder cache (struct eamrl_cache).
 

@@ -426,6 +426,30 @@ int eamrl_ea_cvrp_run(const float* locs, const float* demand, const float* vcap,
                       const double* cross_rand, const double* cross_u, const double* mut_rand, const double* mut_u,
                       void* stream);
 
+/* EA.run for PCTSP (env = EAMRL_ENV_PCTSP) and OP (env = EAMRL_ENV_OP) populations  [evolution.py:252-354;
+ *  PCTSP: :364-370 (fitness = f32(2.5*L) - cost, cost = -PCTSPEnv reward), :905-1101 (cycle_crossover_pctsp: cycles of the
+ *  pair found from the first parent's side, children deduplicated and topped up by descending float32 prize/penalty
+ *  ratio until the float64 prize sum reaches 1 - 1e-5), :555-583 (inverse_mutate_pctsp: reverse [i1, i2) inside the
+ *  visited prefix, or swap two neighbours when the two draws coincide);
+ *  OP: :372-378 (fitness = collected prize), :1110-1346 (order_crossover_op: acts only on parents that are all zeros
+ *  from index 1 on; the first `end` entries, then customers 1..L in index order while route + leg + way back fits
+ *  max - 0.1, post-checked against max - 1e-5), :1468-1572 (inverse_mutate_op: reverse [s, e] if the float64 route
+ *  length of float32 distances stays within max - 1e-5)].
+ *   locs [B][N+1][2] f32, depot first;  prize [B][N+1] f32 with the depot's 0 first (PCTSP: td["real_prize"], OP:
+ *   td["prize"]);  aux [B][N+1] f32: PCTSP td["penalty"], OP td["max_length"] (only entry 0 of an instance is used);
+ *   pop [B][S][L] i64 action rows, 0 = depot, zero-padded; in/out;  fitness [B][S] f32 out.
+ *   S <= 128, N <= 127, L <= 128.  top_k as in eamrl_ea_cvrp_run.
+ * Defined where the reference is not: the cycle crossover's `next(iter(set))` starts at the smallest remaining node;
+ * ties in a sort keep index order; customers beyond the node count are skipped by the OP crossover.
+ * An initial mutation pass precedes the generations.  Draws are uniforms in [0, 1), randint as in eamrl_ea_cvrp_run:
+ *   init_mut_rand [B][S], init_mut_u [B][S][2];  cross_rand [G][B][P], cross_u [G][B][P] (OP: the cut; PCTSP: unused,
+ *   may be NULL);  mut_rand [G][B][O], mut_u [G][B][O][2]. */
+int eamrl_ea_prize_run(int env, const float* locs, const float* prize, const float* aux, int64_t* pop, float* fitness,
+                       int64_t B, int S, int N, int L, int num_generations, double mutation_rate, double crossover_rate,
+                       double selection_rate, int top_k, const double* init_mut_rand, const double* init_mut_u,
+                       const double* cross_rand, const double* cross_u, const double* mut_rand, const double* mut_u,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

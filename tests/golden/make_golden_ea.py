@@ -14,6 +14,7 @@ a thread pool, which only interleaves the draws).
 """
 from __future__ import annotations
 
+import contextlib
 import importlib
 import os
 import sys
@@ -282,7 +283,258 @@ def cvrp_case(name, N, B, S, G, mutation_rate, crossover_rate, selection_rate, s
           f"mean cost {np.mean(2.5 * L - out_fit):.4f}")
 
 
+class _Float64Args:
+    """numba compiles the PCTSP / OP operators with float32 array arguments and float64 accumulators (`x = 0.0;
+    x += a[i]` unifies to float64).  Executed as plain Python under NumPy >= 2 the same lines would accumulate in
+    float32.  Handing the operators float64 COPIES of their float32 arrays (same values) makes every such sum come out
+    in float64 as under numba; arrays the operators allocate themselves (`prize_ratios`, float32) keep their type, so
+    stores into them round to float32 as numba's do."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, *args):
+        return self.fn(*[a.astype(np.float64) if isinstance(a, np.ndarray) and a.dtype == np.float32 else a for a in args])
+
+
+def _prize_run(name, env_name, ea, td_keys, td, init, G, mutation_rate, crossover_rate, selection_rate, method, run_oracle,
+               extra, guard=contextlib.nullcontext):
+    """Shared driver of the PCTSP / OP cases: EA.run of the reference per instance with its draws recorded, the draw
+    log replayed through the restatement (which must reproduce the reference's population), per-slot uniforms stored."""
+    B, S, L = init.shape
+    ne = int(selection_rate * S) if S > 2 else S
+    ne = S if ne == 0 else ne
+    P = (ne - ne % 2) // 2
+    O = 2 * P
+    out_pop = np.zeros_like(init); out_fit = np.zeros((B, S), dtype=np.float32)
+    imr = np.zeros((B, S)); imu = np.zeros((B, S, 2))
+    cr = np.zeros((G, B, P)); cu = np.zeros((G, B, P))
+    mr = np.zeros((G, B, O)); mu = np.zeros((G, B, O, 2))
+    ea.crossover_fn = _Float64Args(ea.crossover_fn)
+    ea.mutate_fn = _Float64Args(ea.mutate_fn)
+    proxy, ev.np = ev.np, np                          # these operators allocate float32 arrays that must stay float32
+    try:
+        for b in range(B):
+            env_td = TensorDict({k: td[k][b:b + 1] for k in td_keys}, batch_size=[1])
+            with DrawLog() as log, guard():
+                pop, fit = ea.run(init[b], env_td)
+            out_pop[b], out_fit[b] = pop, fit
+            vec_iter = (e[1] for e in log.events if e[0] == "random")
+            imr[b] = next(vec_iter)
+            for g in range(G):
+                cr[g, b] = next(vec_iter); mr[g, b] = next(vec_iter)
+            fc = FlatConsumer([e for e in log.events if e[0] == "randint"])
+            opop, ofit = run_oracle(b, imr[b], cr[:, b], mr[:, b], fc)
+            fc.done()
+            assert np.array_equal(opop, pop), f"{name}: restatement differs from the reference on instance {b}"
+            assert np.allclose(ofit, fit, rtol=1e-5, atol=1e-5), f"{name}: fitness differs on instance {b}"
+            for key, u in fc.u.items():
+                if key[0] == ("init",):
+                    imu[b, key[1], key[2]] = u
+                elif key[0][0] == "cross":
+                    cu[key[0][1], b, key[1]] = u
+                else:
+                    mu[key[0][1], b, key[1], key[2]] = u
+    finally:
+        ev.np = proxy
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), env_name=env_name, init_pop=init, num_generations=G,
+                        mutation_rate=mutation_rate, crossover_rate=crossover_rate, selection_rate=selection_rate,
+                        top_k=int(method == "am"), init_mut_rand=imr, init_mut_u=imu, cross_rand=cr, cross_u=cu, mut_rand=mr,
+                        mut_u=mu, pop=out_pop, fitness=out_fit, torch_version=torch.__version__, **extra)
+    changed = int((out_pop != init).any(-1).sum())
+    print(f"{name}: seed={extra.get('seed')} B={B} S={S} L={L} G={G} pairs={P}; {changed} of {B * S} individuals changed; mean fitness {out_fit.mean():.4f}")
+
+
+def pctsp_case(name, N, B, S, G, mutation_rate, crossover_rate, selection_rate, seed, method=None):
+    """EA.run of the reference on PCTSP populations: random customer orders cut where the collected prize reaches 1."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import ea_oracle as eo
+    from rl4co.envs.routing.pctsp.env import PCTSPEnv
+
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    env = PCTSPEnv(generator_params=dict(num_loc=N))
+    td = env.reset(batch_size=[B])
+    locs = td["locs"].numpy().copy()                 # [B, N+1, 2], depot first
+    prize = td["real_prize"].numpy().copy()          # [B, N+1], depot (0) first
+    penalty = td["penalty"].numpy().copy()           # [B, N+1], depot (0) first
+    ea = ev.EA(env, dict(num_generations=G, mutation_rate=mutation_rate, crossover_rate=crossover_rate,
+                         selection_rate=selection_rate, method=method))
+    tours = []
+    for b in range(B):
+        rows = []
+        for s in range(S):
+            first = s % N + 1
+            order = [first] + [int(x) for x in np.random.permutation([c for c in range(1, N + 1) if c != first])]
+            row, got = [], 0.0
+            for c in order:
+                row.append(c); got += float(prize[b, c])
+                if got >= 1.0 + 1e-3 and len(row) >= 4:
+                    break
+            rows.append(row)
+        tours.append(rows)
+    L = max(len(r) for rows in tours for r in rows) + 3
+    init = np.zeros((B, S, L), dtype=np.int64)
+    for b in range(B):
+        for s in range(S):
+            init[b, s, :len(tours[b][s])] = tours[b][s]
+
+    def run_oracle(b, imr, cr, mr, fc):
+        return eo.ea_run_pctsp(locs[b], prize[b], penalty[b], init[b], G, mutation_rate, crossover_rate, selection_rate,
+                               imr, cr, mr, fc, top_k=(method == "am"))
+
+    _prize_run(name, "pctsp", ea, ("locs", "real_prize", "penalty"), td, init, G, mutation_rate, crossover_rate,
+               selection_rate, method, run_oracle, dict(locs=locs, real_prize=prize, penalty=penalty, seed=seed))
+
+
+class TieGuard:
+    """Asserts that no np.argsort call of the run sees equal keys.  numpy's default argsort is not stable (on this host
+    it is a SIMD sorting network), so with equal fitness values the reference's result is not a function of its inputs;
+    the fixtures are recorded only from runs where that cannot matter."""
+
+    def __enter__(self):
+        self._argsort = np.argsort
+
+        def argsort(a, *args, **kw):
+            assert len(np.unique(np.asarray(a))) == len(a), "fitness tie: pick another seed"
+            return self._argsort(a, *args, **kw)
+
+        np.argsort = argsort
+        return self
+
+    def __exit__(self, *exc):
+        np.argsort = self._argsort
+
+
+def op_case(name, N, B, S, G, mutation_rate, crossover_rate, selection_rate, seed, method=None, degenerate=0):
+    """EA.run of the reference on OP populations: random customer orders, each customer taken while the route and the
+    way back fit the length budget; tour s starts at customer s + 1 (POMO layout, per-start-node replacement).
+    The OP fitness (sum of collected prizes) is tie-prone: the env's prizes are hundredths, so different node sets often
+    have equal totals and float32 sums of equal totals differ by summation order (torch's CPU reduction order depends on
+    the host's vector width).  The operators never read the prize VALUES, so the fixtures use random multiples of 2^-20
+    instead: every sum is exact in float32 in any order and different node sets have different totals; TieGuard asserts
+    that no sort of the run sees equal keys.  (The top-k replacement of method="am" necessarily ties a mutated copy with
+    its parent, so for OP it is covered by the operator fixtures and by the PCTSP / CVRP runs, not by an EA.run fixture.)
+    `degenerate` individuals per instance are [customer, 0, 0, ...]: the only parents the reference's crossover acts on."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import ea_oracle as eo
+    from rl4co.envs.routing.op.env import OPEnv
+
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    env = OPEnv(generator_params=dict(num_loc=N, prize_distribution="dist"))   # the default sampler is Uniform(1, 1), rejected by this torch and unused
+    td = env.reset(batch_size=[B])
+    td["prize"] = torch.nn.functional.pad(torch.randint(1, 2 ** 20, (B, N)).float() / 2 ** 20, (1, 0))
+    locs = td["locs"].numpy().copy()                 # [B, N+1, 2], depot first
+    prize = td["prize"].numpy().copy()               # [B, N+1], depot (0) first
+    maxlen = td["max_length"].numpy().copy()         # [B, N+1]: budget minus the way back from each node
+    ea = ev.EA(env, dict(num_generations=G, mutation_rate=mutation_rate, crossover_rate=crossover_rate,
+                         selection_rate=selection_rate, method=method))
+    tours = []
+    for b in range(B):
+        d = eo.op_dist_matrix(locs[b]).astype(np.float64)
+        budget = float(maxlen[b, 0]) - 0.02
+        rows = []
+        for s in range(S):
+            first = s % N + 1
+            order = [first] + [int(x) for x in np.random.permutation([c for c in range(1, N + 1) if c != first])]
+            row, cur, prev = [], 0.0, 0
+            for c in order:
+                if s >= S - degenerate and row:
+                    break
+                if cur + d[prev, c] + d[c, 0] <= budget:
+                    row.append(c); cur += d[prev, c]; prev = c
+            rows.append(row)
+        tours.append(rows)
+    L = max(len(r) for rows in tours for r in rows) + 3
+    assert L + 1 <= N + 1, "the reference's crossover indexes used[1..L]: keep L below the node count"
+    init = np.zeros((B, S, L), dtype=np.int64)
+    for b in range(B):
+        for s in range(S):
+            init[b, s, :len(tours[b][s])] = tours[b][s]
+
+    def run_oracle(b, imr, cr, mr, fc):
+        return eo.ea_run_op(locs[b], prize[b], maxlen[b], init[b], G, mutation_rate, crossover_rate, selection_rate,
+                            imr, cr, mr, fc, top_k=(method == "am"))
+
+    _prize_run(name, "op", ea, ("locs", "prize", "max_length"), td, init, G, mutation_rate, crossover_rate,
+               selection_rate, method, run_oracle, dict(locs=locs, prize=prize, max_length=maxlen, seed=seed), guard=TieGuard)
+
+
+def op_operator_cases():
+    """Single calls of the OP operators (no fitness, no sorting): ordinary parents (the reference's crossover returns
+    them unchanged), degenerate ones [customer, 0, ...] (the only ones it rebuilds) and children with interior depot
+    visits going through the mutation."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import ea_oracle as eo
+
+    np.random.seed(31)
+    N, L, n = 20, 12, 16
+    locs = np.random.rand(N + 1, 2).astype(np.float32)
+    prize = np.concatenate([[0.0], np.random.randint(1, 2 ** 20, N) / 2 ** 20]).astype(np.float32)
+    dist = eo.op_dist_matrix(locs)
+    maxd = (np.float32(2.0) - dist[0] - np.float32(1e-6)).astype(np.float32)
+    parents = np.zeros((n, L), dtype=np.int64)
+    for i in range(n):
+        if i % 4 < 2:                                   # degenerate
+            parents[i, 0] = 0 if i == 5 else 1 + (3 * i) % N
+        else:
+            order, cur, prev, k = np.random.permutation(np.arange(1, N + 1)), 0.0, 0, 0
+            for c in order:
+                if cur + dist[prev, c] + dist[c, 0] <= 1.9 and k < L - 3:
+                    parents[i, k] = c; cur += float(dist[prev, c]); prev = c; k += 1
+    parents[[2, 4]] = parents[[4, 2]]                   # pairs (0,1) degenerate, (2,3)/(4,5) mixed, ...
+    proxy, ev.np = ev.np, np
+    try:
+        with DrawLog() as log:
+            off = _Float64Args(ev.order_crossover_op)(parents, 0.95, prize, dist, maxd)
+        cr = [e[1] for e in log.events if e[0] == "random"][0]
+        fc = FlatConsumer([e for e in log.events if e[0] == "randint"])
+        mine = eo.order_crossover_op(parents, 0.95, prize, dist, maxd, cr, fc, ("cross", 0)); fc.done()
+        assert np.array_equal(mine, off), "order_crossover_op restatement differs"
+        cu = np.zeros(n // 2)
+        for key, u in fc.u.items():
+            cu[key[1]] = u
+        with DrawLog() as log:
+            mut = _Float64Args(ev.inverse_mutate_op)(off, 0.9, prize, dist, maxd)
+        mr = [e[1] for e in log.events if e[0] == "random"][0]
+        fc = FlatConsumer([e for e in log.events if e[0] == "randint"])
+        mine = eo.inverse_mutate_op(off, 0.9, prize, dist, maxd, mr, fc, ("mut", 0)); fc.done()
+        assert np.array_equal(mine, mut), "inverse_mutate_op restatement differs"
+        mu = np.zeros((n, 2))
+        for key, u in fc.u.items():
+            mu[key[1], key[2]] = u
+    finally:
+        ev.np = proxy
+    np.savez_compressed(os.path.join(HERE, "ea_op_operators.npz"), locs=locs, prize=prize, max_length=maxd, parents=parents,
+                        crossover_rate=0.95, cross_rand=cr, cross_u=cu, offspring=off, mutation_rate=0.9, mut_rand=mr,
+                        mut_u=mu, mutated=mut)
+    print("ea_op_operators: rebuilt", int((off != parents).any(-1).sum()), "of", n, "rows; mutated", int((mut != off).any(-1).sum()))
+
+
+def prize_cases():
+    pctsp_case("ea_pctsp20_default", N=20, B=3, S=20, G=3, mutation_rate=0.1, crossover_rate=0.6, selection_rate=0.2, seed=21)
+    pctsp_case("ea_pctsp20_busy", N=20, B=3, S=20, G=4, mutation_rate=0.7, crossover_rate=0.9, selection_rate=0.7, seed=22)
+    pctsp_case("ea_pctsp50_am", N=50, B=2, S=30, G=3, mutation_rate=0.5, crossover_rate=0.8, selection_rate=0.5, seed=23,
+               method="am")
+    def tie_free(name, seed, **kw):          # the first seed from `seed` on whose run sorts no equal fitness values
+        for sd in range(seed, seed + 200):
+            try:
+                return op_case(name, seed=sd, **kw)
+            except AssertionError as e:
+                if "fitness tie" not in str(e):
+                    raise
+        raise RuntimeError(name + ": no tie-free seed found")
+
+    tie_free("ea_op20_default", 24, N=20, B=3, S=20, G=3, mutation_rate=0.1, crossover_rate=0.6, selection_rate=0.2)
+    tie_free("ea_op20_busy", 40, N=20, B=3, S=20, G=4, mutation_rate=0.7, crossover_rate=0.9, selection_rate=0.7, degenerate=6)
+    tie_free("ea_op50_busy", 60, N=50, B=2, S=30, G=3, mutation_rate=0.5, crossover_rate=0.8, selection_rate=0.5, degenerate=8)
+    op_operator_cases()
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "prize":
+        return prize_cases()
     operator_cases()
     tsp_case("ea_tsp20_default", N=20, B=3, S=20, G=3, mutation_rate=0.1, crossover_rate=0.6, selection_rate=0.2, seed=5)
     tsp_case("ea_tsp20_busy", N=20, B=3, S=20, G=4, mutation_rate=0.6, crossover_rate=0.9, selection_rate=0.7, seed=6)
@@ -291,6 +543,7 @@ def main():
     cvrp_case("ea_cvrp20_busy", N=20, B=3, S=20, G=4, mutation_rate=0.7, crossover_rate=0.9, selection_rate=0.7, seed=9)
     cvrp_case("ea_cvrp50_am", N=50, B=2, S=30, G=3, mutation_rate=0.5, crossover_rate=0.8, selection_rate=0.5, seed=10,
               method="am")
+    prize_cases()
 
 
 if __name__ == "__main__":

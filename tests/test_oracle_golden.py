@@ -331,6 +331,84 @@ def test_ea_cvrp_run_matches_reference(name):
                 assert load <= float(g["vehicle_capacity"]) + 1e-5
 
 
+def _prize_rint(g, b):
+    from oracle import ea_oracle as ea
+
+    u = {}
+    S, P, O, G = g["init_mut_u"].shape[1], g["cross_u"].shape[2], g["mut_u"].shape[2], g["cross_u"].shape[0]
+    for i in range(S):
+        for k in range(2):
+            u[(("init",), i, k)] = g["init_mut_u"][b, i, k]
+    for gg in range(G):
+        for p in range(P):
+            u[(("cross", gg), p, 0)] = g["cross_u"][gg, b, p]
+        for i in range(O):
+            for k in range(2):
+                u[(("mut", gg), i, k)] = g["mut_u"][gg, b, i, k]
+    return ea.StructuredDraws(u)
+
+
+@pytest.mark.parametrize("name", ["ea_pctsp20_default", "ea_pctsp20_busy", "ea_pctsp50_am"])
+def test_ea_pctsp_run_matches_reference(name):
+    """EA.run of the reference on PCTSP (cycle_crossover_pctsp + inverse_mutate_pctsp executed with recorded draws,
+    numba's float64 accumulators emulated, see make_golden_ea.py) vs the restatement: identical populations."""
+    from oracle import ea_oracle as ea
+
+    g = golden(name)
+    for b in range(g["locs"].shape[0]):
+        pop, fit = ea.ea_run_pctsp(g["locs"][b], g["real_prize"][b], g["penalty"][b], g["init_pop"][b],
+                                   int(g["num_generations"]), float(g["mutation_rate"]), float(g["crossover_rate"]),
+                                   float(g["selection_rate"]), g["init_mut_rand"][b], g["cross_rand"][:, b],
+                                   g["mut_rand"][:, b], _prize_rint(g, b), top_k=bool(g["top_k"]))
+        np.testing.assert_array_equal(pop, g["pop"][b])
+        np.testing.assert_allclose(fit, g["fitness"][b], rtol=1e-5, atol=1e-5)
+        for row in pop:      # no customer twice, the minimum prize collected (or everything visited)
+            nodes = [x for x in row.tolist() if x]
+            assert len(nodes) == len(set(nodes))
+            assert float(g["real_prize"][b][nodes].sum()) >= 1 - 1e-5 or len(nodes) == g["locs"].shape[1] - 1
+
+
+@pytest.mark.parametrize("name", ["ea_op20_default", "ea_op20_busy", "ea_op50_busy"])
+def test_ea_op_run_matches_reference(name):
+    """EA.run of the reference on OP (order_crossover_op + inverse_mutate_op, recorded draws; tie-free runs with
+    exactly summable prizes, see make_golden_ea.py) vs the restatement: identical populations, feasible routes."""
+    from oracle import ea_oracle as ea
+
+    g = golden(name)
+    for b in range(g["locs"].shape[0]):
+        pop, fit = ea.ea_run_op(g["locs"][b], g["prize"][b], g["max_length"][b], g["init_pop"][b],
+                                int(g["num_generations"]), float(g["mutation_rate"]), float(g["crossover_rate"]),
+                                float(g["selection_rate"]), g["init_mut_rand"][b], g["cross_rand"][:, b],
+                                g["mut_rand"][:, b], _prize_rint(g, b), top_k=bool(g["top_k"]))
+        np.testing.assert_array_equal(pop, g["pop"][b])
+        np.testing.assert_array_equal(fit, g["fitness"][b])          # sums of multiples of 2^-20: exact in any order
+        dist = ea.op_dist_matrix(g["locs"][b]).astype(np.float64)
+        for row in pop:
+            nodes = [x for x in row.tolist() if x]
+            assert len(nodes) == len(set(nodes))
+            path = [0] + row.tolist() + [0]
+            assert sum(dist[a, c] for a, c in zip(path[:-1], path[1:])) <= float(g["max_length"][b][0]) + 1e-5
+
+
+def test_ea_op_operators_match_reference():
+    """Single calls of the reference's OP operators: ordinary parents come back unchanged from the crossover, the
+    degenerate ones [customer, 0, ...] are rebuilt; rows with interior depot visits go through the mutation."""
+    from oracle import ea_oracle as ea
+
+    g = golden("ea_op_operators")
+    dist = ea.op_dist_matrix(g["locs"])
+    n = g["parents"].shape[0]
+    u = {(("cross", 0), p, 0): g["cross_u"][p] for p in range(n // 2)}
+    off = ea.order_crossover_op(g["parents"], float(g["crossover_rate"]), g["prize"], dist, g["max_length"], g["cross_rand"],
+                                ea.StructuredDraws(u), ("cross", 0))
+    np.testing.assert_array_equal(off, g["offspring"])
+    assert (off != g["parents"]).any(-1).sum() >= 4
+    u = {(("mut", 0), i, k): g["mut_u"][i, k] for i in range(n) for k in range(2)}
+    mut = ea.inverse_mutate_op(g["offspring"], float(g["mutation_rate"]), g["prize"], dist, g["max_length"], g["mut_rand"],
+                               ea.StructuredDraws(u), ("mut", 0))
+    np.testing.assert_array_equal(mut, g["mutated"])
+
+
 @pytest.mark.parametrize("name", ["tsp20_beam", "tsp20_beam5_all", "cvrp20_beam", "tsp50_beam12_all", "sdvrp20_beam", "pctsp20_beam"])
 def test_beam_search_matches_reference(oracle, name):
     """decode_type="beam_search" of the reference (beam_width = num_loc or given, with and without select_best)."""
