@@ -490,6 +490,28 @@ __attribute__((visibility("default"))) int eamrl_sum_logp(const float* logp, int
     return launched(launch_sum_logp(logp, ld, out, R, T, (hipStream_t)stream), "eamrl_sum_logp");
 }
 
+__attribute__((visibility("default"))) int eamrl_rollout_finish(int env, const float* locs, const int64_t* actions,
+                                                               const float* logp, int64_t ld, const float* demand,
+                                                               const float* vcap, float* reward, float* ll, int32_t* bad,
+                                                               int64_t R, int64_t B, int M, int T, void* stream)
+{
+    REQUIRE(env == EAMRL_ENV_TSP || env == EAMRL_ENV_CVRP, "eamrl_rollout_finish (TSP or CVRP)");
+    REQUIRE(locs && actions && R >= 0 && B > 0 && M >= 2 && M <= 4096 && T > 0, "eamrl_rollout_finish");
+    REQUIRE(!ll || (logp && ld >= T), "eamrl_rollout_finish (logp)");
+    if (env == EAMRL_ENV_CVRP && bad) REQUIRE(demand && vcap, "eamrl_rollout_finish (demand, vcap)");
+    if (R == 0) return 0;
+    return launched(launch_rollout_finish(env, locs, actions, logp, ld, demand, vcap, reward, ll, bad, R, B, M, T,
+                                          (hipStream_t)stream), "eamrl_rollout_finish");
+}
+
+__attribute__((visibility("default"))) int eamrl_multi_copy(int n, const void* const* src, void* const* dst,
+                                                           const int64_t* bytes, void* stream)
+{
+    REQUIRE(n >= 0 && n <= EAMRL_MULTI_COPY_MAX && (n == 0 || (src && dst && bytes)), "eamrl_multi_copy");
+    for (int i = 0; i < n; ++i) REQUIRE(bytes[i] >= 0 && (bytes[i] == 0 || dst[i]), "eamrl_multi_copy (segment)");
+    return launched(launch_multi_copy(n, src, dst, bytes, (hipStream_t)stream), "eamrl_multi_copy");
+}
+
 __attribute__((visibility("default"))) int eamrl_check_solution(int env, const int64_t* actions, const float* demand,
                                                                const float* vcap, int64_t R, int64_t B, int N, int T,
                                                                int32_t* bad, void* stream)

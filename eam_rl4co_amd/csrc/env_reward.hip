@@ -631,6 +631,119 @@ __global__ __launch_bounds__(EB) void k_check_solution(int env, const int64_t* a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Rollout epilogue in one launch (TSP / CVRP): reward (k_tour_length), validity (k_check_solution) and the log-likelihood
+// (k_sum_logp) of a row by one wavefront, in exactly the orders of the three kernels it replaces.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EB) void k_rollout_finish(int env, const float* locs, const int64_t* actions, const float* logp,
+                                                       int64_t ld, const float* demand, const float* vcap, float* reward,
+                                                       float* ll, int32_t* bad, int64_t R, int64_t B, int M, int T)
+{
+    __shared__ uint32_t seen_all[ROWS_PER_BLOCK][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wv;
+    if (r >= R) return;
+    const int with_depot = env != EAMRL_ENV_TSP;
+    const float* L = locs + (r % B) * (int64_t)M * 2;
+    const int64_t* act = actions + r * T;
+    // ---- tour length: lane tree over the legs --------------------------------------------------------------------------
+    if (reward) {
+        const int P = T + with_depot;
+        float total = 0.0f;
+        for (int b0 = 0; b0 < P; b0 += 64) {
+            const int t = b0 + lane;
+            float d = 0.0f;
+            if (t < P) {
+                int64_t a0, a1;
+                if (with_depot) {
+                    a0 = (t == 0) ? 0 : act[t - 1];
+                    a1 = (t + 1 == P) ? 0 : act[t];
+                } else {
+                    a0 = act[t];
+                    a1 = act[(t + 1 == P) ? 0 : t + 1];
+                }
+                a0 = a0 < 0 ? 0 : (a0 >= M ? M - 1 : a0);
+                a1 = a1 < 0 ? 0 : (a1 >= M ? M - 1 : a1);
+                const float2 p0 = *reinterpret_cast<const float2*>(L + 2 * a0);
+                const float2 p1 = *reinterpret_cast<const float2*>(L + 2 * a1);
+                const float dx = p1.x - p0.x, dy = p1.y - p0.y;
+                d = __builtin_sqrtf(fma_(dy, dy, dx * dx));
+            }
+            const float s = wave_tree_sum(d);
+            total = (b0 == 0) ? s : total + s;
+        }
+        if (lane == 0) reward[r] = -total;
+    }
+    // ---- log-likelihood: strictly sequential over the steps --------------------------------------------------------------
+    if (ll) {
+        float s = 0.0f;
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const float v = (t0 + lane < T) ? logp[r * ld + t0 + lane] : 0.0f;
+            const int tn = T - t0 < 64 ? T - t0 : 64;
+#pragma unroll
+            for (int t = 0; t < 64; ++t)
+                if (t < tn) s = s + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
+        }
+        if (lane == 0) ll[r] = s;
+    }
+    // ---- validity ---------------------------------------------------------------------------------------------------------
+    if (!bad) return;
+    uint32_t* seen = seen_all[wv];
+    for (int i = lane; i < 128; i += 64) seen[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int N = with_depot ? M - 1 : M;
+    const int top = with_depot ? N : N - 1;
+    int bad_lane = 0;
+    for (int t = lane; t < T; t += 64) {
+        const int64_t a = act[t];
+        if (a < 0 || a > top) { bad_lane = 1; continue; }
+        if (with_depot && a == 0) continue;
+        const uint32_t bit = 1u << (a & 31);
+        const uint32_t old = atomicOr(&seen[a >> 5], bit);
+        if (old & bit) bad_lane = 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int n = with_depot + lane; n <= top; n += 64)
+        if (!((seen[n >> 5] >> (n & 31)) & 1u)) bad_lane = 1;
+    const bool invalid = __ballot(bad_lane != 0) != 0ull;
+    if (lane != 0) return;
+    if (invalid) { atomicAdd(&bad[0], 1); return; }
+    if (with_depot) {
+        const float cap = vcap[r], lim = cap + 1e-5f;
+        const float* dem = demand + (r % B) * N;
+        float usedc = 0.0f;
+        int over = 0;
+        for (int t = 0; t < T; ++t) {
+            const int64_t a = act[t];
+            usedc = usedc + ((a == 0) ? -cap : dem[a - 1]);
+            if (usedc < 0.0f) usedc = 0.0f;
+            if (usedc > lim) over = 1;
+        }
+        if (over) atomicAdd(&bad[1], 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Several small device copies / zero fills in one launch (state clones and output buffers of a rollout, the input
+// refresh of a replayed graph): blockIdx.y = segment, 16-byte vectors where both ends are aligned.
+// ---------------------------------------------------------------------------------------------------------------------
+struct MultiCopyArgs { const char* src[EAMRL_MULTI_COPY_MAX]; char* dst[EAMRL_MULTI_COPY_MAX]; int64_t bytes[EAMRL_MULTI_COPY_MAX]; };
+
+__global__ __launch_bounds__(256) void k_multi_copy(MultiCopyArgs a)
+{
+    const int seg = blockIdx.y;
+    const char* src = a.src[seg];
+    char* dst = a.dst[seg];
+    const int64_t n = a.bytes[seg];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool vec = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
+    const int64_t nv = vec ? n >> 4 : 0;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int64_t i = i0; i < nv; i += stride)
+        reinterpret_cast<uint4*>(dst)[i] = src ? reinterpret_cast<const uint4*>(src)[i] : z;
+    for (int64_t i = (nv << 4) + i0; i < n; i += stride) dst[i] = src ? src[i] : (char)0;
+}
+
 static inline unsigned row_blocks(int64_t R) { return (unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
 
 int launch_tsp_step(uint8_t* mask, int64_t* first, int64_t* cur, int64_t* istep, const int64_t* action,
@@ -736,6 +849,33 @@ int launch_tour_length(const float* locs, const int64_t* actions, float* reward,
 int launch_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, hipStream_t st)
 {
     hipLaunchKernelGGL(k_sum_logp, dim3((unsigned)((R + 63) / 64)), dim3(256), 0, st, logp, ld, out, R, T);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_rollout_finish(int env, const float* locs, const int64_t* actions, const float* logp, int64_t ld, const float* demand,
+                          const float* vcap, float* reward, float* ll, int32_t* bad, int64_t R, int64_t B, int M, int T,
+                          hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rollout_finish, dim3(row_blocks(R)), dim3(EB), 0, st, env, locs, actions, logp, ld, demand, vcap, reward,
+                       ll, bad, R, B, M, T);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_multi_copy(int n, const void* const* src, void* const* dst, const int64_t* bytes, hipStream_t st)
+{
+    MultiCopyArgs a;
+    int64_t mx = 0;
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        if (bytes[i] <= 0) continue;
+        a.src[m] = (const char*)src[i]; a.dst[m] = (char*)dst[i]; a.bytes[m] = bytes[i];
+        mx = bytes[i] > mx ? bytes[i] : mx;
+        ++m;
+    }
+    if (m == 0) return 0;
+    int64_t bx = (mx / 16 + 255) / 256;
+    bx = bx < 1 ? 1 : (bx > 2048 ? 2048 : bx);
+    hipLaunchKernelGGL(k_multi_copy, dim3((unsigned)bx, (unsigned)m), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 

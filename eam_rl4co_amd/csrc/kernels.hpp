@@ -72,6 +72,10 @@ int launch_op_check(const int64_t* actions, const float* locs, const float* maxl
 int launch_tour_length(const float* locs, const int64_t* actions, float* reward, int64_t R, int64_t B, int M, int T,
                        int with_depot, hipStream_t st, const float* penalty = nullptr);
 int launch_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, hipStream_t st);
+int launch_rollout_finish(int env, const float* locs, const int64_t* actions, const float* logp, int64_t ld, const float* demand,
+                          const float* vcap, float* reward, float* ll, int32_t* bad, int64_t R, int64_t B, int M, int T,
+                          hipStream_t st);
+int launch_multi_copy(int n, const void* const* src, void* const* dst, const int64_t* bytes, hipStream_t st);
 int launch_check_solution(int env, const int64_t* actions, const float* demand, const float* vcap, int64_t R, int64_t B,
                           int N, int T, int32_t* bad, hipStream_t st);
 int launch_beam_topk(const float* logprobs, const float* parent, int64_t B, int BW, int M, int64_t* node, int32_t* beam,

@@ -26,6 +26,13 @@ namespace eamrl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef EAMRL_STAMPS   // development build only (tools/build_stamps.sh): per-phase cycle sums over all wavefronts
+__device__ unsigned long long g_ms_stamps[24];
+#define MSTAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_t; st_t = now_; } while (0)
+#else
+#define MSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int ME = 128, MH = 8;
@@ -133,6 +140,9 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
 
     const int nqt = (S + 15) >> 4;
     int t = 0;
+#ifdef EAMRL_STAMPS
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_readcyclecounter();
+#endif
     for (;;) {
         int active = 0;
         for (int s = tid; s < S; s += blockDim.x) active |= !s_done[s];
@@ -161,7 +171,9 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
             const bool live = sq < S && !s_done[sq];
             uint4 mb = make_uint4(0, 0, 0, 0);
             if (live) mb = *reinterpret_cast<const uint4*>(&s_bits[sq][0]);
+            MSTAMP(0);
             __syncthreads();
+            MSTAMP(1);
             // ---- glimpse of head wv ------------------------------------------------------------------------------------------
             {
                 const float* qp = QT + j * TS + G * TG + 4 * wv;
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
                         m = vmax_raw(m, s[kt][r]);
                     }
                 m = group_max(m);
+                MSTAMP(2);
                 // softmax weights; a masked node has s = -inf and d_expf2_nonpos gives it exactly 0 (as the canonical select does)
 #pragma unroll
                 for (int kt = 0; kt < RTT; ++kt) {
@@ -193,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
                     const f32x2 e23 = d_expf2_nonpos((f32x2){s[kt][2] - m, s[kt][3] - m});
                     s[kt] = (f32x4){e01.x, e01.y, e23.x, e23.y};
                 }
+                MSTAMP(3);
                 // Value product per node chunk g = [g C, (g+1) C), chunks in ascending order: `cur` accumulates the chunk in
                 // progress (A_g against V^T, Z_g against a row of ones), `tot` the finished ones as ((A0 + A1) + A2) + A3.
                 // K-step t holds nodes 4 t .. 4 t + 3 (this lane: 4 t + G); where it straddles a chunk boundary it is issued
@@ -232,7 +246,9 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hp[r * TG] = tot_o[r] / tot_z[r];
             }
+            MSTAMP(4);
             __syncthreads();
+            MSTAMP(5);
             // ---- logits of key tile wv, finish ----------------------------------------------------------------------------
             float x[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             bool fe[4] = {false, false, false, false};
@@ -255,6 +271,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
                         c[g] = mf(lpf[64 * (8 * g + 4 * u + 3)], hi.y, c[g]);
                     }
                 }
+                MSTAMP(6);
                 if (a.mode == EAMRL_SAMPLE && live) {
                     const int64_t r = (int64_t)sq * a.B + b;
                     if (a.use_rng) {
@@ -266,6 +283,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
                             if (nbase + rr < M) nz[rr] = np_[nbase + rr];
                     }
                 }
+                MSTAMP(7);
                 f32x2 v01, v23;
                 {
                     const f32x4 u = ((c[0] + c[1]) + c[2]) + c[3];
@@ -289,7 +307,9 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
                 const float mx = group_max(vmax_raw(vmax_raw(x[0], x[1]), vmax_raw(x[2], x[3])));
                 if (G == 0) RED[wv][j] = mx;
             }
+            MSTAMP(8);
             __syncthreads();
+            MSTAMP(9);
             float mq = -INFINITY;
 #pragma unroll
             for (int w = 0; w < RTT; ++w) mq = vmax_raw(mq, RED[w][j]);
@@ -302,7 +322,9 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
                 const float ts = group_sum((e0 + e1) + (e2 + e3));      // lane tree levels 1, 2 (in lane), 4, 8 (lane groups)
                 if (G == 0) RED2[wv][j] = ts;
             }
+            MSTAMP(10);
             __syncthreads();
+            MSTAMP(11);
             float lse, lp[4];
             {
                 float T[8];
@@ -354,7 +376,9 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
             }
             if (wv == 0 && G == 0) SEL[j] = sel;
             if (fl) atomicOr(&s_flags, fl);
+            MSTAMP(12);
             __syncthreads();
+            MSTAMP(13);
             // ---- env transition (TSPEnv._step, tsp/env.py:62-88) of the tile's 16 starts -------------------------------------
             if (tid < 16) {
                 const int s = 16 * qt + tid;
@@ -375,9 +399,16 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
                 }
             }
             // (the next tile's first barrier orders this against its readers; the tile buffers are rewritten only after it)
+            MSTAMP(14);
         }
         ++t;
     }
+#ifdef EAMRL_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_ms_stamps[i], st_acc[i]);
+        atomicAdd(&g_ms_stamps[16], 1ull);
+    }
+#endif
     // ---- final state -------------------------------------------------------------------------------------------------------------
     __syncthreads();
     for (int s = tid; s < S; s += blockDim.x) {
@@ -409,6 +440,18 @@ int launch_t(const DecArgs& a, int S, hipStream_t st)
 }
 
 }  // namespace
+
+#ifdef EAMRL_STAMPS
+extern "C" __attribute__((visibility("default"))) int eamrl_debug_read_ms_stamps(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ms_stamps), sizeof(g_ms_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[24] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ms_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 bool rollout_ms_mfma_supports(int env, const DecArgs& a)
 {

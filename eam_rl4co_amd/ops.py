@@ -602,6 +602,62 @@ def sum_logp(logp):
     return out
 
 
+MULTI_COPY_MAX = 16
+
+
+def multi_copy_(pairs):
+    """[(dst, src | None), ...] -> dst.copy_(src) / dst.zero_() for all of them in ONE launch per 16 segments
+    (eamrl_multi_copy).  Tensors must be contiguous, on the same device, src of dst's dtype and size."""
+    lib = _lib.load()
+    segs = []
+    for dst, src in pairs:
+        _need_gpu(dst, "multi_copy dst")
+        if not dst.is_contiguous():
+            raise ValueError("multi_copy: dst must be contiguous")
+        if src is not None:
+            if src.dtype != dst.dtype or src.numel() != dst.numel() or not src.is_contiguous() or src.device != dst.device:
+                raise ValueError("multi_copy: src must be a contiguous tensor of dst's dtype, size and device")
+        if dst.numel():
+            segs.append((dst, src))
+    for i in range(0, len(segs), MULTI_COPY_MAX):
+        part = segs[i:i + MULTI_COPY_MAX]
+        n = len(part)
+        srcs = (C.c_void_p * n)(*[None if s_ is None else s_.data_ptr() for _, s_ in part])
+        dsts = (C.c_void_p * n)(*[d.data_ptr() for d, _ in part])
+        nbytes = (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in part])
+        _lib.check(lib.eamrl_multi_copy(n, srcs, dsts, nbytes, _stream(part[0][0])), "eamrl_multi_copy")
+
+
+def rollout_finish(env_name, locs, actions, logp=None, demand=None, vcap=None, want_reward=True, bad=None):
+    """Reward, summed log-likelihood and validity counters of TSP / CVRP tours in one launch (eamrl_rollout_finish):
+    bit-identical to tour_length_reward / sum_logp / check_solution.  bad: int32[2] device tensor to add to, or None.
+    -> (reward [R] | None, ll [R] | None)."""
+    lib = _lib.load()
+    _chk(locs, "locs", torch.float32)
+    _chk(actions, "actions", torch.int64)
+    B, M, _ = locs.shape
+    R, T = actions.shape
+    if R % B:
+        raise ValueError("rollout_finish: rows must be a multiple of the number of instances")
+    reward = torch.empty(R, device=locs.device, dtype=torch.float32) if want_reward else None
+    ll, ld = None, 0
+    if logp is not None:
+        _need_gpu(logp, "logp")
+        if logp.dtype != torch.float32 or logp.shape != actions.shape or logp.stride(1) != 1:
+            raise ValueError("rollout_finish: logp must be [R, T] fp32 with unit inner stride")
+        ll, ld = torch.empty(R, device=locs.device, dtype=torch.float32), logp.stride(0)
+    vc = None
+    if env_name == "cvrp" and bad is not None:
+        _chk(demand, "demand", torch.float32, (B, M - 1))
+        vc = vcap.reshape(-1).contiguous()
+        if vc.numel() != R:
+            vc = vc.repeat(R // vc.numel())
+        _chk(vc, "vehicle_capacity", torch.float32, (R,))
+    _lib.check(lib.eamrl_rollout_finish(ENVS[env_name], _ptr(locs), _ptr(actions), _ptr(logp), ld, _ptr(demand), _ptr(vc),
+                                        _ptr(reward), _ptr(ll), _ptr(bad), R, B, M, T, _stream(locs)), "eamrl_rollout_finish")
+    return reward, ll
+
+
 def check_solution(env_name, actions, demand=None, vcap=None, num_loc=None):
     """-> device int32[2]: (invalid tours, over-capacity rows); sdvrp: (rows with demand left, double depot visits)."""
     lib = _lib.load()
@@ -933,11 +989,23 @@ def exp1_noise(seed: int, R: int, T: int, M: int, device="cuda", seed_dev=None):
     return out
 
 
+def _rollout_outputs(R, t_max, dev):
+    """actions [R, t_max] i64, logps [R, t_max] f32 and flags int32[4] = (steps, status, bad0, bad1) as views of ONE
+    zero-filled buffer (one fill launch instead of three)."""
+    n = R * t_max
+    buf = torch.zeros(n * 12 + 16, dtype=torch.uint8, device=dev)
+    actions = buf[:n * 8].view(torch.int64).view(R, t_max)
+    logps = buf[n * 8:n * 12].view(torch.float32).view(R, t_max)
+    flags = buf[n * 12:].view(torch.int32)
+    return actions, logps, flags
+
+
 def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0,
-            t_max=None, top_k=0, top_p=0.0, seed=None, seed_dev=None):
+            t_max=None, top_k=0, top_p=0.0, seed=None, seed_dev=None, return_flags=False):
     """Whole decode loop in one launch.  -> (actions [R,t_max], logps [R,t_max], info int32[2] = (steps, status)).
     Sampling takes its Exp(1) noise from `noise` [R, T, M] or, with `seed` (XOR the device word `seed_dev`), from the counter-based
-    generator -- in place where the kernel supports it (TSP multistart), else through a scratch tensor of the same draws."""
+    generator -- in place where the kernel supports it (TSP multistart), else through a scratch tensor of the same draws.
+    return_flags: info is int32[4] = (steps, status, 0, 0), the last two free for the caller's validity counters."""
     lib = _lib.load()
     _validate_state(st, cache)
     R, M, dev = st.R, st.M, st.mask.device
@@ -949,9 +1017,7 @@ def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, giv
         if top_k or (0.0 < top_p < 1.0):
             noise = exp1_noise(seed, R, int(t_max), M, dev, seed_dev)      # the filtering (streaming) kernel reads a tensor
         else:
-            actions = torch.zeros(R, t_max, dtype=torch.int64, device=dev)
-            logps = torch.zeros(R, t_max, dtype=torch.float32, device=dev)
-            info = torch.zeros(2, dtype=torch.int32, device=dev)
+            actions, logps, info = _rollout_outputs(R, int(t_max), dev)
             cs, ss = cache.struct(), st.struct()
             native = lib.eamrl_rollout_rng_native(ENVS[st.env_name], C.byref(cs), R)
             scratch = None if native else torch.empty(R, t_max, M, dtype=torch.float32, device=dev)
@@ -961,7 +1027,7 @@ def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, giv
                                                    float(temp), int(t_max), _ptr(actions), _ptr(logps),
                                                    C.c_void_p(info.data_ptr()), C.c_void_p(info.data_ptr() + 4),
                                                    _stream(st.mask)), "eamrl_am_rollout_seeded")
-            return actions, logps, info
+            return actions, logps, (info if return_flags else info[:2])
     t_given = 0
     if noise is not None:
         _chk(noise, "noise", torch.float32)
@@ -978,9 +1044,7 @@ def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, giv
         t_given = given.shape[1]
         if noise is None:
             t_max = min(t_max, t_given) if st.env_name != "tsp" else t_max
-    actions = torch.zeros(R, t_max, dtype=torch.int64, device=dev)
-    logps = torch.zeros(R, t_max, dtype=torch.float32, device=dev)
-    info = torch.zeros(2, dtype=torch.int32, device=dev)  # [steps, status]
+    actions, logps, info = _rollout_outputs(R, int(t_max), dev)          # info: [steps, status, -, -]
     cs, ss = cache.struct(), st.struct()
     steps_ptr = C.c_void_p(info.data_ptr())
     status_ptr = C.c_void_p(info.data_ptr() + 4)
@@ -988,7 +1052,7 @@ def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, giv
                                     _ptr(given), t_given, float(clip), float(temp), int(top_k), float(top_p), int(t_max),
                                     _ptr(actions),
                                     _ptr(logps), steps_ptr, status_ptr, _stream(st.mask)), "eamrl_am_rollout")
-    return actions, logps, info
+    return actions, logps, (info if return_flags else info[:2])
 
 
 def raise_on_status(status: int):

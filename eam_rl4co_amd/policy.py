@@ -499,6 +499,7 @@ def state_from_td(env_name, td, num_starts: int = 0, copy: bool = True) -> ops.R
                            "device; there is no CPU fallback. Use td.to('cuda').")
     st = ops.RolloutState.__new__(ops.RolloutState)
     st.env_name, st.R, st.M = env_name, B * S, M
+    clones = []                                           # (dst, src): all clones of a call go out as ONE launch
 
     def rep(t, dtype):
         src = t
@@ -508,7 +509,12 @@ def state_from_td(env_name, td, num_starts: int = 0, copy: bool = True) -> ops.R
         if S > 1:
             t = t.repeat(S, *([1] * (t.dim() - 1)))
         elif copy and t.data_ptr() == src.data_ptr():     # still the caller's storage
-            t = t.clone()
+            if t.is_contiguous():
+                dst = torch.empty_like(t)
+                clones.append((dst, t))
+                t = dst
+            else:
+                t = t.clone()
         t = t.contiguous()
         return t.reshape(-1) if t.dim() == 2 and t.shape[1] == 1 else t
 
@@ -547,6 +553,8 @@ def state_from_td(env_name, td, num_starts: int = 0, copy: bool = True) -> ops.R
             st.locs = td["locs"].contiguous()
             st.tw = td["time_windows"].to(torch.float32).contiguous()
             st.dur = td["durations"].to(torch.float32).contiguous()
+    if clones:
+        ops.multi_copy_(clones)
     return st
 
 
@@ -775,7 +783,8 @@ class AttentionModelPolicy(nn.Module):
             info = None
         else:
             acts, lps, info = ops.rollout(st, cache, mode, noise=noise, given=given, clip=tanh_clipping,
-                                          temp=temperature, t_max=t_max, top_k=top_k, top_p=top_p, seed=seed, seed_dev=seed_dev)
+                                          temp=temperature, t_max=t_max, top_k=top_k, top_p=top_p, seed=seed, seed_dev=seed_dev,
+                                          return_flags=True)          # int32[4]: steps, status, 2 free validity counters
         # Everything below is enqueued on the PADDED [R, t_max] arrays before the rollout's single host sync:
         # padding is depot visits with log-prob 0, which change neither the tour length (zero-length legs, and
         # x + 0 is exact in the lane tree), nor the log-likelihood sum, nor validity.
@@ -784,7 +793,15 @@ class AttentionModelPolicy(nn.Module):
         native_env = type(env).__name__ in ("TSPEnv", "CVRPEnv", "SDVRPEnv", "PCTSPEnv", "SPCTSPEnv", "OPEnv", "CVRPTWEnv") and type(env).__module__ == RL4COEnvBase.__module__
         fast = info is not None and native_env and not select_best
         reward_pad = ll_pad = bad = None
-        if fast:
+        one_launch = fast and self.env_name in ("tsp", "cvrp") and calc_reward
+        if one_launch:              # reward + validity + log-likelihood of a row by one wavefront, one launch
+            want_ll = return_sum_log_likelihood and "mask" not in td.keys()
+            bad = info[2:] if env.check_solution else None
+            reward_pad, ll_pad = ops.rollout_finish(self.env_name, td["locs"].contiguous(), actions_pad,
+                                                    logp_pad if want_ll else None,
+                                                    td["demand"].contiguous() if self.env_name == "cvrp" else None,
+                                                    st.vcap, bad=bad)
+        elif fast:
             locs = td["locs"].contiguous()
             if calc_reward:
                 if self.env_name == "pctsp":        # depot padding: zero-length legs and zero penalties, exact
@@ -804,7 +821,10 @@ class AttentionModelPolicy(nn.Module):
                 ll_pad = ops.sum_logp(logp_pad)
         flags = None
         if info is not None:
-            flags = torch.cat((info, bad)) if bad is not None else info
+            if one_launch:
+                flags = info if bad is not None else info[:2]
+            else:
+                flags = torch.cat((info[:2], bad)) if bad is not None else info[:2]
         else:
             flags = torch.tensor([T, status], dtype=torch.int32)
         return dict(flags=flags, has_bad=bad is not None, pre=1 if pre_actions else 0, t_max=t_max, M=M, S=S,
@@ -1086,12 +1106,18 @@ class GraphedRollout:
         net = getattr(self.policy.encoder, "net", None)
         if hasattr(net, "_fused_layers"):
             net._fused_layers(self._embed_probe)          # re-packs changed encoder weights into the buffers the graph reads
+        pairs = []
         for k in self._keys:
             src = td[k]
             dst = self.static_td[k]
             if src.shape != dst.shape or src.dtype != dst.dtype:
                 raise ValueError(f"GraphedRollout was captured for {k}: {tuple(dst.shape)} {dst.dtype}")
-            dst.copy_(src)
+            if src.is_contiguous() and dst.is_contiguous() and src.device == dst.device:
+                pairs.append((dst, src))
+            else:
+                dst.copy_(src)
+        if pairs:
+            ops.multi_copy_(pairs)       # all inputs in one launch
         self.graph.replay()
         out = self.policy._finish(self._pending)
         return {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}

@@ -370,6 +370,20 @@ int eamrl_op_check_solution(const int64_t* actions, const float* locs, const flo
 /* out[r] = sum_t logp[r][t], sequential  (get_log_likelihood, utils/decoding.py:38-64) */
 int eamrl_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, void* stream);
 
+/* The epilogue of a TSP / CVRP rollout in one launch: reward[r] = get_reward [tsp/env.py:90-100, cvrp/env.py:146-155]
+ * (as eamrl_tour_length), ll[r] = sum_t logp[r][t] (as eamrl_sum_logp), bad += check_solution_validity (as
+ * eamrl_check_solution) -- each in the order of the single-purpose entry point, so the results are bit-identical.
+ * locs [B][M][2] (CVRP: depot first, M = N + 1); demand [B][M-1], vcap [R] for CVRP; reward / ll / bad may be NULL. */
+int eamrl_rollout_finish(int env, const float* locs, const int64_t* actions, const float* logp, int64_t ld,
+                         const float* demand, const float* vcap, float* reward, float* ll, int32_t* bad, int64_t R,
+                         int64_t B, int M, int T, void* stream);
+
+/* n <= EAMRL_MULTI_COPY_MAX device-to-device copies (src[i] != NULL) or zero fills (src[i] == NULL) of bytes[i] bytes
+ * in one launch: the state clones and output buffers of a rollout (the reference clones its TensorDict per call,
+ * constructive/base.py:203-217) and the input refresh of a replayed HIP graph.  src / dst / bytes are HOST arrays. */
+#define EAMRL_MULTI_COPY_MAX 16
+int eamrl_multi_copy(int n, const void* const* src, void* const* dst, const int64_t* bytes, void* stream);
+
 /* check_solution_validity on the device: bad[0] += invalid tours, bad[1] += over-capacity rows
  * [tsp/env.py:161-168; cvrp/env.py:157-185].  bad: device int32[2], caller zeroes.
  * EAMRL_ENV_PCTSP [pctsp/env.py:189-205]: demand = real_prize [B][N+1], vcap unused; bad[0] += rows with a customer

@@ -729,6 +729,76 @@ def test_eam_single_start_improvement(env_name):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# launch fusion helpers: eamrl_multi_copy, eamrl_rollout_finish
+# ---------------------------------------------------------------------------------------------------------
+def test_multi_copy_segments():
+    """Copies and zero fills of mixed dtypes / sizes (odd byte counts, unaligned views, > 16 segments) in fused launches."""
+    from eam_rl4co_amd import ops
+
+    torch.manual_seed(0)
+    pairs, expect = [], []
+    base = torch.randint(0, 255, (4099,), dtype=torch.uint8, device=DEV)
+    for i, (n, dt) in enumerate([(1, torch.bool), (7, torch.uint8), (1024 * 100, torch.bool), (1024, torch.int64), (333, torch.float32),
+                                 (5, torch.int32), (0, torch.float32), (100_003, torch.uint8), (64, torch.float64)] * 2 + [(17, torch.int16)]):
+        if dt in (torch.bool,):
+            src = torch.rand(n, device=DEV) > 0.5
+        elif dt.is_floating_point:
+            src = torch.randn(n, device=DEV, dtype=dt)
+        else:
+            src = torch.randint(0, 100, (n,), device=DEV).to(dt)
+        dst = torch.full_like(src, 1)
+        pairs.append((dst, src)); expect.append(src.clone())
+    unal_src, unal_dst = base[3:4000], torch.zeros(4099, dtype=torch.uint8, device=DEV)[5:4002]      # 3 / 5 bytes off alignment
+    pairs.append((unal_dst, unal_src)); expect.append(unal_src.clone())
+    z = torch.full((777,), 3.5, device=DEV)
+    pairs.append((z, None)); expect.append(torch.zeros(777, device=DEV))
+    assert len(pairs) > ops.MULTI_COPY_MAX
+    ops.multi_copy_(pairs)
+    for (dst, _), e in zip(pairs, expect):
+        assert torch.equal(dst, e)
+    with pytest.raises(ValueError):
+        ops.multi_copy_([(torch.zeros(4, device=DEV), torch.zeros(5, device=DEV))])
+
+
+@pytest.mark.parametrize("env_name,N,B,S", [("tsp", 20, 7, 1), ("tsp", 100, 33, 1), ("tsp", 50, 4, 10), ("cvrp", 20, 9, 1),
+                                            ("cvrp", 100, 17, 1), ("cvrp", 50, 3, 12), ("tsp", 150, 5, 1)])
+def test_rollout_finish_equals_the_three_kernels(env_name, N, B, S):
+    """eamrl_rollout_finish == eamrl_tour_length + eamrl_sum_logp + eamrl_check_solution bit for bit, on real rollouts
+    (depot padding included) and on corrupted tours (duplicates, over-capacity, out-of-range ids)."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import ops
+
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=N + B)
+    torch.manual_seed(N)
+    td = env.reset(batch_size=[B]).to(DEV)
+    pol = make_policy("am_" + env_name)
+    kw = dict(decode_type="multistart_sampling", num_starts=S) if S > 1 else dict(decode_type="sampling")
+    out = pol(td.clone(), env, phase="test", return_sum_log_likelihood=False, **kw)
+    acts, lp = out["actions"].contiguous(), out["log_likelihood"].contiguous()
+    R = acts.shape[0]
+    locs = td["locs"].contiguous()
+    demand = td["demand"].contiguous() if env_name == "cvrp" else None
+    vcap = td["vehicle_capacity"].reshape(-1).repeat(max(S, 1)) if env_name == "cvrp" else None
+    for corrupt in (False, True):
+        a = acts.clone()
+        if corrupt:
+            a[0, 1] = a[0, 2]                       # a customer twice
+            a[R // 2, 0] = N + 5                    # out of range
+            if env_name == "cvrp":
+                row = a[R - 1]
+                a[R - 1] = torch.where(row == 0, row[0], row)      # no depot returns: over capacity / duplicates
+        bad = torch.zeros(2, dtype=torch.int32, device=DEV)
+        reward, ll = ops.rollout_finish(env_name, locs, a, lp, demand, vcap, bad=bad)
+        assert_bits_equal(reward, ops.tour_length_reward(locs, a, with_depot=env_name != "tsp").cpu().numpy(), "reward")
+        assert_bits_equal(ll, ops.sum_logp(lp).cpu().numpy(), "log-likelihood")
+        ref_bad = ops.check_solution(env_name, a, demand, vcap) if env_name == "cvrp" else ops.check_solution("tsp", a, num_loc=N)
+        assert bad.tolist() == ref_bad.tolist()
+        assert (sum(bad.tolist()) > 0) == corrupt
+        r2, l2 = ops.rollout_finish(env_name, locs, a, None, demand, vcap, bad=None)
+        assert l2 is None and torch.equal(r2, reward)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # beam search (decode_type="beam_search"): step API + eamrl_beam_topk
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,BW,M", [(1, 2, 3), (5, 20, 20), (3, 7, 101), (2, 128, 128), (4, 100, 101)])
