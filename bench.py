@@ -316,6 +316,10 @@ def main():
     env = ea.get_env(env_name, generator_params=dict(num_loc=num_loc), seed=1234 + rank)
     torch.manual_seed(1234 + rank)
     td0 = env.reset(batch_size=[batch]).to(device)         # synthetic uniform-[0,1]^2 instances, resident in HBM
+    # the timed steps rotate through NBATCH different synthetic batches (all resident before the clock starts), so that no
+    # step meets the instances of the step before it in a cache
+    NBATCH = 4
+    tds = [td0] + [env.reset(batch_size=[batch]).to(device) for _ in range(NBATCH - 1)]
     pomo = args.workload.startswith("pomo")
     policy = build_policy(env_name, device, pomo=pomo)
     M = td0["locs"].shape[1]
@@ -329,15 +333,21 @@ def main():
         policy.train()
         stepper = PolicyGradientStep(policy, env, num_starts=S)       # Adam(1e-4, wd 1e-6), clip 1.0, shared baseline
 
-    def make_step(td, graph=True):
-        if train:
-            return lambda: stepper(td)
-        g = None if (args.no_graph or not graph) else ea.GraphedRollout(policy, env, td, decode_type=decode_type, **dkw)
-        if g is not None:
-            return lambda: g(td)                      # copy inputs into the captured buffers + one graph replay
-        return lambda: policy(td.clone(), env, phase="test", decode_type=decode_type, **dkw)
+    def make_step(batches, graph=True):
+        it = {"i": 0}
 
-    one_step = make_step(td0)
+        def nxt():
+            it["i"] += 1
+            return batches[it["i"] % len(batches)]
+
+        if train:
+            return lambda: stepper(nxt())
+        g = None if (args.no_graph or not graph) else ea.GraphedRollout(policy, env, batches[0], decode_type=decode_type, **dkw)
+        if g is not None:
+            return lambda: g(nxt())                   # copy inputs into the captured buffers + one graph replay
+        return lambda: policy(nxt().clone(), env, phase="test", decode_type=decode_type, **dkw)
+
+    one_step = make_step(tds)
 
     # per launch family: HIP events around the calls on the launch stream, in eager passes before the timed region
     ft = FamilyTimer(torch)
@@ -402,8 +412,7 @@ def main():
     strong = None
     if world > 1 and not args.strong and not train and batch % world == 0:
         # the same GLOBAL batch as the 1-GPU run, split over the ranks (north_star: strong scaling)
-        td_s = td0[: batch // world]
-        el_s, _, _ = timed(make_step(td_s), args.steps, max(1, args.warmup))
+        el_s, _, _ = timed(make_step([t_[: batch // world] for t_ in tds]), args.steps, max(1, args.warmup))
         strong = {"global_batch": batch, "batch_per_gpu": batch // world, "ms_per_step": round(el_s / args.steps * 1e3, 4),
                   "value": round(batch * S * num_loc * args.steps / el_s, 1), "unit": "env-steps/s"}
 
@@ -491,7 +500,8 @@ def main():
             "metric": "env-steps/sec (batch x num_loc / s), AttentionModel construction rollout",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": f"synthetic (uniform instances, {NBATCH} different batches in rotation)",
             "config": cfg, "roofline": roofline, "roofline_decode": roofline_decode, "roofline_gemm": roofline_gemm,
             "roofline_attention": roofline_att, "roofline_encoder_fused": roofline_enc,
         }

@@ -32,7 +32,7 @@ class EncoderLayer(C.Structure):
 
 class EncoderCache(C.Structure):
     """struct eamrl_encoder_cache"""
-    _fields_ = [("Wc", _vp), ("WoutT", _vp), ("out", _vp), ("ld", _i64), ("nproj", C.c_int32)]
+    _fields_ = [("Wc", _vp), ("WoutT", _vp), ("out", _vp), ("ld", _i64), ("nproj", C.c_int32), ("Wg", _vp), ("gctx", _vp)]
 
 
 class Reeval(C.Structure):

@@ -394,12 +394,48 @@ __global__ void k_small_linear(GemmArgs g)
     g.y[r * g.ldy + j] = acc;
 }
 
+// the same, four adjacent outputs per thread (one 16-byte store): the init embeddings write B*M*E floats from 2-4 inputs,
+// i.e. the launch is a pure store stream.  in_dim is a template parameter and the epilogue is bias only, so that all loads of
+// a thread are issued before the first is consumed (with run-time trip counts they serialise behind s_waitcnt).
+template <int K>
+__global__ __launch_bounds__(256) void k_small_linear4(GemmArgs g)
+{
+    const int oq = g.out_dim >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.rows * oq) return;
+    const int64_t r = idx / oq;
+    const int j = 4 * (int)(idx - r * oq);
+    float x[K], w[4][K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) x[k] = g.x[r * g.ldx + k];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < K; ++k) w[c][k] = g.W[(int64_t)(j + c) * g.ldw + k];
+    float4 acc = g.bias ? *reinterpret_cast<const float4*>(g.bias + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        acc.x = fma_(x[k], w[0][k], acc.x);
+        acc.y = fma_(x[k], w[1][k], acc.y);
+        acc.z = fma_(x[k], w[2][k], acc.z);
+        acc.w = fma_(x[k], w[3][k], acc.w);
+    }
+    *reinterpret_cast<float4*>(g.y + r * g.ldy + j) = acc;
+}
+
 int launch_linear(const GemmArgs& g0, hipStream_t st)
 {
     GemmArgs g = g0;
     const bool force_valu = g_debug[0] != 0;
     if (g.rows <= 0) return 0;
-    if (g.in_dim <= 4) {
+    if (g.in_dim >= 2 && g.in_dim <= 4 && !g.wt && !g.relu && !g.res && !g.bn_gamma && (g.out_dim & 3) == 0 && (g.ldy & 3) == 0 &&
+        ((uintptr_t)g.y & 15) == 0 && (!g.bias || ((uintptr_t)g.bias & 15) == 0) && !force_valu) {
+        const int64_t n = g.rows * (g.out_dim >> 2);
+        const dim3 grid((unsigned)((n + 255) / 256));
+        if (g.in_dim == 2) hipLaunchKernelGGL(k_small_linear4<2>, grid, dim3(256), 0, st, g);
+        else if (g.in_dim == 3) hipLaunchKernelGGL(k_small_linear4<3>, grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(k_small_linear4<4>, grid, dim3(256), 0, st, g);
+    } else if (g.in_dim <= 4) {
         const int64_t n = g.rows * g.out_dim;
         hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g);
     } else if (!force_valu && g.rows * g.out_dim <= 16384) {

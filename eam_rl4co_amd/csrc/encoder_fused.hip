@@ -58,6 +58,8 @@ struct FusedArgs {
     // optional decoder cache (AttentionModelDecoder._precompute_cache) computed from the final embeddings while they are
     // still in LDS: slots 0 .. nproj-1 = h Wc_s^T (K | V | L | Pa (| Pb)), slot nproj = Lp = L Wout
     const float* Wc; const float* WoT; float* cache; int64_t ld; int nproj;
+    // optional graph context: gctx[inst] = mean_n(h) Wg^T (embeddings.mean(1) -> project_fixed_context, no bias)
+    const float* Wg; float* gctx;
     FusedLayer L[MAX_FUSED_LAYERS];
 };
 
@@ -469,6 +471,30 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
         }
     }
     ESTAMP(13);
+    // ---- graph context: mean over the nodes in node order (k_mean_nodes), then a k-ordered chain per output (k_linear) ----
+    if (a.gctx) {
+        float* MEAN = CST;                          // the layer constants are dead
+        if (tid < FE) {
+            const float* col = HB + (tid & 3) * GA + (tid >> 2);
+            float s = 0.0f;
+            for (int n = 0; n < M; ++n) s = s + col[n * SA];
+            MEAN[tid] = s / (float)M;
+        }
+        __syncthreads();
+        if (tid < FE) {
+            const float4* w = reinterpret_cast<const float4*>(a.Wg + (int64_t)tid * FE);
+            float acc = 0.0f;
+#pragma unroll 8
+            for (int k4 = 0; k4 < FE / 4; ++k4) {
+                const float4 wv4 = w[k4];
+                acc = fma_(MEAN[4 * k4 + 0], wv4.x, acc);
+                acc = fma_(MEAN[4 * k4 + 1], wv4.y, acc);
+                acc = fma_(MEAN[4 * k4 + 2], wv4.z, acc);
+                acc = fma_(MEAN[4 * k4 + 3], wv4.w, acc);
+            }
+            a.gctx[inst * FE + tid] = acc;
+        }
+    }
     // ---- decoder cache from the resident embeddings: nproj projections of h, then Lp = L Wout ------------------------------
     if (a.cache) {
         float* STG = QA;                           // L in the A layout (operand of the Lp pass); aliases the dead attention buffers
@@ -571,8 +597,11 @@ int launch_encoder_fused(const float* h_in, float* h_out, int64_t B, int M, int 
     if (B <= 0) return 0;
     FusedArgs a;
     a.h_in = h_in; a.h_out = h_out; a.M = M; a.nlayers = nlayers; a.norm = norm; a.eps = eps;
-    a.Wc = nullptr; a.WoT = nullptr; a.cache = nullptr; a.ld = 0; a.nproj = 0;
-    if (cache) { a.Wc = cache->Wc; a.WoT = cache->WoutT; a.cache = cache->out; a.ld = cache->ld; a.nproj = cache->nproj; }
+    a.Wc = nullptr; a.WoT = nullptr; a.cache = nullptr; a.ld = 0; a.nproj = 0; a.Wg = nullptr; a.gctx = nullptr;
+    if (cache) {
+        a.Wc = cache->Wc; a.WoT = cache->WoutT; a.cache = cache->out; a.ld = cache->ld; a.nproj = cache->nproj;
+        if (cache->Wg && cache->gctx) { a.Wg = cache->Wg; a.gctx = cache->gctx; }
+    }
     for (int l = 0; l < nlayers; ++l) {
         const eamrl_encoder_layer& s = layers[l];
         a.L[l] = FusedLayer{s.Wqkv, s.bqkv, s.Wo, s.bo, s.W1, s.b1, s.W2, s.b2, s.n1_gamma, s.n1_beta, s.n1_mean, s.n1_var,

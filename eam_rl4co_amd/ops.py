@@ -192,8 +192,8 @@ def encoder_fused_supported(M, E, H, ff_hidden, nlayers) -> bool:
 def encoder_fused(h, layers, num_heads, ff_hidden, norm, eps, cache=None):
     """All encoder layers of every instance in one launch.  h [B, M, E]; layers: list of dicts with the 16 fields of
     struct eamrl_encoder_layer (packed weights, biases, norm parameters; running stats may be None for instance norm).
-    cache = (Wc_packed, WoutT_packed, out [B, M, ld], nproj): also fill the slot-major decoder cache (struct
-    eamrl_encoder_cache)."""
+    cache = (Wc_packed, WoutT_packed, out [B, M, ld], nproj[, Wg [E, E], gctx [B, E]]): also fill the slot-major decoder
+    cache and, with the last two, the graph context (struct eamrl_encoder_cache)."""
     lib = _lib.load()
     _chk(h, "h", torch.float32)
     B, M, E = h.shape
@@ -209,7 +209,8 @@ def encoder_fused(h, layers, num_heads, ff_hidden, norm, eps, cache=None):
     out = torch.empty_like(h)
     cstruct = None
     if cache is not None:
-        Wc, WoT, buf, nproj = cache
+        Wc, WoT, buf, nproj = cache[:4]
+        Wg, gctx = cache[4:6] if len(cache) >= 6 else (None, None)
         _chk(Wc, "packed cache weights", torch.float32, (nproj * E * E,))
         _chk(WoT, "packed project_out^T", torch.float32, (E * E,))
         _chk(buf, "decoder cache", torch.float32)
@@ -217,6 +218,12 @@ def encoder_fused(h, layers, num_heads, ff_hidden, norm, eps, cache=None):
             raise ValueError("encoder_fused: cache buffer must be [B, M, >= (nproj + 1) * E]")
         cs = _lib.EncoderCache()
         cs.Wc, cs.WoutT, cs.out, cs.ld, cs.nproj = _ptr(Wc), _ptr(WoT), _ptr(buf), buf.shape[2], int(nproj)
+        if Wg is not None:
+            _chk(Wg, "project_fixed_context.weight", torch.float32, (E, E))
+            _chk(gctx, "graph context", torch.float32, (B, E))
+            if Wg.data_ptr() % 16:
+                raise ValueError("encoder_fused: Wg must be 16-byte aligned")
+            cs.Wg, cs.gctx = _ptr(Wg), _ptr(gctx)
         cstruct = C.byref(cs)
     _lib.check(lib.eamrl_encoder_fused(_ptr(h), _ptr(out), B, M, E, int(num_heads), int(ff_hidden), len(layers), int(norm),
                                        float(eps), C.cast(arr, C.c_void_p), cstruct, _stream(h)), "eamrl_encoder_fused")

@@ -52,6 +52,22 @@ class TSPInitEmbedding(nn.Module):
         return ops.linear(td["locs"].contiguous(), self.init_embed.weight, self.init_embed.bias)
 
 
+def _depot_and_customers(mod, locs, feat):
+    """[B, M, E] init embeddings of a depot env: row 0 = init_embed_depot(depot), rows 1.. = init_embed(customer features).
+    Both linears write straight into the result (no concatenation of [B, M, E] tensors): the customer linear runs over
+    all B*M rows of the zero-padded feature tensor -- one uniform row stride -- and the depot linear then overwrites
+    row 0 of every instance.  Same values as the two separate linears."""
+    B, M, _ = locs.shape
+    E = mod.init_embed.weight.shape[0]
+    out = torch.empty(B, M, E, device=locs.device, dtype=torch.float32)
+    if B * M == 0:
+        return out
+    feat_all = torch.nn.functional.pad(feat, (0, 0, 1, 0))                   # [B, M, F], row 0 unused
+    ops.linear(feat_all, mod.init_embed.weight, mod.init_embed.bias, out=out)
+    ops.linear(locs[:, 0, :], mod.init_embed_depot.weight, mod.init_embed_depot.bias, out=out[:, 0, :])
+    return out
+
+
 class VRPInitEmbedding(nn.Module):
     def __init__(self, embed_dim, linear_bias=True, node_dim: int = 3):
         super().__init__()
@@ -60,10 +76,8 @@ class VRPInitEmbedding(nn.Module):
 
     def forward(self, td):
         locs = td["locs"]
-        depot = ops.linear(locs[:, :1, :].contiguous(), self.init_embed_depot.weight, self.init_embed_depot.bias)
         feat = torch.cat((locs[:, 1:, :], td["demand"][..., None]), -1)   # [B, N, 3] input assembly (plumbing)
-        cust = ops.linear(feat, self.init_embed.weight, self.init_embed.bias)
-        return torch.cat((depot, cust), 1)
+        return _depot_and_customers(self, locs, feat)
 
 
 class PCTSPInitEmbedding(nn.Module):
@@ -76,10 +90,8 @@ class PCTSPInitEmbedding(nn.Module):
 
     def forward(self, td):
         locs = td["locs"]
-        depot = ops.linear(locs[:, :1, :].contiguous(), self.init_embed_depot.weight, self.init_embed_depot.bias)
         feat = torch.cat((locs[:, 1:, :], td["expected_prize"][..., None], td["penalty"][..., 1:, None]), -1)
-        cust = ops.linear(feat, self.init_embed.weight, self.init_embed.bias)
-        return torch.cat((depot, cust), 1)
+        return _depot_and_customers(self, locs, feat)
 
 
 class VRPTWInitEmbedding(nn.Module):
@@ -109,10 +121,8 @@ class OPInitEmbedding(nn.Module):
 
     def forward(self, td):
         locs = td["locs"]
-        depot = ops.linear(locs[:, :1, :].contiguous(), self.init_embed_depot.weight, self.init_embed_depot.bias)
         feat = torch.cat((locs[:, 1:, :], td["prize"][..., 1:, None]), -1)
-        cust = ops.linear(feat, self.init_embed.weight, self.init_embed.bias)
-        return torch.cat((depot, cust), 1)
+        return _depot_and_customers(self, locs, feat)
 
 
 class _Holder(nn.Module):
@@ -211,7 +221,8 @@ class GraphAttentionNetwork(nn.Module):
             layers, H, ff, norm, eps = fused
             cache = None
             if cache_spec is not None:
-                cache = (cache_spec["Wc"], cache_spec["WoT"], cache_spec["buf"], cache_spec["nproj"])
+                cache = (cache_spec["Wc"], cache_spec["WoT"], cache_spec["buf"], cache_spec["nproj"], cache_spec.get("Wg"),
+                         cache_spec.get("gctx"))
             out = ops.encoder_fused(x.contiguous(), layers, H, ff, norm, eps, cache=cache)
             if cache_spec is not None:
                 cache_spec["filled"] = True
@@ -370,7 +381,11 @@ class AttentionModelDecoder(nn.Module):
             WoT = ops.pack_linear_weight(Wout.detach().t().contiguous(), out=old[1] if keep else None)
             self._fc, self._fc_key = (Wc, WoT), key
         buf = torch.empty(B, M, len(slots) * E, device=device, dtype=torch.float32)
-        return {"buf": buf, "Wc": self._fc[0], "WoT": self._fc[1], "nproj": nproj, "filled": False}
+        spec = {"buf": buf, "Wc": self._fc[0], "WoT": self._fc[1], "nproj": nproj, "filled": False}
+        Wg = self.project_fixed_context.weight if self.use_graph_context else None
+        if Wg is not None and Wg.is_contiguous() and Wg.data_ptr() % 16 == 0 and B > 0:     # the live parameter: nothing to refresh
+            spec["Wg"], spec["gctx"] = Wg.detach(), torch.empty(B, E, device=device, dtype=torch.float32)
+        return spec
 
     def _precompute_cache(self, embeddings: torch.Tensor, num_starts: int = 0, prefilled=None) -> ops.DecodeCache:
         """K | V | L (+ folded context / logit projections) in one slot-major buffer (ops.DecodeCache).  prefilled: a
@@ -403,7 +418,10 @@ class AttentionModelDecoder(nn.Module):
                              out=flat[:, slots["Lp"] * E:(slots["Lp"] + 1) * E])
         gctx = None
         if self.use_graph_context:
-            gctx = ops.linear(ops.mean_nodes(emb), self.project_fixed_context.weight)
+            if prefilled is not None and prefilled.get("filled") and prefilled.get("gctx") is not None:
+                gctx = prefilled["gctx"]                  # written by the fused encoder kernel
+            else:
+                gctx = ops.linear(ops.mean_nodes(emb), self.project_fixed_context.weight)
         dyn = None
         if self.is_dynamic_embedding:       # key and value columns as they are; the logit-key column times project_out
             w = self.dynamic_embedding.projection.weight.detach().reshape(3, E)

@@ -197,6 +197,11 @@ typedef struct eamrl_encoder_cache {
     float* out;
     int64_t ld;
     int nproj;          /* 4 (depot envs: K V L Pa) or 5 (TSP: K V L Pa Pb) */
+    /* optional graph context  [zoo/am/decoder.py:221-226]: gctx [B][E] = embeddings.mean(1) project_fixed_context^T, the mean
+     * in node order and the projection as a k-ordered chain (= eamrl_mean_nodes + eamrl_linear).  Wg: the PLAIN row-major
+     * weight [E][E] (16-byte aligned).  Both NULL: not computed. */
+    const float* Wg;
+    float* gctx;
 } eamrl_encoder_cache;
 
 /* Wp = W [out_dim][in_dim] (torch.nn.Linear.weight) re-ordered for the fused encoder: block (ct, u) of 256 floats holds,
