@@ -75,7 +75,8 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
     __shared__ __attribute__((aligned(16))) float QT[16 * TS];
     __shared__ __attribute__((aligned(16))) float HT[16 * TS];
     __shared__ float RED[8][16], RED2[8][16], LPS[16];
-    __shared__ int REDI[8][16], SEL[16];
+    __shared__ int REDI[8][16];
+    __shared__ float REDLP[8][16], LP0[16];
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[SMAX][4];
     __shared__ int s_cur[SMAX], s_first[SMAX], s_istep[SMAX], s_cnt[SMAX], s_done[SMAX];
     __shared__ uint32_t s_flags;
@@ -140,6 +141,31 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
 
     const int nqt = (S + 15) >> 4;
     int t = 0;
+    // thread (jq, e4): four columns 4 e4 .. 4 e4 + 3 of query row jq of a tile
+    const int jq = tid >> 5, e4 = tid & 31;
+    auto q_load = [&](int qtile) -> float4 {
+        const int s = 16 * qtile + jq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < S && !s_done[s]) {
+            float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.gctx) g4 = *reinterpret_cast<const float4*>(a.gctx + b * ME + 4 * e4);
+            if (s_istep[s] == 0) {
+                const float4 c4 = *reinterpret_cast<const float4*>(a.cvec + 4 * e4);
+                v = make_float4(c4.x + g4.x, c4.y + g4.y, c4.z + g4.z, c4.w + g4.w);
+            } else {
+                const float4 p = *reinterpret_cast<const float4*>(a.Pa + (b * M + s_first[s]) * ld + 4 * e4);
+                const float4 c4 = *reinterpret_cast<const float4*>(a.Pb + (b * M + s_cur[s]) * ld + 4 * e4);
+                v = make_float4((p.x + c4.x) + g4.x, (p.y + c4.y) + g4.y, (p.z + c4.z) + g4.z, (p.w + c4.w) + g4.w);
+            }
+        }
+        return v;
+    };
+    auto q_store = [&](const float4 v) {
+        float* p = QT + jq * TS + e4;
+        p[0] = 0.25f * v.x; p[TG] = 0.25f * v.y; p[2 * TG] = 0.25f * v.z; p[3 * TG] = 0.25f * v.w;
+    };
+    const bool pre = nqt > 1;
+    bool have_q = false;                // QT already holds the tile about to be processed
 #ifdef EAMRL_STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_readcyclecounter();
 #endif
@@ -149,30 +175,16 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
         if (!__syncthreads_or(active) || t >= a.t_max) break;
         for (int qt = 0; qt < nqt; ++qt) {
             // ---- q~ tile: 0.25 * ((Pa[first] + Pb[cur]) + gctx), or 0.25 * (c0 + gctx) before the first node is chosen ----------
-            {
-                const int jq = tid >> 5, e4 = tid & 31, s = 16 * qt + jq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (s < S && !s_done[s]) {
-                    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a.gctx) g4 = *reinterpret_cast<const float4*>(a.gctx + b * ME + 4 * e4);
-                    if (s_istep[s] == 0) {
-                        const float4 c4 = *reinterpret_cast<const float4*>(a.cvec + 4 * e4);
-                        v = make_float4(c4.x + g4.x, c4.y + g4.y, c4.z + g4.z, c4.w + g4.w);
-                    } else {
-                        const float4 p = *reinterpret_cast<const float4*>(a.Pa + (b * M + s_first[s]) * ld + 4 * e4);
-                        const float4 c4 = *reinterpret_cast<const float4*>(a.Pb + (b * M + s_cur[s]) * ld + 4 * e4);
-                        v = make_float4((p.x + c4.x) + g4.x, (p.y + c4.y) + g4.y, (p.z + c4.z) + g4.z, (p.w + c4.w) + g4.w);
-                    }
-                }
-                float* p = QT + jq * TS + e4;
-                p[0] = 0.25f * v.x; p[TG] = 0.25f * v.y; p[2 * TG] = 0.25f * v.z; p[3 * TG] = 0.25f * v.w;
-            }
+            // With more than one tile per step the NEXT tile's rows are fetched behind this tile's logit phase and stored
+            // before its last barrier (q_next below): a tile's starts are touched by no other tile, so their state is final
+            // since their own transition one round earlier, and QT is free once every wave has left the glimpse phase.
+            if (!have_q) q_store(q_load(qt));
             const int sq = 16 * qt + j;                           // this lane's start (query j of the tile)
             const bool live = sq < S && !s_done[sq];
             uint4 mb = make_uint4(0, 0, 0, 0);
             if (live) mb = *reinterpret_cast<const uint4*>(&s_bits[sq][0]);
             MSTAMP(0);
-            __syncthreads();
+            if (!have_q) __syncthreads();
             MSTAMP(1);
             // ---- glimpse of head wv ------------------------------------------------------------------------------------------
             {
@@ -249,6 +261,8 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
             MSTAMP(4);
             __syncthreads();
             MSTAMP(5);
+            float4 q_next = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pre) q_next = q_load(qt + 1 == nqt ? 0 : qt + 1);
             // ---- logits of key tile wv, finish ----------------------------------------------------------------------------
             float x[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             bool fe[4] = {false, false, false, false};
@@ -361,32 +375,46 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
                 }
                 cand = group_min(cand);
                 if (G == 0) REDI[wv][j] = cand;
+                if (cand >= nbase && cand < nbase + 4) REDLP[wv][j] = lp[cand - nbase];     // the log-prob of this tile's candidate
+                if (wv == 0 && G == 0) LP0[j] = lp[0];
             }
+            if (pre) q_store(q_next);           // QT is free since the glimpse barrier; the barrier below publishes it
+            have_q = pre;
+            MSTAMP(12);
             __syncthreads();
+            MSTAMP(13);
             int sel = 1 << 20;
 #pragma unroll
             for (int w = 0; w < RTT; ++w) sel = min(sel, REDI[w][j]);
+            const int picked = sel;             // the wave whose candidate this is holds its log-prob in REDLP
             if (a.mode == EAMRL_EVALUATE && live)
                 sel = (t < a.t_given) ? (int)a.given[((int64_t)sq * a.B + b) * a.t_given + t] : 0;
             uint32_t fl = 0;
             if (live) {
                 if (nan_seen) fl |= EAMRL_ST_NAN_LOGITS;
                 if (sel < 0 || sel >= M) { fl |= EAMRL_ST_INFEASIBLE; sel = 0; }
-                if (wv < RTT && sel >= nbase && sel < nbase + 4) LPS[j] = lp[sel - nbase];
             }
-            if (wv == 0 && G == 0) SEL[j] = sel;
             if (fl) atomicOr(&s_flags, fl);
-            MSTAMP(12);
-            __syncthreads();
-            MSTAMP(13);
-            // ---- env transition (TSPEnv._step, tsp/env.py:62-88) of the tile's 16 starts -------------------------------------
+            if (a.mode == EAMRL_EVALUATE) {     // the given node's log-prob lives in whichever wave owns that key tile
+                if (live && wv < RTT && sel >= nbase && sel < nbase + 4) LPS[j] = lp[sel - nbase];
+                __syncthreads();
+            }
+            // ---- env transition (TSPEnv._step, tsp/env.py:62-88) of the tile's 16 starts: lanes (j, G = 0) of wave 0 -------------
             if (tid < 16) {
                 const int s = 16 * qt + tid;
                 if (s < S && !s_done[s]) {
-                    const int sl = SEL[tid];
+                    const int sl = sel;
+                    float lpv;
+                    if (a.mode == EAMRL_EVALUATE) lpv = LPS[tid];
+                    else {
+                        lpv = LP0[tid];         // (sel was replaced by node 0 after an infeasible pick)
+#pragma unroll
+                        for (int w = 0; w < RTT; ++w)
+                            if (sl == picked && REDI[w][tid] == picked) lpv = REDLP[w][tid];
+                    }
                     const int64_t r = (int64_t)s * a.B + b;
                     a.action[r * a.t_max + t] = sl;
-                    a.logp[r * a.t_max + t] = LPS[tid];
+                    a.logp[r * a.t_max + t] = lpv;
                     const uint32_t bit = 1u << (sl & 31);
                     const uint32_t wd = s_bits[s][sl >> 5];
                     if (!(wd & bit)) atomicOr(&s_flags, EAMRL_ST_INFEASIBLE);
@@ -398,7 +426,8 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
                     s_done[s] = s_cnt[s] == 0;
                 }
             }
-            // (the next tile's first barrier orders this against its readers; the tile buffers are rewritten only after it)
+            // (ordered against its readers by the barriers of the next tile: REDI / REDLP are rewritten only after three of them,
+            //  and the state of these 16 starts is next read one round later, or behind the tile-start barrier when nqt == 1)
             MSTAMP(14);
         }
         ++t;
