@@ -333,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
     __shared__ __attribute__((aligned(16))) float QT[16 * TS];
     __shared__ __attribute__((aligned(16))) float HT[16 * TS];
     __shared__ float DU[16 * RTT * DS];
+    __shared__ float LSE[16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, G = lane >> 4;
@@ -341,6 +342,9 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
     const int s0 = (int)((int64_t)a.S * ch / a.nchunk), s1 = (int)((int64_t)a.S * (ch + 1) / a.nchunk);
     const int64_t nq = (int64_t)(s1 - s0) * a.T;
     const int64_t ntiles = (nq + 15) / 16;
+    // lse == NULL: no forward pass was run -- logp holds the ROLLOUT's log-prob of the chosen node (the same quantity in the
+    // rollout kernels' arithmetic), and the normaliser is recovered as z[action] - logp, one extra LDS hand-off per tile
+    const bool derive_lse = a.lse == nullptr;
 
     float kf[RTT][4], vtf[4 * RTT], lpf[32], lptf[4 * RTT];
     load_head_frags<RTT>(a, b, wv, lane, kf, vtf);
@@ -364,13 +368,26 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
         if (q.qi >= 0) {
             mb = *reinterpret_cast<const uint4*>(a.maskbits + q.qi * 4);
             act = (int)a.actions[q.qi];
-            if (q.active) { g = a.glogp[q.qi]; lse = a.lse[q.qi]; }
+            if (q.active) { g = a.glogp[q.qi]; lse = derive_lse ? a.logp[q.qi] : a.lse[q.qi]; }
         }
         __syncthreads();
         glimpse_tile<RTT>(kf, vtf, QT, HT, wv, lane, mb, a.M);
         __syncthreads();
+        f32x4 u = z4();
+        if (wv < RTT) u = logit_tile(lpf, HT, lane);
+        if (derive_lse) {           // the lane that owns the chosen node publishes z[action] - logp for its query
+            if (wv < RTT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float dzdu;
+                    const float z = process_logit(u[r], a.clip, inv_temp, dzdu);
+                    if (16 * wv + 4 * r + G == act && g != 0.0f) LSE[j] = z - lse;
+                }
+            }
+            __syncthreads();
+            if (g != 0.0f) lse = LSE[j];
+        }
         if (wv < RTT) {
-            const f32x4 u = logit_tile(lpf, HT, lane);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n0 = 16 * wv + 4 * r;

@@ -296,7 +296,7 @@ class ReevalPlan:
     buf [B, M, P*E]: the instance operands side by side -- K | V | Lp | Pa (| Pb); gctx [B, E] or None; cvec [NC, E] or
     None; idxA / idxB int32 [R, T]; sc [NC, R, T]; maskbits int32 [R, T, 4]; actions int64 [R, T]."""
 
-    def __init__(self, buf, has_pb, gctx, cvec, idxA, idxB, sc, maskbits, actions, S, tstart, clip, temp):
+    def __init__(self, buf, has_pb, gctx, cvec, idxA, idxB, sc, maskbits, actions, S, tstart, clip, temp, rollout_logp=None):
         _chk(buf, "operands", torch.float32)
         self.B, self.M, width = buf.shape
         self.E = width // (5 if has_pb else 4)
@@ -318,8 +318,14 @@ class ReevalPlan:
         self.idxA, self.idxB, self.sc, self.maskbits, self.actions = idxA, idxB, sc, maskbits, actions
         self.R, self.T, self.S, self.tstart, self.clip, self.temp = R, T, int(S), int(tstart), float(clip), float(temp)
         self.nchunk = max(1, min(self.S, -(-512 // self.B)))
-        self.logp = torch.empty(R, T, dtype=torch.float32, device=buf.device)
-        self.lse = torch.empty(R, T, dtype=torch.float32, device=buf.device)
+        # rollout_logp [R, T]: the per-step log-probs the rollout kernel produced for exactly these actions.  Then no
+        # forward pass is needed for the gradient: forward() hands them back and the backward recovers the normaliser.
+        if rollout_logp is not None:
+            _chk(rollout_logp, "rollout log-probs", torch.float32, (R, T))
+            self.logp, self.lse = rollout_logp, None
+        else:
+            self.logp = torch.empty(R, T, dtype=torch.float32, device=buf.device)
+            self.lse = torch.empty(R, T, dtype=torch.float32, device=buf.device)
 
     def _struct(self):
         s = _lib.Reeval()
@@ -337,6 +343,8 @@ class ReevalPlan:
         return s
 
     def forward(self):
+        if self.lse is None:
+            return self.logp
         lib = _lib.load()
         s = self._struct()
         _lib.check(lib.eamrl_reeval_forward(C.byref(s), _stream(self.buf)), "eamrl_reeval_forward")

@@ -681,9 +681,13 @@ class AttentionModelPolicy(nn.Module):
                                       "only outside training (reinforce.py:64)")
         if p["top_k"] or p["top_p"]:
             raise NotImplementedError("top-k / top-p filtering is not part of the differentiable re-evaluation")
+        # the rollout's own per-step log-probs let the re-evaluation skip its forward pass (train.evaluate_log_likelihood)
+        fl = p.get("final_logp")
+        if fl is not None and (fl.shape != p["final_actions"].shape or os.environ.get("EAMRL_REEVAL_FORWARD", "0") == "1"):
+            fl = None
         re = evaluate_log_likelihood(self, p["td"], p["env"], p["final_actions"], num_starts=p["S"],
                                      multistart=bool(p["pre"]), temperature=p["temperature"],
-                                     tanh_clipping=p["tanh_clipping"])
+                                     tanh_clipping=p["tanh_clipping"], rollout_logp=fl)
         td_mask = p["td"].get("mask", None) if hasattr(p["td"], "get") else None
         if td_mask is not None:
             re = re.masked_fill(~td_mask, 0)
@@ -924,6 +928,7 @@ class AttentionModelPolicy(nn.Module):
             out["init_embeds"] = p["init_embeds"]
         self._last_td = td_out   # final env state of the last rollout (the reference keeps it in a local)
         p["final_actions"] = actions_out
+        p["final_logp"] = logprobs if not (S > 0 and p["select_best"]) else None
         return out
 
     def _beam_search(self, td, env, kw, calc_reward, return_actions, return_sum_log_likelihood, return_hidden,

@@ -421,7 +421,8 @@ class _NativeReeval(torch.autograd.Function):
         buf = torch.cat([x.detach() for x in parts], -1).contiguous()
         plan = ops.ReevalPlan(buf, Pb is not None, None if gctx is None else gctx.detach().contiguous(),
                               None if cvec is None else cvec.detach().contiguous(), meta["idxA"], meta["idxB"], meta["sc"],
-                              meta["maskbits"], meta["actions"], meta["S"], meta["tstart"], meta["clip"], meta["temp"])
+                              meta["maskbits"], meta["actions"], meta["S"], meta["tstart"], meta["clip"], meta["temp"],
+                              rollout_logp=meta.get("rollout_logp"))
         ctx.plan = plan
         ctx.has = (Pb is not None, gctx is not None, cvec is not None)
         return plan.forward()
@@ -436,7 +437,7 @@ class _NativeReeval(torch.autograd.Function):
                 dc if ctx.has[2] else None, None)
 
 
-def _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip):
+def _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip, rollout_logp=None):
     """Differentiable log-probs [R, T]: the weight folds (Lp = L Wout, Pa / Pb = emb x halves of project_context, state
     columns) as small autograd GEMMs on the decoder tensors `t`, everything per (row, step) in the HIP kernels."""
     E = t["emb"].shape[-1]
@@ -450,17 +451,21 @@ def _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip):
     else:
         cvec = Wctx[:, E:].t()                                                                      # [NC, E] state columns
     meta.update(actions=actions.contiguous(), S=S, clip=float(clip), temp=float(temperature))
+    if rollout_logp is not None:
+        meta["rollout_logp"] = rollout_logp.detach().to(torch.float32).contiguous()
     return _NativeReeval.apply(t["K"], t["V"], Lp, Pa, Pb, t.get("gctx"), cvec, meta)
 
 
 def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, temperature=None, tanh_clipping=None,
-                            chunk_rows: int = 4096, multistart=None, checkpoint=None, native=None):
+                            chunk_rows: int = 4096, multistart=None, checkpoint=None, native=None, rollout_logp=None):
     """Differentiable per-step log-probabilities of `actions` [R, T] (R = B or S*B rows in (s b) order).  native
     (default: where supported -- TSP / CVRP / PCTSP / OP / CVRPTW, graphs up to 112 nodes): forward and backward of the
     decode steps run in the HIP re-evaluation kernels; otherwise (and as the cross-check) PyTorch autograd ops.  multistart
     (default: num_starts > 1): the first column is the start node and gets log-prob 0; False with num_starts > 1 is
     the multi-sample layout (every column a decision).  checkpoint (default: by size): keep no activations in the
-    forward and recompute chunk by chunk in the backward.  Returns logp [R, T]."""
+    forward and recompute chunk by chunk in the backward.  rollout_logp [R, T] (native path only): the per-step log-probs
+    the rollout kernel produced for exactly these actions with this policy -- the HIP forward pass is then skipped (the
+    returned values are these; the backward recovers each step's normaliser from them).  Returns logp [R, T]."""
     temperature = policy.temperature if temperature is None else temperature
     clip = policy.tanh_clipping if tanh_clipping is None else tanh_clipping
     H = policy.decoder.num_heads
@@ -475,7 +480,7 @@ def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, tempe
     if native is None:
         native = native_reeval_supported(policy, M)
     if native:
-        return _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip)
+        return _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip, rollout_logp)
     static = {k: td[k] for k in _STATE_KEYS[env_name]}
     # rows are processed in chunks of whole start-groups so that memory stays bounded ([rows, H, T, M] scores)
     starts_per_chunk = max(1, chunk_rows // B)

@@ -253,7 +253,9 @@ typedef struct eamrl_reeval {
     const int32_t* idxA; const int32_t* idxB; const float* sc;
     const uint32_t* maskbits; const int64_t* actions;       /* actions [R][T] */
     int64_t B, R; int S, T, M, tstart, nchunk; float clip, temp;      /* nchunk: workgroups per instance (rows split) */
-    float* logp; float* lse;                                /* [R][T]: forward writes both; backward reads lse */
+    float* logp; float* lse;                                /* [R][T]: forward writes both; backward reads lse -- or, with
+                                                             * lse == NULL (no forward pass run), logp = the ROLLOUT's per-step
+                                                             * log-probs of `actions`, from which the normaliser is recovered */
     const float* glogp; float* dheads;                      /* backward: dL/dlogp [R][T]; scratch [R][T][E] */
     float *dK, *dV, *dLp, *dPa, *dPb; int64_t ldg;          /* gradients [B][M][.] (row stride ldg), ACCUMULATED into (+=) */
     float *dgctx, *dCvec;                                   /* [B][E] or NULL, [NC][E]; accumulated */
@@ -261,7 +263,7 @@ typedef struct eamrl_reeval {
 
 int eamrl_reeval_supported(int M, int E, int H);                  /* 1 for M <= 112, E = 128, H = 8 */
 int eamrl_reeval_forward(const eamrl_reeval* p, void* stream);    /* -> logp, lse */
-int eamrl_reeval_backward(const eamrl_reeval* p, void* stream);   /* glogp, lse -> dK dV dLp dPa dPb dgctx dCvec */
+int eamrl_reeval_backward(const eamrl_reeval* p, void* stream);   /* glogp, lse (or rollout logp) -> dK dV dLp dPa dPb dgctx dCvec */
 
 /* bits[(r * T + t) * 4 + n / 32] bit (n % 32) = mask[r][n] for step t (call after every replayed env transition). */
 int eamrl_pack_mask_bits(const uint8_t* mask, uint32_t* bits, int64_t R, int M, int T, int t, void* stream);

@@ -215,11 +215,14 @@ def test_native_reevaluation_matches_autograd(cfg, env_name, N, B, ns, ms):
     assert native_reeval_supported(pol, td["locs"].shape[1])
     w = torch.randn(acts.shape, device=DEV)
     res = []
-    for native in (True, False):
+    for native in (True, False, "from_rollout"):
         pol.zero_grad()
-        lp = evaluate_log_likelihood(pol, td, env, acts, num_starts=ns, multistart=ms, native=native)
+        # "from_rollout": the forward kernel is skipped, the backward recovers the normalisers from the rollout's log-probs
+        lp = evaluate_log_likelihood(pol, td, env, acts, num_starts=ns, multistart=ms, native=bool(native),
+                                     rollout_logp=out["log_likelihood"] if native == "from_rollout" else None)
         (lp * w).sum().backward()
         res.append((lp.detach(), {k: p.grad.clone() for k, p in pol.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[2][0], out["log_likelihood"])
     tol = 2e-4 if env_name == "cvrptw" else 1e-5          # cvrptw: unscaled inputs (see the oracle tests)
     np.testing.assert_allclose(res[0][0].cpu().numpy(), out["log_likelihood"].cpu().numpy(), rtol=0, atol=tol)
     np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), rtol=0, atol=tol)
@@ -229,9 +232,10 @@ def test_native_reevaluation_matches_autograd(cfg, env_name, N, B, ns, ms):
     gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in res[1][1].values())))
     top = max(float(g.abs().max()) for g in res[1][1].values())
     loose = 300.0 if env_name == "cvrptw" else 1.0    # cvrptw: unscaled inputs, an ill-conditioned network (see the oracle tests)
-    for k in res[1][1]:
-        ref, got = res[1][1][k].double(), res[0][1][k].double()
-        rel = float((got - ref).norm()) / max(float(ref.norm()), 1e-2 * gnorm)
-        assert rel <= 1e-4 * loose, (k, rel)
-        scale = max(float(ref.abs().max()), 1e-2 * top)
-        assert float((got - ref).abs().max()) <= 5e-4 * loose * scale, k
+    for which in (0, 2):
+        for k in res[1][1]:
+            ref, got = res[1][1][k].double(), res[which][1][k].double()
+            rel = float((got - ref).norm()) / max(float(ref.norm()), 1e-2 * gnorm)
+            assert rel <= 1e-4 * loose, (which, k, rel)
+            scale = max(float(ref.abs().max()), 1e-2 * top)
+            assert float((got - ref).abs().max()) <= 5e-4 * loose * scale, (which, k)
