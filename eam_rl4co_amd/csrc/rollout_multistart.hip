@@ -70,7 +70,7 @@ __device__ __forceinline__ int group_min(int v)
 // decision folds away; left to run time the ~100 uniform conditions are hoisted out of the loops into SGPRs that spill
 // (measured: 256 VGPRs + scratch vs 167 VGPRs), so the common sizes get their own instantiation.
 template <int RTT, int CC>
-__global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
+__global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, int nsplit)
 {
     __shared__ __attribute__((aligned(16))) float QT[16 * TS];
     __shared__ __attribute__((aligned(16))) float HT[16 * TS];
@@ -87,7 +87,10 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, G = lane >> 4, pi = 4 * (j & 3) + (j >> 2);
     const int M = a.M;
-    const int64_t b = blockIdx.x;
+    // nsplit workgroups share an instance (small batches: fills the CUs a 64-instance batch would leave idle): workgroup
+    // `part` owns the query tiles [qt0, qt1) -- tiles never interact, each start's state is private to its tile
+    const int64_t b = blockIdx.x / nsplit;
+    const int part = (int)(blockIdx.x - b * nsplit);
     const int64_t ld = a.ld;
     const int C = CC > 0 ? CC : (M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
     const float sqrtE = __builtin_sqrtf((float)ME);
@@ -123,7 +126,10 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
         for (int t = 0; t < 32; ++t) lpf[64 * t] = n < M ? a.Lp[(b * M + n) * ld + 4 * t + G] : 0.0f;
     }
     // ---- per-start state ----------------------------------------------------------------------------------------------------
-    for (int s = tid; s < S; s += blockDim.x) {
+    const int nqt_all = (S + 15) >> 4;
+    const int qt0 = nqt_all * part / nsplit, qt1 = nqt_all * (part + 1) / nsplit;
+    const int s_lo = 16 * qt0, s_hi = min(S, 16 * qt1);
+    for (int s = s_lo + tid; s < s_hi; s += blockDim.x) {
         const int64_t r = (int64_t)s * a.B + b;
         uint32_t w[4] = {0, 0, 0, 0};
         int cnt = 0;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
     if (tid == 0) s_flags = 0;
     __syncthreads();
 
-    const int nqt = (S + 15) >> 4;
+    const int nqt = qt1 - qt0;
     int t = 0;
     // thread (jq, e4): four columns 4 e4 .. 4 e4 + 3 of query row jq of a tile
     const int jq = tid >> 5, e4 = tid & 31;
@@ -171,9 +177,9 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
 #endif
     for (;;) {
         int active = 0;
-        for (int s = tid; s < S; s += blockDim.x) active |= !s_done[s];
+        for (int s = s_lo + tid; s < s_hi; s += blockDim.x) active |= !s_done[s];
         if (!__syncthreads_or(active) || t >= a.t_max) break;
-        for (int qt = 0; qt < nqt; ++qt) {
+        for (int qt = qt0; qt < qt1; ++qt) {
             // ---- q~ tile: 0.25 * ((Pa[first] + Pb[cur]) + gctx), or 0.25 * (c0 + gctx) before the first node is chosen ----------
             // With more than one tile per step the NEXT tile's rows are fetched behind this tile's logit phase and stored
             // before its last barrier (q_next below): a tile's starts are touched by no other tile, so their state is final
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
             __syncthreads();
             MSTAMP(5);
             float4 q_next = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pre) q_next = q_load(qt + 1 == nqt ? 0 : qt + 1);
+            if (pre) q_next = q_load(qt + 1 == qt1 ? qt0 : qt + 1);
             // ---- logits of key tile wv, finish ----------------------------------------------------------------------------
             float x[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             bool fe[4] = {false, false, false, false};
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S)
 #endif
     // ---- final state -------------------------------------------------------------------------------------------------------------
     __syncthreads();
-    for (int s = tid; s < S; s += blockDim.x) {
+    for (int s = s_lo + tid; s < s_hi; s += blockDim.x) {
         const int64_t r = (int64_t)s * a.B + b;
         for (int n = 0; n < M; ++n) a.mask[r * M + n] = (s_bits[s][n >> 5] >> (n & 31)) & 1u;
         a.cur[r] = s_cur[s];
@@ -464,7 +470,12 @@ int launch_t(const DecArgs& a, int S, hipStream_t st)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 32 * 1024)) !=
         hipSuccess)
         return EAMRL_E_LAUNCH;
-    hipLaunchKernelGGL(k, dim3((unsigned)a.B), dim3(512), lds, st, a, S);
+    // one workgroup per CU is resident (register budget): a batch smaller than the chip splits each instance's query tiles
+    const int nqt = (S + 15) / 16;
+    int nsplit = a.B > 0 ? (int)(256 / a.B) : 1;
+    nsplit = nsplit < 1 ? 1 : (nsplit > nqt ? nqt : nsplit);
+    if (g_debug[13]) nsplit = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)(a.B * nsplit)), dim3(512), lds, st, a, S, nsplit);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 

@@ -64,7 +64,8 @@ const char* eamrl_last_error(void);
  * key 7: 1 = eamrl_mha_encoder uses the matrix-core kernel (N <= 128; bit-identical, measured slower) instead of the VALU kernels.
  * key 10: 1 = eamrl_linear configures its epilogue at run time even where a compile-time variant applies.
  * key 6: 1 = eamrl_am_rollout does not use the start-sharing kernel for multistart batches (R = S*B rows).
- * key 11: 1 = eamrl_am_rollout does not use the MFMA start-sharing kernel (TSP multistart) but the VALU ones. */
+ * key 11: 1 = eamrl_am_rollout does not use the MFMA start-sharing kernel (TSP multistart) but the VALU ones.
+ * key 13: 1 = the MFMA start-sharing kernel never splits an instance's starts over several workgroups (small batches). */
 int eamrl_debug_set(int key, int value);
 
 /* ---- environment state machines ---------------------------------------------------------------- */

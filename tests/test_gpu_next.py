@@ -162,16 +162,19 @@ def test_start_sharing_kernel_matches_oracle_and_single_row_kernel(oracle, env_n
         noise = torch.empty(B * S, 3 * M + 1, M).exponential_(1, generator=torch.Generator().manual_seed(N + S))
         kw["noise"] = noise.to(DEV)
     outs = []
-    # default (TSP: the MFMA start-sharing kernel) | VALU start-sharing kernel | one row per workgroup
-    for single, no_mfma in ((0, 0), (0, 1), (1, 1)):
+    # default (TSP: the MFMA start-sharing kernel, an instance's query tiles split over workgroups at these batch sizes) |
+    # the same, one workgroup per instance | VALU start-sharing kernel | one row per workgroup
+    for single, no_mfma, no_split in ((0, 0, 0), (0, 0, 1), (0, 1, 0), (1, 1, 0)):
         _lib.load().eamrl_debug_set(6, single)
         _lib.load().eamrl_debug_set(11, no_mfma)
+        _lib.load().eamrl_debug_set(13, no_split)
         try:
             outs.append(pol(td_cpu.to(DEV), env, phase="test", decode_type="multistart_" + mode,
                             return_sum_log_likelihood=False, **kw))
         finally:
             _lib.load().eamrl_debug_set(6, 0)
             _lib.load().eamrl_debug_set(11, 0)
+            _lib.load().eamrl_debug_set(13, 0)
     o = oracle.policy_rollout(golden_weights(cfg), env_name, locs, demand, decode_type="multistart_" + mode,
                               num_starts=S, noise=None if noise is None else noise.numpy())
     for out in outs:

@@ -154,6 +154,9 @@ def main():
         bench_mha(a.iters)
     if a.what in ("ea", "all"):
         bench_ea(a.iters)
+    for kv in filter(None, os.environ.get("EAMRL_DEBUG_KEYS", "").split(",")):   # kernel A/B experiments only
+        from eam_rl4co_amd import _lib
+        _lib.load().eamrl_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
     if a.what in ("train",):
         bench_train(a.iters)
     if a.what in ("decode",):
