@@ -29,8 +29,9 @@ struct DecArgs {
 
 // LDS carve for one row handled by one workgroup.
 struct RowLds {
-    float* q;       // [E]
-    float* heads;   // [E]
+    static constexpr int PAD = 4;   // floats between the per-head / per-chunk segments of q / heads (bank spreading)
+    float* q;       // [H][D + PAD]
+    float* heads;   // [NCHUNK][E / NCHUNK + PAD]
     float* w;       // [H][M] scores -> softmax weights
     float* x;       // [M]    processed logits -> log-probs
     float* partA;   // [NCHUNK][E]
@@ -43,7 +44,7 @@ struct RowLds {
 
 inline size_t row_lds_bytes(int M, int E, int H)
 {
-    size_t f = 2 * (size_t)E + (size_t)H * M + M + (size_t)EAMRL_NCHUNK * E + (size_t)EAMRL_NCHUNK * H +
+    size_t f = 2 * (size_t)E + (size_t)RowLds::PAD * (H + EAMRL_NCHUNK) + (size_t)H * M + M + (size_t)EAMRL_NCHUNK * E + (size_t)EAMRL_NCHUNK * H +
                (size_t)M * EAMRL_NCHUNK + 64 + 64;
     return f * 4 + (((size_t)M + 15) & ~(size_t)15);
 }
@@ -52,8 +53,8 @@ __device__ __forceinline__ RowLds carve_row_lds(char* base, int M, int E, int H)
 {
     RowLds l;
     float* f = reinterpret_cast<float*>(base);
-    l.q = f; f += E;
-    l.heads = f; f += E;
+    l.q = f; f += E + RowLds::PAD * H;
+    l.heads = f; f += E + RowLds::PAD * EAMRL_NCHUNK;
     l.w = f; f += (size_t)H * M;
     l.x = f; f += M;
     l.partA = f; f += EAMRL_NCHUNK * E;

@@ -78,6 +78,9 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
     float* sd_hl = sd_pr + a.H;                                // [NCHUNK]     heads_c . lw_c
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int M = a.M, E = a.E, H = a.H, D = E / H;
+    // LDS strides of q (per head) and heads (per column chunk): + 4 floats, so that the 8 heads / 4 chunks a wavefront reads
+    // side by side start in different banks (with the dense layout they are 64 / 128 B apart: 4-way conflicts on every read)
+    const int QS = D + RowLds::PAD, HS = E / EAMRL_NCHUNK + RowLds::PAD;
     const int64_t bi = r % a.B;
     const int64_t ld = a.ld;
     const float* K = a.K + bi * M * ld;
@@ -99,7 +102,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             ctx = fma_(a.cvec[e], state, a.Pa[(bi * M + s.cur) * ld + e]);
             if (ENV == EAMRL_ENV_CVRPTW) ctx = fma_(a.cvec[E + e], s.now, ctx);      // VRPTWContext: + current time column
         }
-        l.q[e] = ctx + g;
+        l.q[(e / D) * QS + (e % D)] = ctx + g;
     }
     __syncthreads();
 
@@ -108,7 +111,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
     if (SD) {       // q_h . wk_h, one thread per head
         if (tid < H) {
             float qw = 0.0f;
-            for (int d = 0; d < D; ++d) qw = fma_(l.q[tid * D + d], dyn[tid * D + d], qw);
+            for (int d = 0; d < D; ++d) qw = fma_(l.q[tid * QS + d], dyn[tid * D + d], qw);
             sd_qw[tid] = qw;
         }
         __syncthreads();
@@ -137,7 +140,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             const int p = p0 + u * BLOCK;
             if (p >= M * H) break;
             const int n = p / H, h = p - n * H;
-            const float* qp = l.q + h * D;
+            const float* qp = l.q + h * QS;
             float acc = 0.0f;
 #pragma unroll
             for (int d4 = 0; d4 < 4; ++d4) {
@@ -157,7 +160,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         float sc = -INFINITY;
         if (l.msk[n]) {
             const float* kp = K + (int64_t)n * ld + h * D;
-            const float* qp = l.q + h * D;
+            const float* qp = l.q + h * QS;
             float acc = 0.0f;
             for (int d = 0; d < D; d += 4) {
                 float4 kk = *reinterpret_cast<const float4*>(kp + d);
@@ -240,14 +243,14 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
 #pragma unroll
         for (int g = 1; g < EAMRL_NCHUNK; ++g) { A = A + l.partA[g * E + e]; Z = Z + l.partZ[g * H + h]; }
         if (SD) A = fma_(sd_pr[h], dyn[E + e], A);
-        l.heads[e] = A / Z;
+        l.heads[(e / (E / EAMRL_NCHUNK)) * HS + (e % (E / EAMRL_NCHUNK))] = A / Z;
     }
     __syncthreads();
     const int EC0 = E / EAMRL_NCHUNK;
     if (SD) {       // heads_c . lw_c, one thread per column chunk
         if (tid < EAMRL_NCHUNK) {
             float hl = 0.0f;
-            for (int e = tid * EC0; e < (tid + 1) * EC0; ++e) hl = fma_(l.heads[e], dyn[2 * E + e], hl);
+            for (int e = tid * EC0; e < (tid + 1) * EC0; ++e) hl = fma_(l.heads[tid * HS + (e - tid * EC0)], dyn[2 * E + e], hl);
             sd_hl[tid] = hl;
         }
         __syncthreads();
@@ -279,7 +282,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
                 const int p = p0 + u * BLOCK;
                 if (p >= M * EAMRL_NCHUNK) break;
                 const int c = p % EAMRL_NCHUNK;
-                const float* hp = l.heads + c * EC;
+                const float* hp = l.heads + c * HS;
                 float cg = 0.0f;
 #pragma unroll
                 for (int e4 = 0; e4 < 8; ++e4) {
@@ -298,7 +301,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             float cg = 0.0f;
             if (l.msk[n]) {
                 const float* lp = Lp + (int64_t)n * ld + c * EC;
-                const float* hp = l.heads + c * EC;
+                const float* hp = l.heads + c * HS;
                 for (int e = 0; e < EC; e += 4) {
                     float4 v = *reinterpret_cast<const float4*>(lp + e);
                     cg = fma_(hp[e], v.x, cg);
