@@ -42,7 +42,7 @@ class Reeval(C.Structure):
                 ("idxA", _vp), ("idxB", _vp), ("sc", _vp), ("maskbits", _vp), ("actions", _vp),
                 ("B", _i64), ("R", _i64), ("S", C.c_int32), ("T", C.c_int32), ("M", C.c_int32), ("tstart", C.c_int32),
                 ("nchunk", C.c_int32), ("clip", _f32), ("temp", _f32),
-                ("logp", _vp), ("lse", _vp), ("glogp", _vp), ("dheads", _vp),
+                ("logp", _vp), ("lse", _vp), ("glogp", _vp), ("dheads", _vp), ("entropy", _vp),
                 ("dK", _vp), ("dV", _vp), ("dLp", _vp), ("dPa", _vp), ("dPb", _vp), ("ldg", _i64),
                 ("dgctx", _vp), ("dCvec", _vp)]
 

@@ -295,7 +295,7 @@ static int check_reeval(const eamrl_reeval* p, const char* what, bool bwd)
 {
     REQUIRE(p, what);
     REQUIRE(reeval_supports(p->M, 128, 8), what);
-    REQUIRE(p->K && p->V && p->Lp && p->Pa && p->idxA && p->maskbits && p->actions && p->logp && (p->lse || bwd), what);
+    REQUIRE(p->K && p->V && p->Lp && p->Pa && p->idxA && p->maskbits && p->actions && p->logp, what);
     REQUIRE((p->idxB == nullptr) == (p->Pb == nullptr) || p->Pb, what);
     REQUIRE(p->B > 0 && p->S > 0 && p->T > 0 && p->R == p->B * p->S && p->nchunk >= 1 && p->nchunk <= p->S, what);
     REQUIRE(p->ld >= 128 && p->ld % 4 == 0 && p->NC >= 0 && p->NC <= 4 && (p->NC == 0 || (p->Cvec && p->sc)), what);

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
 {
     __shared__ __attribute__((aligned(16))) float QT[16 * TS];
     __shared__ __attribute__((aligned(16))) float HT[16 * TS];
-    __shared__ float RED[8][16], RED2[8][16], ZA[16];
+    __shared__ float RED[8][16], RED2[8][16], RED3[8][16], ZA[16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, G = lane >> 4;
@@ -281,22 +281,34 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
         for (int w = 0; w < RTT; ++w) M_ = fmaxf(M_, RED[w][j]);
         if (M_ == -INFINITY) M_ = 0.0f;
         if (wv < RTT) {
-            float sm = 0.0f;
+            float sm = 0.0f, sz = 0.0f;          // sum of e^(z - M) and of e^(z - M) z (for the entropy)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sm += fexp(z[r] - M_);
+            for (int r = 0; r < 4; ++r) {
+                const float e = fexp(z[r] - M_);
+                sm += e;
+                if (z[r] != -INFINITY) sz = fmaf(e, z[r], sz);
+            }
             sm = group_sum(sm);
             if (G == 0) RED2[wv][j] = sm;
+            if (a.entropy) {
+                sz = group_sum(sz);
+                if (G == 0) RED3[wv][j] = sz;
+            }
         }
         __syncthreads();
         if (tid < 16) {
             const Q qq = tile_query(a, b, s0, nq, tile, tid);
             if (qq.qi >= 0) {
-                float sm = 0.0f, mm = -INFINITY;
+                float sm = 0.0f, sz = 0.0f, mm = -INFINITY;
                 for (int w = 0; w < RTT; ++w) { sm += RED2[w][tid]; mm = fmaxf(mm, RED[w][tid]); }
                 if (mm == -INFINITY) mm = 0.0f;
                 const float lse = mm + __builtin_amdgcn_logf(sm) * 0.6931471805599453f;
-                a.lse[qq.qi] = lse;
+                if (a.lse) a.lse[qq.qi] = lse;
                 a.logp[qq.qi] = qq.active ? ZA[tid] - lse : 0.0f;
+                if (a.entropy) {       // -sum_n p_n log p_n = lse - sum_n p_n z_n over the feasible nodes; 0 for a forced step
+                    for (int w = 0; w < RTT; ++w) sz += RED3[w][tid];
+                    a.entropy[qq.qi] = (qq.active && sm > 0.0f) ? lse - sz / sm : 0.0f;
+                }
             }
         }
         // (the next tile's first barrier orders these reads before QT / RED / ZA are rewritten: ZA and RED are only

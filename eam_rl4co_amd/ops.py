@@ -296,11 +296,17 @@ class ReevalPlan:
     buf [B, M, P*E]: the instance operands side by side -- K | V | Lp | Pa (| Pb); gctx [B, E] or None; cvec [NC, E] or
     None; idxA / idxB int32 [R, T]; sc [NC, R, T]; maskbits int32 [R, T, 4]; actions int64 [R, T]."""
 
-    def __init__(self, buf, has_pb, gctx, cvec, idxA, idxB, sc, maskbits, actions, S, tstart, clip, temp, rollout_logp=None):
+    def __init__(self, buf, has_pb, gctx, cvec, idxA, idxB, sc, maskbits, actions, S, tstart, clip, temp, rollout_logp=None,
+                 slots=None, E=None, want_entropy=False):
         _chk(buf, "operands", torch.float32)
+        # slots: {"K", "V", "Lp", "Pa"[, "Pb"]} -> E-wide column block of buf (default: side by side in that order); with it
+        # the plan reads a decoder cache (ops.DecodeCache.buf) in place
         self.B, self.M, width = buf.shape
-        self.E = width // (5 if has_pb else 4)
+        self.slots = slots or {n: i for i, n in enumerate(["K", "V", "Lp", "Pa"] + (["Pb"] if has_pb else []))}
+        self.E = E if E is not None else width // (5 if has_pb else 4)
         self.buf, self.has_pb, self.gctx, self.cvec = buf, has_pb, gctx, cvec
+        self.entropy = None
+        self.want_entropy = bool(want_entropy)
         R, T = actions.shape
         if R != S * self.B:
             raise ValueError("reeval: rows must be S * B")
@@ -331,8 +337,8 @@ class ReevalPlan:
         s = _lib.Reeval()
         E4 = self.E * 4
         base = self.buf.data_ptr()
-        s.K, s.V, s.Lp, s.Pa = (C.c_void_p(base + i * E4) for i in range(4))
-        s.Pb = C.c_void_p(base + 4 * E4) if self.has_pb else None
+        s.K, s.V, s.Lp, s.Pa = (C.c_void_p(base + self.slots[n] * E4) for n in ("K", "V", "Lp", "Pa"))
+        s.Pb = C.c_void_p(base + self.slots["Pb"] * E4) if self.has_pb else None
         s.ld = self.buf.shape[2]
         s.gctx, s.Cvec, s.NC = _ptr(self.gctx), _ptr(self.cvec), self.NC
         s.idxA, s.idxB, s.sc = _ptr(self.idxA), _ptr(self.idxB if self.has_pb else None), _ptr(self.sc if self.NC else None)
@@ -340,12 +346,17 @@ class ReevalPlan:
         s.B, s.R, s.S, s.T, s.M, s.tstart, s.nchunk = self.B, self.R, self.S, self.T, self.M, self.tstart, self.nchunk
         s.clip, s.temp = self.clip, self.temp
         s.logp, s.lse = _ptr(self.logp), _ptr(self.lse)
+        s.entropy = _ptr(self.entropy)
         return s
 
     def forward(self):
-        if self.lse is None:
+        if self.lse is None and not self.want_entropy:
             return self.logp
         lib = _lib.load()
+        if self.want_entropy:
+            self.entropy = torch.empty(self.R, self.T, dtype=torch.float32, device=self.buf.device)
+            if self.lse is None:        # (the rollout's log-probs stay untouched: the kernel writes into a scratch)
+                self.logp = torch.empty(self.R, self.T, dtype=torch.float32, device=self.buf.device)
         s = self._struct()
         _lib.check(lib.eamrl_reeval_forward(C.byref(s), _stream(self.buf)), "eamrl_reeval_forward")
         return self.logp

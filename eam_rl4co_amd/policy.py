@@ -722,6 +722,17 @@ class AttentionModelPolicy(nn.Module):
         if not decoding_kwargs.pop("mask_logits", self.mask_logits):
             raise NotImplementedError("mask_logits=False is not built for MI355X")
         store_all_logp = decoding_kwargs.pop("store_all_logp", return_entropy)
+        # The reference keeps every step's full log-prob vector only to compute the entropy from it (base.py:259-260) -- the
+        # tensor itself is never returned.  Where the re-evaluation kernel covers the shape, the rollout stays one launch
+        # and the entropy comes from one teacher-forced pass over the finished tours (`_native_entropy`) instead of a
+        # host-driven step loop over [R, T, M] log-probs.
+        entropy_native = False
+        if store_all_logp and os.environ.get("EAMRL_ENTROPY_STEPWISE", "0") != "1":
+            from .train import native_reeval_supported
+            tk, tp = decoding_kwargs.get("top_k", 0) or 0, decoding_kwargs.get("top_p", 0.0) or 0.0
+            Mq = td["action_mask"].shape[-1]
+            if native_reeval_supported(self, Mq) and Mq <= 128 and not tk and not (0.0 < tp < 1.0):
+                store_all_logp, entropy_native = False, return_entropy
         num_starts = decoding_kwargs.pop("num_starts", None)
         num_samples = decoding_kwargs.pop("num_samples", None)
         multistart = decoding_kwargs.pop("multistart", False) or "multistart" in decode_type or (
@@ -853,7 +864,7 @@ class AttentionModelPolicy(nn.Module):
                     temperature=temperature, tanh_clipping=tanh_clipping, top_k=top_k, top_p=top_p,
                     select_best=select_best, calc_reward=calc_reward, env=env, st=st, td=td, cache=cache,
                     actions_pad=actions_pad, logp_pad=logp_pad, reward_pad=reward_pad, ll_pad=ll_pad,
-                    all_logp=all_logp, init_embeds=init_embeds, return_actions=return_actions,
+                    all_logp=all_logp, entropy_native=entropy_native, init_embeds=init_embeds, return_actions=return_actions,
                     return_entropy=return_entropy, return_hidden=return_hidden, return_init_embeds=return_init_embeds,
                     return_sum_log_likelihood=return_sum_log_likelihood)
 
@@ -920,8 +931,11 @@ class AttentionModelPolicy(nn.Module):
         if p["return_actions"]:
             out["actions"] = actions_out
         if p["return_entropy"]:
-            lp = torch.nan_to_num(p["all_logp"], nan=0.0, neginf=0.0)
-            out["entropy"] = -(lp.exp() * lp).sum(-1).sum(1)
+            if p.get("entropy_native"):
+                out["entropy"] = self._native_entropy(p, actions_out)
+            else:
+                lp = torch.nan_to_num(p["all_logp"], nan=0.0, neginf=0.0)
+                out["entropy"] = -(lp.exp() * lp).sum(-1).sum(1)
         if p["return_hidden"]:
             out["hidden"] = p["cache"]
         if p["return_init_embeds"]:
@@ -930,6 +944,32 @@ class AttentionModelPolicy(nn.Module):
         p["final_actions"] = actions_out
         p["final_logp"] = logprobs if not (S > 0 and p["select_best"]) else None
         return out
+
+    @torch.no_grad()
+    def _native_entropy(self, p: dict, actions_out: torch.Tensor) -> torch.Tensor:
+        """calculate_entropy (rl4co/utils/ops.py: -(p log p) summed over nodes and steps) of the finished tours [R, T]: one
+        launch of the teacher-forced forward kernel on the decoder cache of this very rollout, the env states replayed from
+        the actions (train.replay_states).  Forced steps (the multistart column, rows that are done) contribute 0, as the
+        reference's one-hot log-prob vectors do.  Hardware exp / log: within 1e-5 of the step-wise computation."""
+        from .train import replay_states
+
+        cache = p["cache"]
+        if p["S"] > 0 and p["select_best"]:
+            raise NotImplementedError("return_entropy together with select_best")
+        acts = actions_out.contiguous()
+        S = max(int(p["S"]), 1)
+        meta = replay_states(self, p["td"], acts, S, bool(p["pre"]))
+        E = cache.E
+        if self.env_name == "tsp":
+            cvec = cache.cvec.reshape(1, E).contiguous() if meta["placeholder"] else None
+        else:
+            cvec = cache.cvec.reshape(-1, E).contiguous()
+        slots = {n: cache.slots[n] for n in ("K", "V", "Lp", "Pa") + (("Pb",) if "Pb" in cache.slots else ())}
+        plan = ops.ReevalPlan(cache.buf, "Pb" in cache.slots, cache.gctx, cvec, meta["idxA"], meta["idxB"], meta["sc"],
+                              meta["maskbits"], acts, S, meta["tstart"], float(p["tanh_clipping"]), float(p["temperature"]),
+                              slots=slots, E=E, want_entropy=True)
+        plan.forward()
+        return plan.entropy.sum(1)
 
     def _beam_search(self, td, env, kw, calc_reward, return_actions, return_sum_log_likelihood, return_hidden,
                      return_init_embeds, max_steps):

@@ -258,12 +258,14 @@ typedef struct eamrl_reeval {
                                                              * lse == NULL (no forward pass run), logp = the ROLLOUT's per-step
                                                              * log-probs of `actions`, from which the normaliser is recovered */
     const float* glogp; float* dheads;                      /* backward: dL/dlogp [R][T]; scratch [R][T][E] */
+    float* entropy;                                         /* forward, optional: [R][T] entropy of each step's distribution
+                                                             * over the feasible nodes (calculate_entropy, utils/ops.py) */
     float *dK, *dV, *dLp, *dPa, *dPb; int64_t ldg;          /* gradients [B][M][.] (row stride ldg), ACCUMULATED into (+=) */
     float *dgctx, *dCvec;                                   /* [B][E] or NULL, [NC][E]; accumulated */
 } eamrl_reeval;
 
 int eamrl_reeval_supported(int M, int E, int H);                  /* 1 for M <= 112, E = 128, H = 8 */
-int eamrl_reeval_forward(const eamrl_reeval* p, void* stream);    /* -> logp, lse */
+int eamrl_reeval_forward(const eamrl_reeval* p, void* stream);    /* -> logp, lse (lse may be NULL) [, entropy] */
 int eamrl_reeval_backward(const eamrl_reeval* p, void* stream);   /* glogp, lse (or rollout logp) -> dK dV dLp dPa dPb dgctx dCvec */
 
 /* bits[(r * T + t) * 4 + n / 32] bit (n % 32) = mask[r][n] for step t (call after every replayed env transition). */

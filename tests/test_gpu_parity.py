@@ -556,6 +556,45 @@ def test_entropy_and_stepwise_path_agree_with_single_launch():
     assert torch.isfinite(b["entropy"]).all() and (b["entropy"] >= 0).all()
 
 
+@pytest.mark.parametrize("env_name,N,B,kw", [
+    ("tsp", 20, 6, dict(decode_type="sampling")), ("tsp", 100, 4, dict(decode_type="multistart_sampling", num_starts=10)),
+    ("tsp", 50, 3, dict(decode_type="greedy", num_samples=4, multisample=True)),
+    ("cvrp", 20, 6, dict(decode_type="sampling")), ("cvrp", 100, 3, dict(decode_type="multistart_greedy", num_starts=6)),
+    ("pctsp", 20, 5, dict(decode_type="sampling")), ("op", 20, 5, dict(decode_type="greedy")),
+    ("cvrptw", 20, 4, dict(decode_type="sampling")), ("tsp", 112, 2, dict(decode_type="sampling", temperature=1.7)),
+])
+def test_return_entropy_single_launch_equals_stepwise(env_name, N, B, kw):
+    """`return_entropy=True` (what the fork's EAM trainer passes, earl/model.py:153-155): the rollout stays one launch and
+    the entropy comes from one teacher-forced pass over the finished tours; same tours, log-likelihood and -- within 1e-4
+    relative -- the entropy of the host-driven step loop over full log-prob vectors (EAMRL_ENTROPY_STEPWISE=1)."""
+    import os
+
+    import eam_rl4co_amd as ea
+
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=N)
+    torch.manual_seed(N + B)
+    td = env.reset(batch_size=[B]).to(DEV)
+    pol = make_policy("am_" + env_name)
+    R = B * max(kw.get("num_starts", 1), kw.get("num_samples", 1))
+    noise = None
+    if "sampling" in kw["decode_type"]:
+        noise = torch.empty(R, 3 * td["locs"].shape[1] + 1, td["locs"].shape[1], device=DEV).exponential_(1)
+    outs = []
+    for stepwise in ("0", "1"):
+        os.environ["EAMRL_ENTROPY_STEPWISE"] = stepwise
+        try:
+            outs.append(pol(td.clone(), env, phase="test", return_entropy=True, **(dict(noise=noise) if noise is not None else {}),
+                            **kw))
+        finally:
+            os.environ.pop("EAMRL_ENTROPY_STEPWISE", None)
+    a, b = outs
+    assert torch.equal(a["actions"], b["actions"]) and torch.equal(a["reward"], b["reward"])
+    assert_bits_equal(a["log_likelihood"], b["log_likelihood"].cpu().numpy(), "log-likelihood")
+    ea_, eb = a["entropy"].cpu().numpy(), b["entropy"].cpu().numpy()
+    assert ea_.shape == (R,) and (eb > 0).all()
+    np.testing.assert_allclose(ea_, eb, rtol=1e-4, atol=1e-4)
+
+
 def test_status_flags_mirror_reference_asserts():
     """NaN weights -> 'Logits contain NaNs'; teacher forcing an already visited node -> 'infeasible action selected'."""
     import eam_rl4co_amd as ea
