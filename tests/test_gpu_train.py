@@ -105,6 +105,73 @@ def test_reference_trainer_step_runs_on_the_policy_and_matches_reference_gradien
                                        err_msg=str(k))
 
 
+@pytest.mark.parametrize("env_name,cfg,N", [("tsp", "pomo_tsp", 20), ("cvrp", "am_cvrp", 20)])
+def test_eam_shared_step_restated_runs_on_the_policy(env_name, cfg, N):
+    """EAM.shared_step's training branch (zoo/earl/model.py:146-247, POMO baseline) restated line by line around the policy
+    and evolution_worker -- including the `return_entropy=True` of its first policy call: differentiable log-likelihoods
+    for the sampled and the improved tours, the combined loss equal to train.eam_loss with the same evolution draws."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import train
+
+    B, S = 5, 8
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=11)
+    torch.manual_seed(11)
+    td = env.reset(batch_size=[B]).to(DEV)
+    init_td = td.clone()
+    pol = make_policy(cfg).train()
+    runner = ea.EA(env, dict(num_generations=2, mutation_rate=0.3, crossover_rate=0.8, selection_rate=0.6))
+    noise = torch.empty(B * S, 3 * td["locs"].shape[1] + 1, td["locs"].shape[1], device=DEV).exponential_(1)
+
+    def align(improved, original):                       # EAM._align_improved_actions, model.py:116-127
+        if improved.shape[-1] + 1 == original.shape[-1]:
+            return torch.cat([original[..., :1], improved], dim=-1)
+        return improved
+
+    # run_original_policy (model.py:150-156)
+    original_out = pol(td, env, phase="train", num_starts=S, return_entropy=True, decode_type="multistart_sampling", noise=noise)
+    assert original_out["entropy"].shape == (B * S,) and (original_out["entropy"] > 0).all()
+    # run_improved_policy (model.py:158-203)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    improved_actions, _ = ea.evolution_worker(original_out["actions"], init_td, runner, env, generator=gen)
+    improved_actions = align(improved_actions, original_out["actions"])
+    improved_out = pol(init_td, env, phase="train", num_starts=S, actions=improved_actions)
+    # losses (model.py:205-244)
+    original_reward = ea.unbatchify(original_out["reward"], (0, S))
+    original_ll = ea.unbatchify(original_out["log_likelihood"], (0, S))
+    calculate_loss(SharedBaseline(), td, env, original_out, original_reward, original_ll)
+    improved_reward = ea.unbatchify(improved_out["reward"], (0, S))
+    improved_ll = ea.unbatchify(improved_out["log_likelihood"], (0, S))
+    combined_out = {k: torch.cat([original_out[k], improved_out[k]], dim=0) for k in original_out
+                    if k in improved_out and isinstance(original_out[k], torch.Tensor) and original_out[k].dim() > 0}
+    combined_reward = torch.cat([original_reward, improved_reward], dim=0)
+    combined_ll = torch.cat([original_ll, improved_ll], dim=0)
+    calculate_loss(SharedBaseline(), None, env, combined_out, combined_reward, combined_ll)
+    loss = combined_out["loss"]
+    assert loss.requires_grad
+    pol.zero_grad()
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in pol.named_parameters() if p.grad is not None}
+    assert grads and all(torch.isfinite(g).all() for g in grads.values())
+    # the packaged step with the same noise and evolution draws
+    pol.zero_grad()
+    pol2 = pol
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    orig_forward = pol2.forward
+
+    def with_noise(td_, env_, **kw):                     # train.eam_loss samples its own noise: pin it to the recorded one
+        if kw.get("actions") is None:
+            kw["noise"] = noise
+        return orig_forward(td_, env_, **kw)
+
+    pol2.forward = with_noise
+    try:
+        res = train.eam_loss(pol2, env, td.clone(), runner, num_starts=S, generator=gen)
+    finally:
+        pol2.forward = orig_forward
+    assert torch.equal(res["improved_actions"], improved_actions)
+    np.testing.assert_allclose(float(res["loss"].detach()), float(loss.detach()), rtol=1e-6)
+
+
 @pytest.mark.parametrize("cfg,env_name,ns", [("am_tsp", "tsp", 0), ("am_cvrp", "cvrp", 0), ("am_cvrp", "cvrp", 5),
                                               ("pomo_tsp", "tsp", 8)])
 def test_differentiated_policy_is_the_sampled_policy(cfg, env_name, ns):
