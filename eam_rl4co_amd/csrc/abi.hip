@@ -324,6 +324,24 @@ __attribute__((visibility("default"))) int eamrl_reeval_backward(const eamrl_ree
     return launched(launch_reeval_bwd(*p, (hipStream_t)stream), "eamrl_reeval_backward");
 }
 
+__attribute__((visibility("default"))) int eamrl_replay_states(int env, const eamrl_state* s, int64_t R, int64_t B, int M,
+                                                              const int64_t* actions, int T, uint32_t* bits, int32_t* idxA,
+                                                              float* sc, void* stream)
+{
+    REQUIRE(env == EAMRL_ENV_CVRP || env == EAMRL_ENV_CVRPTW || env == EAMRL_ENV_PCTSP || env == EAMRL_ENV_OP,
+            "eamrl_replay_states (CVRP, CVRPTW, PCTSP or OP)");
+    REQUIRE(s && actions && bits && idxA && sc && R >= 0 && B > 0 && R % B == 0 && M >= 2 && M <= 128 && T > 0 &&
+                ((uintptr_t)bits % 16 == 0), "eamrl_replay_states");
+    REQUIRE(s->mask && s->visited && s->used && s->vcap && s->cur && s->demand, "eamrl_replay_states (state)");
+    if (env == EAMRL_ENV_PCTSP || env == EAMRL_ENV_OP) REQUIRE(s->istep != nullptr, "eamrl_replay_states (istep)");
+    if (env == EAMRL_ENV_OP) REQUIRE(s->locs != nullptr, "eamrl_replay_states (locs)");
+    if (env == EAMRL_ENV_CVRPTW) REQUIRE(s->time && s->locs && s->tw && s->dur, "eamrl_replay_states (time windows)");
+    if (R == 0) return 0;
+    return launched(launch_replay_states(env, s->mask, s->visited, s->used, s->vcap, s->cur, s->istep, s->time, s->demand, s->locs,
+                                         s->tw, s->dur, actions, bits, idxA, sc, R, B, M, T, (hipStream_t)stream),
+                    "eamrl_replay_states");
+}
+
 __attribute__((visibility("default"))) int eamrl_pack_mask_bits(const uint8_t* mask, uint32_t* bits, int64_t R, int M, int T,
                                                                int t, void* stream)
 {

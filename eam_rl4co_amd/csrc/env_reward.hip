@@ -42,27 +42,23 @@ __global__ __launch_bounds__(EB) void k_tsp_step(uint8_t* mask, int64_t* first, 
 
 // STEP = 0: mask only (get_action_mask); STEP = 1: transition then mask
 template <int STEP>
-__global__ __launch_bounds__(EB) void k_cvrp_step_mask(uint8_t* visited, float* used, const float* vcap,
-                                                       const float* demand, int64_t* cur, const int64_t* action,
-                                                       uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N)
+__device__ __forceinline__ void cvrp_step_mask_row(uint8_t* visited, float* used, const float* vcap,
+                                                       const float* demand, int64_t* cur, uint8_t* mask, uint8_t* done, int N, int64_t rs, int64_t bi, int lane, int64_t act)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-    if (r >= R) return;
     const int M = N + 1;
-    const float* dem = demand + (r % B) * N;
-    uint8_t* vis = visited + r * M;
-    float u = used[r];
-    int64_t c = cur[r];
+    const float* dem = demand + bi * N;
+    uint8_t* vis = visited + rs * M;
+    float u = used[rs];
+    int64_t c = cur[rs];
     int64_t a = -1;
     if (STEP) {
-        a = action[r];
+        a = act;
         int64_t di = a - 1;
         di = di < 0 ? 0 : (di > N - 1 ? N - 1 : di);
         u = (u + dem[di]) * (a != 0 ? 1.0f : 0.0f);
         c = a;
     }
-    const float lim = vcap[r] + 1e-5f;
+    const float lim = vcap[rs] + 1e-5f;
     int any_free = 0;
     int all_vis = 1;
     for (int j = lane; j < N; j += 64) {
@@ -70,7 +66,7 @@ __global__ __launch_bounds__(EB) void k_cvrp_step_mask(uint8_t* visited, float* 
         if (STEP && j + 1 == a) { v = 1; vis[j + 1] = 1; }
         const float load = dem[j] + u;
         const int blocked = v | (load > lim);
-        mask[r * M + 1 + j] = !blocked;
+        mask[rs * M + 1 + j] = !blocked;
         any_free |= !blocked;
         all_vis &= v;
     }
@@ -79,13 +75,24 @@ __global__ __launch_bounds__(EB) void k_cvrp_step_mask(uint8_t* visited, float* 
     if (lane == 0) {
         int v0 = vis[0] != 0;
         if (STEP && a == 0) { v0 = 1; vis[0] = 1; }
-        mask[r * M] = !((c == 0) && any);
+        mask[rs * M] = !((c == 0) && any);
         if (STEP) {
-            used[r] = u;
-            cur[r] = c;
-            done[r] = (allc && v0) ? 1 : 0;
+            used[rs] = u;
+            cur[rs] = c;
+            done[rs] = (allc && v0) ? 1 : 0;
         }
     }
+}
+
+template <int STEP>
+__global__ __launch_bounds__(EB) void k_cvrp_step_mask(uint8_t* visited, float* used, const float* vcap,
+                                                       const float* demand, int64_t* cur, const int64_t* action,
+                                                       uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    cvrp_step_mask_row<STEP>(visited, used, vcap, demand, cur, mask, done, N, r, r % B, lane, STEP ? action[r] : (int64_t)-1);
 }
 
 // SDVRP: rem = demand_with_depot.  STEP = 0: mask only; STEP = 1: deliver min(rem[action], free capacity), then mask.
@@ -191,24 +198,20 @@ __device__ __forceinline__ float dist2(float ax, float ay, float bx, float by)
 
 // OP: one wavefront per row.  STEP = 0: mask only; STEP = 1: move (tour length += leg), mark visited, then mask.
 template <int STEP>
-__global__ __launch_bounds__(EB) void k_op_step_mask(uint8_t* visited, float* tour_len, float* prize_tot, const float* prize,
+__device__ __forceinline__ void op_step_mask_row(uint8_t* visited, float* tour_len, float* prize_tot, const float* prize,
                                                      const float* locs, const float* maxlen, int64_t* cur, int64_t* istep,
-                                                     const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R,
-                                                     int64_t B, int M)
+                                                     uint8_t* mask, uint8_t* done, int M, int64_t rs, int64_t bi, int lane, int64_t act)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-    if (r >= R) return;
-    const float* L = locs + (r % B) * (int64_t)M * 2;
-    const float* ml = maxlen + (r % B) * (int64_t)M;
-    uint8_t* vis = visited + r * M;
-    float tl = tour_len[r];
-    int64_t c = cur[r];
+    const float* L = locs + bi * (int64_t)M * 2;
+    const float* ml = maxlen + bi * (int64_t)M;
+    uint8_t* vis = visited + rs * M;
+    float tl = tour_len[rs];
+    int64_t c = cur[rs];
     c = c < 0 ? 0 : (c > M - 1 ? M - 1 : c);
     int64_t a = -1;
     int v0 = vis[0] != 0;
     if (STEP) {
-        a = action[r];
+        a = act;
         a = a < 0 ? 0 : (a > M - 1 ? M - 1 : a);     // an out-of-range action must not become an out-of-bounds access
         tl = tl + dist2(L[2 * a], L[2 * a + 1], L[2 * c], L[2 * c + 1]);
         c = a;
@@ -219,61 +222,69 @@ __global__ __launch_bounds__(EB) void k_op_step_mask(uint8_t* visited, float* to
         int v = vis[n] != 0;
         if (STEP && n == a) { v = 1; vis[n] = 1; }
         const int exceeds = (tl + dist2(L[2 * n], L[2 * n + 1], cx, cy)) > ml[n];
-        mask[r * M + n] = !(v | v0 | exceeds);
+        mask[rs * M + n] = !(v | v0 | exceeds);
     }
     if (lane == 0) {
-        mask[r * M] = 1;                             // the depot can always be visited
+        mask[rs * M] = 1;                             // the depot can always be visited
         if (STEP) {
             if (a == 0) vis[0] = 1;
-            tour_len[r] = tl;
-            if (prize_tot) prize_tot[r] = prize_tot[r] + prize[(r % B) * M + a];
-            const int64_t i = istep[r];
-            done[r] = (a == 0 && i > 0) ? 1 : 0;
-            cur[r] = a;
-            istep[r] = i + 1;
+            tour_len[rs] = tl;
+            if (prize_tot) prize_tot[rs] = prize_tot[rs] + prize[bi * M + a];
+            const int64_t i = istep[rs];
+            done[rs] = (a == 0 && i > 0) ? 1 : 0;
+            cur[rs] = a;
+            istep[rs] = i + 1;
         }
     }
 }
 
-// CVRPTW: CVRP transition and mask plus the clock (cvrptw/env.py:103-138).  One wavefront per row.
 template <int STEP>
-__global__ __launch_bounds__(EB) void k_cvrptw_step_mask(uint8_t* visited, float* used, const float* vcap,
-                                                         const float* demand, int64_t* cur, float* time, const float* locs,
-                                                         const float* tw, const float* dur, const int64_t* action,
-                                                         uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N)
+__global__ __launch_bounds__(EB) void k_op_step_mask(uint8_t* visited, float* tour_len, float* prize_tot, const float* prize,
+                                                     const float* locs, const float* maxlen, int64_t* cur, int64_t* istep,
+                                                     const int64_t* action, uint8_t* mask, uint8_t* done, int64_t R,
+                                                     int64_t B, int M)
 {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (r >= R) return;
+    op_step_mask_row<STEP>(visited, tour_len, prize_tot, prize, locs, maxlen, cur, istep, mask, done, M, r, r % B, lane, STEP ? action[r] : (int64_t)-1);
+}
+
+// CVRPTW: CVRP transition and mask plus the clock (cvrptw/env.py:103-138).  One wavefront per row.
+template <int STEP>
+__device__ __forceinline__ void cvrptw_step_mask_row(uint8_t* visited, float* used, const float* vcap,
+                                                         const float* demand, int64_t* cur, float* time, const float* locs,
+                                                         const float* tw, const float* dur, uint8_t* mask, uint8_t* done, int N, int64_t rs, int64_t bi, int lane, int64_t act)
+{
     const int M = N + 1;
-    const float* dem = demand + (r % B) * N;
-    const float* L = locs + (r % B) * (int64_t)M * 2;
-    const float* W = tw + (r % B) * (int64_t)M * 2;
-    uint8_t* vis = visited + r * M;
-    float u = used[r], now = time[r];
-    int64_t c = cur[r];
+    const float* dem = demand + bi * N;
+    const float* L = locs + bi * (int64_t)M * 2;
+    const float* W = tw + bi * (int64_t)M * 2;
+    uint8_t* vis = visited + rs * M;
+    float u = used[rs], now = time[rs];
+    int64_t c = cur[rs];
     c = c < 0 ? 0 : (c > M - 1 ? M - 1 : c);
     int64_t a = -1;
     if (STEP) {
-        a = action[r];
+        a = act;
         a = a < 0 ? 0 : (a > M - 1 ? M - 1 : a);     // an out-of-range action must not become an out-of-bounds access
         const float arrive = now + dist2(L[2 * c], L[2 * c + 1], L[2 * a], L[2 * a + 1]);
         const float start = arrive > W[2 * a] ? arrive : W[2 * a];
-        now = (a != 0 ? 1.0f : 0.0f) * (start + dur[(r % B) * (int64_t)M + a]);
+        now = (a != 0 ? 1.0f : 0.0f) * (start + dur[bi * (int64_t)M + a]);
         int64_t di = a - 1;
         di = di < 0 ? 0 : (di > N - 1 ? N - 1 : di);
         u = (u + dem[di]) * (a != 0 ? 1.0f : 0.0f);
         c = a;
     }
     const float cx = L[2 * c], cy = L[2 * c + 1];
-    const float lim = vcap[r] + 1e-5f;
+    const float lim = vcap[rs] + 1e-5f;
     int any_free = 0, all_vis = 1;
     for (int j = lane; j < N; j += 64) {
         int v = vis[j + 1] != 0;
         if (STEP && j + 1 == a) { v = 1; vis[j + 1] = 1; }
         const int blocked = v | ((dem[j] + u) > lim);
         const int in_time = (now + dist2(cx, cy, L[2 * (j + 1)], L[2 * (j + 1) + 1])) <= W[2 * (j + 1) + 1];
-        mask[r * M + 1 + j] = (!blocked) & in_time;
+        mask[rs * M + 1 + j] = (!blocked) & in_time;
         any_free |= !blocked;                        // the depot rule looks at the CVRP mask only
         all_vis &= v;
     }
@@ -283,14 +294,26 @@ __global__ __launch_bounds__(EB) void k_cvrptw_step_mask(uint8_t* visited, float
         int v0 = vis[0] != 0;
         if (STEP && a == 0) { v0 = 1; vis[0] = 1; }
         const int in_time0 = (now + dist2(cx, cy, L[0], L[1])) <= W[1];
-        mask[r * M] = (!((c == 0) && any)) & in_time0;
+        mask[rs * M] = (!((c == 0) && any)) & in_time0;
         if (STEP) {
-            used[r] = u;
-            time[r] = now;
-            cur[r] = c;
-            done[r] = (allc && v0) ? 1 : 0;
+            used[rs] = u;
+            time[rs] = now;
+            cur[rs] = c;
+            done[rs] = (allc && v0) ? 1 : 0;
         }
     }
+}
+
+template <int STEP>
+__global__ __launch_bounds__(EB) void k_cvrptw_step_mask(uint8_t* visited, float* used, const float* vcap,
+                                                         const float* demand, int64_t* cur, float* time, const float* locs,
+                                                         const float* tw, const float* dur, const int64_t* action,
+                                                         uint8_t* mask, uint8_t* done, int64_t R, int64_t B, int N)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    cvrptw_step_mask_row<STEP>(visited, used, vcap, demand, cur, time, locs, tw, dur, mask, done, N, r, r % B, lane, STEP ? action[r] : (int64_t)-1);
 }
 
 // the time-window replay of CVRPTWEnv.check_solution_validity (cvrptw/env.py:203-227): sequential, one thread per row
@@ -385,6 +408,44 @@ __global__ __launch_bounds__(EB) void k_check_op(const int64_t* actions, const f
 // PCTSP: one wavefront per row.  STEP = 0: mask only; STEP = 1: collect prize (and penalty), mark visited, then mask.
 // prize / penalty [B][M] with a zero depot slot; pen_tot / penalty may be null together.
 template <int STEP>
+__device__ __forceinline__ void pctsp_step_mask_row(uint8_t* visited, float* prize_tot, float* pen_tot,
+                                                        const float* prize, const float* penalty, int64_t* cur,
+                                                        int64_t* istep, uint8_t* mask,
+                                                        uint8_t* done, int M, int64_t rs, int64_t bi, int lane, int64_t act)
+{
+    uint8_t* vis = visited + rs * M;
+    float pt = prize_tot[rs];
+    int64_t a = -1;
+    int v0 = vis[0] != 0;
+    if (STEP) {
+        a = act;
+        a = a < 0 ? 0 : (a > M - 1 ? M - 1 : a);     // an out-of-range action must not become an out-of-bounds access
+        pt = pt + prize[bi * M + a];
+        if (a == 0) v0 = 1;
+    }
+    int unvisited = 0;
+    for (int n = 1 + lane; n < M; n += 64) {
+        int v = vis[n] != 0;
+        if (STEP && n == a) { v = 1; vis[n] = 1; }
+        mask[rs * M + n] = !(v | v0);
+        unvisited |= !v;
+    }
+    const bool unv = __ballot(unvisited != 0) != 0ull;
+    if (lane == 0) {
+        mask[rs * M] = !((pt < 1.0f) && unv);
+        if (STEP) {
+            if (a == 0) vis[0] = 1;
+            prize_tot[rs] = pt;
+            if (pen_tot) pen_tot[rs] = pen_tot[rs] + penalty[bi * M + a];
+            const int64_t i = istep[rs];
+            done[rs] = (i > 0 && a == 0) ? 1 : 0;
+            cur[rs] = a;
+            istep[rs] = i + 1;
+        }
+    }
+}
+
+template <int STEP>
 __global__ __launch_bounds__(EB) void k_pctsp_step_mask(uint8_t* visited, float* prize_tot, float* pen_tot,
                                                         const float* prize, const float* penalty, int64_t* cur,
                                                         int64_t* istep, const int64_t* action, uint8_t* mask,
@@ -393,36 +454,7 @@ __global__ __launch_bounds__(EB) void k_pctsp_step_mask(uint8_t* visited, float*
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (r >= R) return;
-    uint8_t* vis = visited + r * M;
-    float pt = prize_tot[r];
-    int64_t a = -1;
-    int v0 = vis[0] != 0;
-    if (STEP) {
-        a = action[r];
-        a = a < 0 ? 0 : (a > M - 1 ? M - 1 : a);     // an out-of-range action must not become an out-of-bounds access
-        pt = pt + prize[(r % B) * M + a];
-        if (a == 0) v0 = 1;
-    }
-    int unvisited = 0;
-    for (int n = 1 + lane; n < M; n += 64) {
-        int v = vis[n] != 0;
-        if (STEP && n == a) { v = 1; vis[n] = 1; }
-        mask[r * M + n] = !(v | v0);
-        unvisited |= !v;
-    }
-    const bool unv = __ballot(unvisited != 0) != 0ull;
-    if (lane == 0) {
-        mask[r * M] = !((pt < 1.0f) && unv);
-        if (STEP) {
-            if (a == 0) vis[0] = 1;
-            prize_tot[r] = pt;
-            if (pen_tot) pen_tot[r] = pen_tot[r] + penalty[(r % B) * M + a];
-            const int64_t i = istep[r];
-            done[r] = (i > 0 && a == 0) ? 1 : 0;
-            cur[r] = a;
-            istep[r] = i + 1;
-        }
-    }
+    pctsp_step_mask_row<STEP>(visited, prize_tot, pen_tot, prize, penalty, cur, istep, mask, done, M, r, r % B, lane, STEP ? action[r] : (int64_t)-1);
 }
 
 // PCTSPEnv.check_solution_validity (pctsp/env.py:189-205): one wavefront per row.  bad[0] += rows with a customer
@@ -628,6 +660,74 @@ __global__ __launch_bounds__(EB) void k_check_solution(int env, const int64_t* a
             if (usedc > lim) over = 1;
         }
         if (over) atomicAdd(&bad[1], 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The env state BEFORE every decode step of given action rows, in one launch (depot envs; TSP is closed-form in the
+// actions: k_tsp_mask_bits): a wavefront keeps its row's state in LDS and alternates "record" (mask as a 128-bit set,
+// current node, state scalars) and the env's own transition -- the very row functions of the step kernels above.
+// Replaces T x (pack bits, copy current node, state scalar, step) launches of the re-evaluation's set-up.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ReplayArgs {
+    const uint8_t* mask; const uint8_t* visited; const float* used; const float* vcap; const int64_t* cur; const int64_t* istep;
+    const float* time; const float* demand; const float* locs; const float* tw; const float* dur;
+    const int64_t* actions; uint32_t* bits; int32_t* idxA; float* sc;
+    int64_t R, B; int M, T;
+};
+
+template <int ENV>
+__global__ __launch_bounds__(EB) void k_replay_states(ReplayArgs a)
+{
+    __shared__ uint8_t s_mask[ROWS_PER_BLOCK][128], s_vis[ROWS_PER_BLOCK][128], s_done[ROWS_PER_BLOCK][8];
+    __shared__ float s_used[ROWS_PER_BLOCK], s_time[ROWS_PER_BLOCK];
+    __shared__ int64_t s_cur[ROWS_PER_BLOCK], s_istep[ROWS_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wv;
+    if (r >= a.R) return;
+    const int M = a.M, T = a.T;
+    const int64_t bi = r % a.B;
+    for (int n = lane; n < 128; n += 64) {
+        s_mask[wv][n] = n < M ? a.mask[r * M + n] : 0;
+        s_vis[wv][n] = n < M ? a.visited[r * M + n] : 0;
+    }
+    if (lane == 0) {
+        s_used[wv] = a.used[r];
+        s_time[wv] = a.time ? a.time[r] : 0.0f;
+        s_cur[wv] = a.cur[r];
+        s_istep[wv] = a.istep ? a.istep[r] : 0;
+        s_done[wv][0] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float vc = a.vcap[r];
+    for (int t = 0; t < T; ++t) {
+        // ---- record ------------------------------------------------------------------------------------------------------
+        const unsigned long long b0 = __ballot(s_mask[wv][lane] != 0), b1 = __ballot(s_mask[wv][64 + lane] != 0);
+        if (lane == 0) {
+            const int64_t q = r * T + t;
+            *reinterpret_cast<uint4*>(a.bits + q * 4) =
+                make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32));
+            a.idxA[q] = (int32_t)s_cur[wv];
+            float free_ = vc - s_used[wv];            // free capacity / prize still to collect / length still allowed
+            if (ENV == EAMRL_ENV_PCTSP) free_ = free_ < 0.0f ? 0.0f : free_;
+            a.sc[q] = free_;
+            if (ENV == EAMRL_ENV_CVRPTW) a.sc[a.R * (int64_t)T + q] = s_time[wv];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- the env transition (+ next mask) ---------------------------------------------------------------------------
+        const int64_t act = a.actions[r * T + t];
+        if (ENV == EAMRL_ENV_CVRP)
+            cvrp_step_mask_row<1>(s_vis[wv], &s_used[wv], &vc, a.demand, &s_cur[wv], s_mask[wv], s_done[wv], M - 1, 0, bi, lane, act);
+        else if (ENV == EAMRL_ENV_CVRPTW)
+            cvrptw_step_mask_row<1>(s_vis[wv], &s_used[wv], &vc, a.demand, &s_cur[wv], &s_time[wv], a.locs, a.tw, a.dur, s_mask[wv],
+                                    s_done[wv], M - 1, 0, bi, lane, act);
+        else if (ENV == EAMRL_ENV_PCTSP)
+            pctsp_step_mask_row<1>(s_vis[wv], &s_used[wv], nullptr, a.demand, nullptr, &s_cur[wv], &s_istep[wv], s_mask[wv], s_done[wv],
+                                   M, 0, bi, lane, act);
+        else
+            op_step_mask_row<1>(s_vis[wv], &s_used[wv], nullptr, nullptr, a.locs, a.demand, &s_cur[wv], &s_istep[wv], s_mask[wv],
+                                s_done[wv], M, 0, bi, lane, act);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -849,6 +949,21 @@ int launch_tour_length(const float* locs, const int64_t* actions, float* reward,
 int launch_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T, hipStream_t st)
 {
     hipLaunchKernelGGL(k_sum_logp, dim3((unsigned)((R + 63) / 64)), dim3(256), 0, st, logp, ld, out, R, T);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_replay_states(int env, const uint8_t* mask, const uint8_t* visited, const float* used, const float* vcap,
+                         const int64_t* cur, const int64_t* istep, const float* time, const float* demand, const float* locs,
+                         const float* tw, const float* dur, const int64_t* actions, uint32_t* bits, int32_t* idxA, float* sc,
+                         int64_t R, int64_t B, int M, int T, hipStream_t st)
+{
+    ReplayArgs a{mask, visited, used, vcap, cur, istep, time, demand, locs, tw, dur, actions, bits, idxA, sc, R, B, M, T};
+    const dim3 grid(row_blocks(R)), block(EB);
+    if (env == EAMRL_ENV_CVRP) hipLaunchKernelGGL(k_replay_states<EAMRL_ENV_CVRP>, grid, block, 0, st, a);
+    else if (env == EAMRL_ENV_CVRPTW) hipLaunchKernelGGL(k_replay_states<EAMRL_ENV_CVRPTW>, grid, block, 0, st, a);
+    else if (env == EAMRL_ENV_PCTSP) hipLaunchKernelGGL(k_replay_states<EAMRL_ENV_PCTSP>, grid, block, 0, st, a);
+    else if (env == EAMRL_ENV_OP) hipLaunchKernelGGL(k_replay_states<EAMRL_ENV_OP>, grid, block, 0, st, a);
+    else return EAMRL_E_ARG;
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 

@@ -281,6 +281,26 @@ def pack_mask_bits_(mask, bits, t):
                "eamrl_pack_mask_bits")
 
 
+def replay_states(st, actions, B):
+    """Depot envs (cvrp, cvrptw, pctsp, op): mask bits [R, T, 4], current node idxA [R, T] and the state scalars
+    sc [NC, R, T] BEFORE every step of actions [R, T], starting from the flat state `st` (not modified) -- one launch
+    (eamrl_replay_states) instead of T rounds of pack-bits / copy / step."""
+    lib = _lib.load()
+    _chk(actions, "actions", torch.int64)
+    R, T = actions.shape
+    if R != st.R or st.env_name not in ("cvrp", "cvrptw", "pctsp", "op") or st.M > 128:
+        raise ValueError("replay_states: cvrp / cvrptw / pctsp / op states of at most 128 nodes, one action row per state row")
+    dev = actions.device
+    NC = 2 if st.env_name == "cvrptw" else 1
+    bits = torch.empty(R, T, 4, dtype=torch.int32, device=dev)
+    idxA = torch.empty(R, T, dtype=torch.int32, device=dev)
+    sc = torch.empty(NC, R, T, dtype=torch.float32, device=dev)
+    ss = st.struct()
+    _lib.check(lib.eamrl_replay_states(ENVS[st.env_name], C.byref(ss), R, int(B), st.M, _ptr(actions), T, _ptr(bits), _ptr(idxA),
+                                       _ptr(sc), _stream(actions)), "eamrl_replay_states")
+    return bits, idxA, sc
+
+
 def tsp_mask_bits(actions, M):
     lib = _lib.load()
     _chk(actions, "actions", torch.int64)

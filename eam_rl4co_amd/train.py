@@ -17,6 +17,8 @@ rl4co/models/rl/reinforce/baselines.py:57-61 (SharedBaseline), rl4co/models/zoo/
 """
 from __future__ import annotations
 
+import os
+
 import math
 
 import torch
@@ -392,7 +394,12 @@ def replay_states(policy, td, actions, S: int, multistart: bool):
             placeholder = True
         return dict(maskbits=bits, idxA=first, idxB=prev.contiguous(), sc=sc, tstart=1 if multistart else 0,
                     placeholder=placeholder)
-    st = state_from_td(env_name, td, S)
+    B = td["action_mask"].shape[0]
+    if os.environ.get("EAMRL_REPLAY_LOOP", "0") != "1":        # one launch: the env's transitions replayed inside a kernel
+        st = state_from_td(env_name, td, S, copy=False)         # read-only
+        bits, idxA, sc = ops.replay_states(st, actions, B)
+        return dict(maskbits=bits, idxA=idxA, idxB=None, sc=sc, tstart=1 if multistart else 0, placeholder=False)
+    st = state_from_td(env_name, td, S)                         # (the step-by-step form, kept as the cross-check)
     NC = 2 if env_name == "cvrptw" else 1
     bits = torch.empty(R, T, 4, dtype=torch.int32, device=dev)
     idxA = torch.empty(R, T, dtype=torch.int32, device=dev)

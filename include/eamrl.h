@@ -403,6 +403,15 @@ int eamrl_multi_copy(int n, const void* const* src, void* const* dst, const int6
 int eamrl_check_solution(int env, const int64_t* actions, const float* demand, const float* vcap, int64_t R,
                          int64_t B, int N, int T, int32_t* bad, void* stream);
 
+/* The per-step inputs of eamrl_reeval_* for the depot envs (EAMRL_ENV_CVRP / _CVRPTW / _PCTSP / _OP) in one launch: starting
+ * from the given state (read-only; the fields of eamrl_state that the env's step kernel uses, per row as there) the env
+ * transitions of actions [R][T] are replayed, and BEFORE each step t are recorded: bits[r][t][4] the feasibility mask,
+ * idxA[r][t] the current node, sc[0][r][t] = vcap - used (PCTSP: clamped at 0: prize still to collect; OP: length still
+ * allowed) and, CVRPTW, sc[1][r][t] = the current time.  Same transitions as eamrl_*_step_mask (the same code), i.e. the
+ * same result as T rounds of {eamrl_pack_mask_bits, copy, eamrl_*_step_mask}.  M <= 128. */
+int eamrl_replay_states(int env, const eamrl_state* state, int64_t R, int64_t B, int M, const int64_t* actions, int T,
+                        uint32_t* bits, int32_t* idxA, float* sc, void* stream);
+
 /* ---- beam search ------------------------------------------------------------------------------------------ */
 
 /* BeamSearch._make_beam_step  [rl4co/utils/decoding.py:573-608].  Rows in "(w b)" order, R = beam_width * B.

@@ -105,6 +105,38 @@ def test_reference_trainer_step_runs_on_the_policy_and_matches_reference_gradien
                                        err_msg=str(k))
 
 
+@pytest.mark.parametrize("env_name,N,B,ns", [("cvrp", 20, 7, 0), ("cvrp", 100, 3, 6), ("cvrp", 127, 2, 0), ("cvrptw", 20, 5, 0),
+                                             ("cvrptw", 50, 2, 4), ("pctsp", 20, 6, 0), ("pctsp", 100, 2, 5), ("op", 20, 6, 0),
+                                             ("op", 100, 3, 4)])
+def test_replay_states_kernel_equals_step_by_step(env_name, N, B, ns):
+    """eamrl_replay_states (the env transitions replayed inside one kernel) gives bit for bit what T rounds of
+    {pack mask bits, copy current node, state scalar, env step kernel} give: the inputs of the re-evaluation kernels."""
+    import os
+
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd.train import replay_states
+
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=N + B)
+    torch.manual_seed(N)
+    td = env.reset(batch_size=[B]).to(DEV)
+    pol = make_policy("am_" + env_name)
+    kw = dict(decode_type="multistart_sampling", num_starts=ns) if ns else dict(decode_type="sampling")
+    with torch.no_grad():
+        acts = pol(td.clone(), env, phase="test", **kw)["actions"].contiguous()
+    res = []
+    for loop in ("0", "1"):
+        os.environ["EAMRL_REPLAY_LOOP"] = loop
+        try:
+            res.append(replay_states(pol, td, acts, max(ns, 1), bool(ns)))
+        finally:
+            os.environ.pop("EAMRL_REPLAY_LOOP", None)
+    a, b = res
+    assert torch.equal(a["maskbits"], b["maskbits"]) and torch.equal(a["idxA"], b["idxA"])
+    assert_bits_equal(a["sc"], b["sc"].cpu().numpy(), "state scalars")
+    assert a["tstart"] == b["tstart"] and a["idxB"] is None and a["sc"].shape[0] == (2 if env_name == "cvrptw" else 1)
+    assert int((a["maskbits"] != 0).sum()) > 0
+
+
 @pytest.mark.parametrize("env_name,cfg,N", [("tsp", "pomo_tsp", 20), ("cvrp", "am_cvrp", 20)])
 def test_eam_shared_step_restated_runs_on_the_policy(env_name, cfg, N):
     """EAM.shared_step's training branch (zoo/earl/model.py:146-247, POMO baseline) restated line by line around the policy
