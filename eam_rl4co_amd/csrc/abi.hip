@@ -443,7 +443,7 @@ __attribute__((visibility("default"))) int eamrl_am_rollout(int env, const eamrl
     a.action = actions; a.logp = logps; a.steps_out = steps_out;
     const bool filtering = top_k > 0 || (top_p > 0.0f && top_p < 1.0f);        // only the streaming kernel filters
     if (!g_debug[11] && !filtering && rollout_ms_mfma_supports(env, a))
-        return launched(launch_rollout_ms_mfma(a, (hipStream_t)stream), "eamrl_am_rollout");
+        return launched(launch_rollout_ms_mfma(env, a, (hipStream_t)stream), "eamrl_am_rollout");
     if (!g_debug[1] && !filtering && rollout_resident_supports(env, a))
         return launched(launch_rollout_resident(env, a, (hipStream_t)stream), "eamrl_am_rollout");
     return launched(launch_rollout_stream(env, a, (hipStream_t)stream), "eamrl_am_rollout");
@@ -480,7 +480,7 @@ __attribute__((visibility("default"))) int eamrl_am_rollout_seeded(int env, cons
     a.action = actions; a.logp = logps; a.steps_out = steps_out;
     if (!g_debug[11] && rollout_ms_mfma_supports(env, a)) {
         a.seed = seed; a.seed_dev = seed_dev; a.use_rng = 1;
-        return launched(launch_rollout_ms_mfma(a, (hipStream_t)stream), "eamrl_am_rollout_seeded");
+        return launched(launch_rollout_ms_mfma(env, a, (hipStream_t)stream), "eamrl_am_rollout_seeded");
     }
     // kernels without in-place noise: the same draws as a tensor in the caller's scratch
     REQUIRE(noise_scratch != nullptr, "eamrl_am_rollout_seeded (noise_scratch [R][t_max][M] needed for this shape)");

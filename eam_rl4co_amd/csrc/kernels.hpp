@@ -90,7 +90,7 @@ void launch_rollout_pad(int env, const DecArgs& a, hipStream_t st);   // final s
 int launch_rollout_resident(int env, const DecArgs& a, hipStream_t st);
 bool rollout_resident_supports(int env, const DecArgs& a);
 bool rollout_ms_mfma_supports(int env, const DecArgs& a);
-int launch_rollout_ms_mfma(const DecArgs& a, hipStream_t st);
+int launch_rollout_ms_mfma(int env, const DecArgs& a, hipStream_t st);
 int launch_exp1_noise(uint64_t seed, const uint64_t* seed_dev, float* noise, int64_t R, int T, int M, hipStream_t st);
 int launch_ea_tsp(const float* locs, int64_t* pop, float* fitness, int64_t B, int S, int N, int G, double mutation_rate,
                   double crossover_rate, double selection_rate, const double* cross_rand, const int32_t* cross_idx,

@@ -69,9 +69,12 @@ __device__ __forceinline__ int group_min(int v)
 // CC: the node-chunk length ceil(M / 4) as a compile-time value (0: run time).  With it every "does k-step t touch chunk g"
 // decision folds away; left to run time the ~100 uniform conditions are hoisted out of the loops into SGPRs that spill
 // (measured: 256 VGPRs + scratch vs 167 VGPRs), so the common sizes get their own instantiation.
-template <int RTT, int CC>
+// ENV: EAMRL_ENV_TSP or EAMRL_ENV_CVRP (state machine of the starts: bit-set masks either way; CVRP adds the visited set, the
+// load of the vehicle and the per-step mask recomputation, cvrp/env.py:68-144).
+template <int RTT, int CC, int ENV>
 __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, int nsplit)
 {
+    constexpr bool CV = ENV == EAMRL_ENV_CVRP;
     __shared__ __attribute__((aligned(16))) float QT[16 * TS];
     __shared__ __attribute__((aligned(16))) float HT[16 * TS];
     __shared__ float RED[8][16], RED2[8][16], LPS[16];
@@ -79,6 +82,8 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
     __shared__ float REDLP[8][16], LP0[16];
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[SMAX][4];
     __shared__ int s_cur[SMAX], s_first[SMAX], s_istep[SMAX], s_cnt[SMAX], s_done[SMAX];
+    __shared__ __attribute__((aligned(16))) uint32_t s_vis[CV ? SMAX : 1][4];       // CVRP: visited nodes (depot = bit 0)
+    __shared__ float s_used[CV ? SMAX : 1], s_cap[CV ? SMAX : 1], s_dem[CV ? 128 : 1];   // load, capacity; demand of node n
     __shared__ uint32_t s_flags;
     extern __shared__ __attribute__((aligned(16))) float LPF[];    // [RTT waves][32 k-steps][64 lanes]: the logit-key (Lp) A fragments
                                                                     // (kept in LDS, lane-linear: 32 VGPRs fewer per wave)
@@ -137,11 +142,23 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
             if (a.mask[r * M + n]) { w[n >> 5] |= 1u << (n & 31); ++cnt; }
         s_bits[s][0] = w[0]; s_bits[s][1] = w[1]; s_bits[s][2] = w[2]; s_bits[s][3] = w[3];
         s_cur[s] = (int)a.cur[r];
-        s_first[s] = (int)a.first[r];
-        s_istep[s] = (int)a.istep[r];
+        if (CV) {
+            uint32_t v[4] = {0, 0, 0, 0};
+            cnt = 0;                                   // CVRP: nodes visited so far (the episode ends at M, depot included)
+            for (int n = 0; n < M; ++n)
+                if (a.visited[r * M + n]) { v[n >> 5] |= 1u << (n & 31); ++cnt; }
+            s_vis[s][0] = v[0]; s_vis[s][1] = v[1]; s_vis[s][2] = v[2]; s_vis[s][3] = v[3];
+            s_used[s] = a.used[r];
+            s_cap[s] = a.vcap[r];
+        } else {
+            s_first[s] = (int)a.first[r];
+            s_istep[s] = (int)a.istep[r];
+        }
         s_cnt[s] = cnt;
         s_done[s] = a.done[r] != 0;
     }
+    if (CV)
+        for (int n = tid; n < 128; n += blockDim.x) s_dem[n] = (n >= 1 && n < M) ? a.demand[b * (M - 1) + n - 1] : 0.0f;
     if (tid == 0) s_flags = 0;
     __syncthreads();
 
@@ -155,7 +172,13 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
         if (s < S && !s_done[s]) {
             float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.gctx) g4 = *reinterpret_cast<const float4*>(a.gctx + b * ME + 4 * e4);
-            if (s_istep[s] == 0) {
+            if (CV) {               // VRPContext: fma(capacity column, free capacity, Pa[current]) + graph context
+                const float4 c4 = *reinterpret_cast<const float4*>(a.cvec + 4 * e4);
+                const float4 p = *reinterpret_cast<const float4*>(a.Pa + (b * M + s_cur[s]) * ld + 4 * e4);
+                const float fr = s_cap[s] - s_used[s];
+                v = make_float4(fma_(c4.x, fr, p.x) + g4.x, fma_(c4.y, fr, p.y) + g4.y, fma_(c4.z, fr, p.z) + g4.z,
+                                fma_(c4.w, fr, p.w) + g4.w);
+            } else if (s_istep[s] == 0) {
                 const float4 c4 = *reinterpret_cast<const float4*>(a.cvec + 4 * e4);
                 v = make_float4(c4.x + g4.x, c4.y + g4.y, c4.z + g4.z, c4.w + g4.w);
             } else {
@@ -176,6 +199,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_readcyclecounter();
 #endif
     for (;;) {
+        __syncthreads();                 // the last tile's transition (its done flags) before anyone looks at them
         int active = 0;
         for (int s = s_lo + tid; s < s_hi; s += blockDim.x) active |= !s_done[s];
         if (!__syncthreads_or(active) || t >= a.t_max) break;
@@ -406,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 __syncthreads();
             }
             // ---- env transition (TSPEnv._step, tsp/env.py:62-88) of the tile's 16 starts: lanes (j, G = 0) of wave 0 -------------
-            if (tid < 16) {
+            if (!CV && tid < 16) {
                 const int s = 16 * qt + tid;
                 if (s < S && !s_done[s]) {
                     const int sl = sel;
@@ -432,6 +456,64 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                     s_done[s] = s_cnt[s] == 0;
                 }
             }
+            // ---- CVRP: CVRPEnv._step + get_action_mask (cvrp/env.py:68-100,132-144).  Half-wavefront hw owns start 16 qt + hw: every
+            // lane knows the pick, lane l tests nodes l, l + 32, l + 64, l + 96, the ballots are the new mask words ---------------
+            if (CV) {
+                const int hw = tid >> 5, l32 = tid & 31;
+                const int s = 16 * qt + hw;
+                if (s < S && !s_done[s]) {
+                    int sl = 1 << 20;
+#pragma unroll
+                    for (int w = 0; w < RTT; ++w) sl = min(sl, REDI[w][hw]);
+                    const int pk = sl;
+                    const int64_t r = (int64_t)s * a.B + b;
+                    if (a.mode == EAMRL_EVALUATE) sl = (t < a.t_given) ? (int)a.given[r * a.t_given + t] : 0;
+                    if (sl < 0 || sl >= M) sl = 0;                 // (flagged above by the query's own lanes)
+                    float lpv;
+                    if (a.mode == EAMRL_EVALUATE) lpv = LPS[hw];
+                    else {
+                        lpv = LP0[hw];
+#pragma unroll
+                        for (int w = 0; w < RTT; ++w)
+                            if (sl == pk && REDI[w][hw] == pk) lpv = REDLP[w][hw];
+                    }
+                    const uint4 ob = *reinterpret_cast<const uint4*>(&s_bits[s][0]);
+                    uint4 vw = *reinterpret_cast<const uint4*>(&s_vis[s][0]);
+                    const uint32_t bit = 1u << (sl & 31);
+                    const int wi = sl >> 5;
+                    const uint32_t oword = wi == 0 ? ob.x : wi == 1 ? ob.y : wi == 2 ? ob.z : ob.w;
+                    const uint32_t vword = wi == 0 ? vw.x : wi == 1 ? vw.y : wi == 2 ? vw.z : vw.w;
+                    const bool was_vis = (vword & bit) != 0;
+                    if (wi == 0) vw.x |= bit; else if (wi == 1) vw.y |= bit; else if (wi == 2) vw.z |= bit; else vw.w |= bit;
+                    int di = sl - 1;
+                    di = di < 0 ? 0 : (di > M - 2 ? M - 2 : di);
+                    const float u = (s_used[s] + s_dem[di + 1]) * (sl != 0 ? 1.0f : 0.0f);
+                    const float lim = s_cap[s] + 1e-5f;
+                    uint32_t nb[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int n = 32 * k + l32;
+                        const uint32_t vk = k == 0 ? vw.x : k == 1 ? vw.y : k == 2 ? vw.z : vw.w;
+                        const bool ok = n >= 1 && n < M && !((vk >> l32) & 1u) && !((s_dem[n] + u) > lim);
+                        const unsigned long long bl = __ballot(ok);
+                        nb[k] = (uint32_t)(bl >> (32 * (hw & 1)));
+                    }
+                    const bool any_free = (nb[0] | nb[1] | nb[2] | nb[3]) != 0u;
+                    if (!((sl == 0) && any_free)) nb[0] |= 1u;          // the depot: closed only while at it with customers left
+                    if (l32 == 0) {
+                        a.action[r * a.t_max + t] = sl;
+                        a.logp[r * a.t_max + t] = lpv;
+                        if (!(oword & bit)) atomicOr(&s_flags, EAMRL_ST_INFEASIBLE);
+                        *reinterpret_cast<uint4*>(&s_bits[s][0]) = make_uint4(nb[0], nb[1], nb[2], nb[3]);
+                        *reinterpret_cast<uint4*>(&s_vis[s][0]) = vw;
+                        s_used[s] = u;
+                        s_cur[s] = sl;
+                        const int cnt = s_cnt[s] + (was_vis ? 0 : 1);
+                        s_cnt[s] = cnt;
+                        s_done[s] = cnt == M;
+                    }
+                }
+            }
             // (ordered against its readers by the barriers of the next tile: REDI / REDLP are rewritten only after three of them,
             //  and the state of these 16 starts is next read one round later, or behind the tile-start barrier when nqt == 1)
             MSTAMP(14);
@@ -450,8 +532,13 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
         const int64_t r = (int64_t)s * a.B + b;
         for (int n = 0; n < M; ++n) a.mask[r * M + n] = (s_bits[s][n >> 5] >> (n & 31)) & 1u;
         a.cur[r] = s_cur[s];
-        a.first[r] = s_first[s];
-        a.istep[r] = s_istep[s];
+        if (CV) {
+            for (int n = 0; n < M; ++n) a.visited[r * M + n] = (s_vis[s][n >> 5] >> (n & 31)) & 1u;
+            a.used[r] = s_used[s];
+        } else {
+            a.first[r] = s_first[s];
+            a.istep[r] = s_istep[s];
+        }
         a.done[r] = s_done[s] ? 1 : 0;
         if (!s_done[s]) atomicOr(&s_flags, EAMRL_ST_STEP_OVERRUN);
     }
@@ -462,11 +549,11 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
     }
 }
 
-template <int RTT, int CC>
+template <int RTT, int CC, int ENV>
 int launch_t(const DecArgs& a, int S, hipStream_t st)
 {
     const size_t lds = (size_t)RTT * 32 * 64 * sizeof(float);
-    auto k = k_rollout_ms_mfma<RTT, CC>;
+    auto k = k_rollout_ms_mfma<RTT, CC, ENV>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 32 * 1024)) !=
         hipSuccess)
         return EAMRL_E_LAUNCH;
@@ -477,6 +564,14 @@ int launch_t(const DecArgs& a, int S, hipStream_t st)
     if (g_debug[13]) nsplit = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)(a.B * nsplit)), dim3(512), lds, st, a, S, nsplit);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+template <int ENV>
+int launch_env_t(const DecArgs& a, int S, int C, hipStream_t st)
+{
+    if (a.M <= 32) return C == 5 ? launch_t<2, 5, ENV>(a, S, st) : C == 6 ? launch_t<2, 6, ENV>(a, S, st) : launch_t<2, 0, ENV>(a, S, st);
+    if (a.M <= 64) return C == 13 ? launch_t<4, 13, ENV>(a, S, st) : launch_t<4, 0, ENV>(a, S, st);
+    return C == 25 ? launch_t<7, 25, ENV>(a, S, st) : C == 26 ? launch_t<7, 26, ENV>(a, S, st) : launch_t<7, 0, ENV>(a, S, st);
 }
 
 }  // namespace
@@ -495,19 +590,24 @@ extern "C" __attribute__((visibility("default"))) int eamrl_debug_read_ms_stamps
 
 bool rollout_ms_mfma_supports(int env, const DecArgs& a)
 {
-    if (env != EAMRL_ENV_TSP || a.E != ME || a.H != MH || a.M < 2 || a.M > 112 || a.ld % 4 != 0) return false;
+    if ((env != EAMRL_ENV_TSP && env != EAMRL_ENV_CVRP) || a.E != ME || a.H != MH || a.M < 2 || a.M > 112 || a.ld % 4 != 0) return false;
+    if (env == EAMRL_ENV_CVRP && (g_debug[14] || !a.visited || !a.used || !a.vcap || !a.demand)) return false;
     if (a.R % a.B != 0) return false;
     const int64_t S = a.R / a.B;
     return S >= 2 && S <= SMAX && a.top_k == 0 && !(a.top_p > 0.0f && a.top_p < 1.0f);
 }
 
-int launch_rollout_ms_mfma(const DecArgs& a, hipStream_t st)
+int launch_rollout_ms_mfma(int env, const DecArgs& a, hipStream_t st)
 {
     const int S = (int)(a.R / a.B);
     const int C = (a.M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
-    if (a.M <= 32) return C == 5 ? launch_t<2, 5>(a, S, st) : launch_t<2, 0>(a, S, st);
-    if (a.M <= 64) return C == 13 ? launch_t<4, 13>(a, S, st) : launch_t<4, 0>(a, S, st);
-    return C == 25 ? launch_t<7, 25>(a, S, st) : C == 26 ? launch_t<7, 26>(a, S, st) : launch_t<7, 0>(a, S, st);
+    if (env == EAMRL_ENV_CVRP) {
+        const int rc = launch_env_t<EAMRL_ENV_CVRP>(a, S, C, st);
+        if (rc) return rc;
+        launch_rollout_pad(env, a, st);          // rows that finished early end at the depot with an empty vehicle
+        return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+    }
+    return launch_env_t<EAMRL_ENV_TSP>(a, S, C, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

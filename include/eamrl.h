@@ -65,7 +65,8 @@ const char* eamrl_last_error(void);
  * key 10: 1 = eamrl_linear configures its epilogue at run time even where a compile-time variant applies.
  * key 6: 1 = eamrl_am_rollout does not use the start-sharing kernel for multistart batches (R = S*B rows).
  * key 11: 1 = eamrl_am_rollout does not use the MFMA start-sharing kernel (TSP multistart) but the VALU ones.
- * key 13: 1 = the MFMA start-sharing kernel never splits an instance's starts over several workgroups (small batches). */
+ * key 13: 1 = the MFMA start-sharing kernel never splits an instance's starts over several workgroups (small batches).
+ * key 14: 1 = CVRP multistart batches use the VALU start-sharing kernel, not the MFMA one. */
 int eamrl_debug_set(int key, int value);
 
 /* ---- environment state machines ---------------------------------------------------------------- */

@@ -743,3 +743,42 @@ def test_full_size_pomo_1024x100_mfma_kernel_equals_valu_kernel():
     acts = a["actions"]
     assert (acts.sort(1).values == torch.arange(N, device=DEV)).all()
     assert (acts[:, 0] == torch.arange(S, device=DEV).repeat_interleave(B)).all()
+
+
+def test_full_size_pomo_cvrp_256x100_mfma_kernel_equals_valu_kernel():
+    """POMO on CVRP-100 (256 instances x 100 starts, multistart sampling, episodes of different lengths): the MFMA
+    start-sharing kernel with its in-kernel CVRP state machine and in-place noise against the register-resident VALU kernel
+    fed the tensor of the same draws -- bit-identical tours, log-probs, rewards and final env state -- plus feasibility."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import _lib, ops
+    from eam_rl4co_amd.policy import _max_decode_steps
+
+    N, B, S = 100, 256, 100
+    pol = make_policy("am_cvrp")
+    env = ea.get_env("cvrp", generator_params=dict(num_loc=N), seed=4321)
+    td = env.reset(batch_size=[B]).to(DEV)
+    torch.manual_seed(77)
+    a = pol(td.clone(), env, phase="train", decode_type="multistart_sampling", num_starts=S, return_sum_log_likelihood=False)
+    td_a = pol._last_td
+    torch.manual_seed(77)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    noise = ops.exp1_noise(seed, B * S, _max_decode_steps("cvrp", N + 1, 1), N + 1, DEV)
+    _lib.load().eamrl_debug_set(14, 1)
+    try:
+        b = pol(td.clone(), env, phase="train", decode_type="multistart_sampling", num_starts=S, noise=noise,
+                return_sum_log_likelihood=False)
+    finally:
+        _lib.load().eamrl_debug_set(14, 0)
+    td_b = pol._last_td
+    del noise
+    assert torch.equal(a["actions"], b["actions"]), "tours differ between the MFMA and the VALU kernel"
+    assert torch.equal(a["log_likelihood"].view(torch.int32), b["log_likelihood"].view(torch.int32)), "log-probs differ"
+    assert torch.equal(a["reward"], b["reward"])
+    for k in ("action_mask", "visited", "used_capacity", "current_node", "done"):
+        assert torch.equal(td_a[k], td_b[k]), k
+    acts = a["actions"]
+    assert (acts[:, 0] == (torch.arange(S, device=DEV).repeat_interleave(B) % N) + 1).all()
+    env.check_solution_validity(ea.batchify(td, S), acts)
+    lens = (acts != 0).sum(1)
+    assert (lens == N).all() and acts.shape[1] > N          # every customer once, depot returns in between
+

@@ -126,7 +126,7 @@ def bench_train(iters):
             parts["forward (rollout + EA + re-evaluation)"] = parts.get("forward (rollout + EA + re-evaluation)", 0) + t1 - t0
             parts["backward + Adam"] = parts.get("backward + Adam", 0) + t2 - t1
 
-        for _ in range(2):
+        for _ in range(4):          # the first steps pay one-time costs (library tuning of the new shapes, Adam state)
             step()
         parts.clear()
         n = max(3, iters // 4)
