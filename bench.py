@@ -56,6 +56,8 @@ WORKLOADS = {
     # configs[3], per-GPU share: POMO policy (6 layers, instance norm, no graph context), num_starts = num_loc
     "pomo100": ("tsp", 100, 1024, "multistart_sampling", "rollout"),
     "pomo100_train": ("tsp", 100, 1024, "multistart_sampling", "train"),   # configs[3]: the whole REINFORCE step
+    "pomo_cvrp100": ("cvrp", 100, 1024, "multistart_sampling", "rollout"),  # the fork's other POMO setting (CVRP-100 x 100 starts)
+    "pomo_cvrp100_train": ("cvrp", 100, 1024, "multistart_sampling", "train"),
     "pomo20_train": ("tsp", 20, 64, "multistart_sampling", "train"),       # small rehearsal of the same step
     # no GPU work at all: the launcher, the rendezvous and the collective half of the training step (flat all-reduce ->
     # clip -> Adam on synthetic per-rank gradients) -- what the CPU (gloo) tests drive
