@@ -806,20 +806,33 @@ __global__ __launch_bounds__(EB) void k_rollout_finish(int env, const float* loc
     for (int n = with_depot + lane; n <= top; n += 64)
         if (!((seen[n >> 5] >> (n & 31)) & 1u)) bad_lane = 1;
     const bool invalid = __ballot(bad_lane != 0) != 0ull;
-    if (lane != 0) return;
-    if (invalid) { atomicAdd(&bad[0], 1); return; }
+    if (invalid) {
+        if (lane == 0) atomicAdd(&bad[0], 1);
+        return;
+    }
     if (with_depot) {
+        // running load, depot resets it (cvrp/env.py:172-185): strictly sequential over the steps; the 64 load changes of
+        // a block are fetched by the lanes at once and consumed in step order through v_readlane (every lane the same chain)
         const float cap = vcap[r], lim = cap + 1e-5f;
         const float* dem = demand + (r % B) * N;
         float usedc = 0.0f;
         int over = 0;
-        for (int t = 0; t < T; ++t) {
-            const int64_t a = act[t];
-            usedc = usedc + ((a == 0) ? -cap : dem[a - 1]);
-            if (usedc < 0.0f) usedc = 0.0f;
-            if (usedc > lim) over = 1;
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            float delta = 0.0f;
+            if (t0 + lane < T) {
+                const int64_t a = act[t0 + lane];
+                delta = (a == 0) ? -cap : dem[a - 1];
+            }
+            const int tn = T - t0 < 64 ? T - t0 : 64;
+#pragma unroll
+            for (int t = 0; t < 64; ++t)
+                if (t < tn) {
+                    usedc = usedc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, delta), t));
+                    if (usedc < 0.0f) usedc = 0.0f;
+                    if (usedc > lim) over = 1;
+                }
         }
-        if (over) atomicAdd(&bad[1], 1);
+        if (over && lane == 0) atomicAdd(&bad[1], 1);
     }
 }
 

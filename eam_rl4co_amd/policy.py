@@ -1155,20 +1155,35 @@ class GraphedRollout:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self._pending = policy._enqueue(self.static_td, env, **self.kw)     # works on copies of the state tensors
+        self._tensors = list(policy.parameters()) + list(policy.buffers())
+        self._sig = None                                                        # first call: look at everything
+
+    def _weights_signature(self):
+        """(sum of in-place version counters, sum of storage addresses) over parameters and buffers: changes with every
+        optimizer step / load_state_dict / replaced tensor."""
+        v = a = 0
+        for t in self._tensors:
+            v += t._version
+            a += t.data_ptr()
+        return v, a
 
     @torch.no_grad()
     def __call__(self, td) -> dict:
         if self.policy.training != self._training:
             raise RuntimeError("GraphedRollout: policy.train() / .eval() changed since capture (different launches)")
         # weight-derived constants live in persistent buffers that the graph reads: refresh them in place when a
-        # parameter changed (optimizer step, load_state_dict); everything else the graph reads are the live parameters
-        self.policy.decoder._weight_constants()
-        if hasattr(self.policy.decoder, "_fused_cache_spec") and getattr(self.policy.decoder, "_fc", None) is not None:
-            M = self._embed_probe.shape[1]
-            self.policy.decoder._fused_cache_spec(0, M, self._embed_probe.device)     # re-packs in place when weights changed
-        net = getattr(self.policy.encoder, "net", None)
-        if hasattr(net, "_fused_layers"):
-            net._fused_layers(self._embed_probe)          # re-packs changed encoder weights into the buffers the graph reads
+        # parameter changed (optimizer step, load_state_dict); everything else the graph reads are the live parameters.
+        # One pass over the version counters decides whether anything has to be looked at.
+        sig = self._weights_signature()
+        if sig != self._sig:
+            self._sig = sig
+            self.policy.decoder._weight_constants()
+            if hasattr(self.policy.decoder, "_fused_cache_spec") and getattr(self.policy.decoder, "_fc", None) is not None:
+                M = self._embed_probe.shape[1]
+                self.policy.decoder._fused_cache_spec(0, M, self._embed_probe.device)     # re-packs in place when weights changed
+            net = getattr(self.policy.encoder, "net", None)
+            if hasattr(net, "_fused_layers"):
+                net._fused_layers(self._embed_probe)          # re-packs changed encoder weights into the buffers the graph reads
         pairs = []
         for k in self._keys:
             src = td[k]
