@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
-timeout -k 10 400 python bench.py --workload pomo100_train --steps 5 --warmup 1 > $OUT/bench_pomo100_train.json 2> $OUT/bench_pomo100_train.err || echo "train bench failed"
+timeout -k 10 400 python bench.py --workload pomo100_train --steps 5 --warmup 3 > $OUT/bench_pomo100_train.json 2> $OUT/bench_pomo100_train.err || echo "train bench failed"
 timeout -k 10 300 python tools/kernel_bench.py train > $OUT/eam_steps.log 2>&1 || echo "eam step bench failed"
 tail -4 $OUT/eam_steps.log
 cd /tmp && export TMPDIR=/tmp

@@ -12,6 +12,7 @@ cd $R
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "exit=$?" >> $OUT/pytest_gpu.log
 tail -3 $OUT/pytest_gpu.log
 grep -q "exit=0" $OUT/pytest_gpu.log || exit 1
+timeout -k 10 120 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1 || exit 1
 timeout -k 10 400 python bench.py --steps 20 --warmup 3 > $OUT/bench_tsp100.json 2> $OUT/bench_tsp100.err || exit 1
 for w in tsp20 cvrp100 cvrp500 pomo100 sdvrp100 pctsp100 op100 cvrptw100; do
   timeout -k 10 400 python bench.py --workload $w --steps 10 --warmup 2 > $OUT/bench_$w.json 2> $OUT/bench_$w.err || echo "bench $w failed"

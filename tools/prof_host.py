@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import eam_rl4co_amd as ea  # noqa: E402
 from eam_rl4co_amd.policy import GraphedRollout  # noqa: E402
 
-N, B = 100, 1024
+N, B = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (100, 1024)
 env = ea.get_env("tsp", generator_params=dict(num_loc=N))
 pol = ea.AttentionModelPolicy(env_name="tsp").eval().to("cuda")
 td = env.reset(batch_size=[B]).to("cuda")
