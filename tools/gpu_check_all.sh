@@ -2,7 +2,7 @@
 # full GPU suite + the headline benches (after a change on the common rollout path)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/c10; mkdir -p $OUT
+OUT=$R/gpurun_out/check_all; mkdir -p $OUT
 cd $R
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"
 tail -5 $OUT/pytest_gpu.log
@@ -13,5 +13,5 @@ done
 python - <<PY
 import json
 for w in ("tsp100","tsp20","cvrp100","pomo100"):
-    d=json.load(open("gpurun_out/c10/%s.json"%w)); print(w, "ms/step", d["ms_per_step"], "value", round(d["value"]/1e6,2), "M/s  shares", d["roofline"].get("share_of_step"))
+    d=json.load(open("gpurun_out/check_all/%s.json"%w)); print(w, "ms/step", d["ms_per_step"], "value", round(d["value"]/1e6,2), "M/s  shares", d["roofline"].get("share_of_step"))
 PY

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/c14; mkdir -p $OUT
+OUT=$R/gpurun_out/check_ms; mkdir -p $OUT
 cd $R
 timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "start or multistart or pomo or seeded or eam or train or reeval or reinforce" > $OUT/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -4 $OUT/pytest.log
 [ $rc -eq 0 ] || exit 1
