@@ -98,6 +98,8 @@ PROTOTYPES = {
     "eamrl_sum_logp": [_vp, _i64, _vp, _i64, _i32, _vp],
     "eamrl_rollout_finish": [_i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "eamrl_multi_copy": [_i32, _vp, _vp, _vp, _vp],
+    "eamrl_instance_norm_forward": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp],
+    "eamrl_instance_norm_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "eamrl_replay_states": [_i32, C.POINTER(State), _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp],
     "eamrl_check_solution": [_i32, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp],
     "eamrl_beam_topk": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp],

@@ -356,6 +356,27 @@ __attribute__((visibility("default"))) int eamrl_tsp_mask_bits(const int64_t* ac
     return launched(launch_tsp_mask_bits(actions, bits, R, M, T, (hipStream_t)stream), "eamrl_tsp_mask_bits");
 }
 
+__attribute__((visibility("default"))) int eamrl_instance_norm_forward(const float* x, float* y, float* mean, float* rstd, int64_t B,
+                                                                      int N, int E, const float* gamma, const float* beta,
+                                                                      float eps, void* stream)
+{
+    REQUIRE(x && y && mean && rstd && B >= 0 && N > 0 && E > 0, "eamrl_instance_norm_forward");
+    if (B == 0) return 0;
+    return launched(launch_instnorm_train_fwd(x, y, mean, rstd, B, N, E, gamma, beta, eps, (hipStream_t)stream),
+                    "eamrl_instance_norm_forward");
+}
+
+__attribute__((visibility("default"))) int eamrl_instance_norm_backward(const float* x, const float* dy, const float* mean,
+                                                                       const float* rstd, const float* gamma, float* dx,
+                                                                       float* dgamma, float* dbeta, int64_t B, int N, int E,
+                                                                       void* stream)
+{
+    REQUIRE(x && dy && mean && rstd && dx && B >= 0 && N > 0 && E > 0, "eamrl_instance_norm_backward");
+    if (B == 0) return 0;
+    return launched(launch_instnorm_train_bwd(x, dy, mean, rstd, gamma, dx, dgamma, dbeta, B, N, E, (hipStream_t)stream),
+                    "eamrl_instance_norm_backward");
+}
+
 __attribute__((visibility("default"))) int eamrl_mean_nodes(const float* emb, float* out, int64_t B, int M, int E,
                                                            void* stream)
 {

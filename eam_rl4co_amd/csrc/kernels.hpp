@@ -30,6 +30,10 @@ int launch_mha_mfma(const float* qkv, float* out, int64_t B, int N, int E, int H
 bool mha_mfma_supports(int64_t B, int N, int E, int H, const float* qkv, const float* out);
 int launch_normalize(float* x, int64_t B, int N, int E, int kind, const float* gamma, const float* beta,
                      const float* mean, const float* var, float eps, hipStream_t st);
+int launch_instnorm_train_fwd(const float* x, float* y, float* mean, float* rstd, int64_t B, int N, int E, const float* gamma,
+                              const float* beta, float eps, hipStream_t st);
+int launch_instnorm_train_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, float* dx,
+                              float* dgamma, float* dbeta, int64_t B, int N, int E, hipStream_t st);
 int launch_batchnorm_train(float* x, int64_t rows, int E, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float momentum, float eps, float* save_mean, float* save_var, float* ws,
                            hipStream_t st);

@@ -141,6 +141,33 @@ def normalize_(x, kind, gamma, beta, mean=None, var=None, eps=1e-5):
     return x
 
 
+def instance_norm_forward(x, gamma, beta, eps):
+    """-> (y, mean, rstd): InstanceNorm1d(affine) over the nodes of x [B, N, E], kept statistics [B, E] for the backward."""
+    lib = _lib.load()
+    _chk(x, "x", torch.float32)
+    B, N, E = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(B, E, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, E, dtype=torch.float32, device=x.device)
+    _lib.check(lib.eamrl_instance_norm_forward(_ptr(x), _ptr(y), _ptr(mean), _ptr(rstd), B, N, E, _ptr(gamma), _ptr(beta),
+                                               float(eps), _stream(x)), "eamrl_instance_norm_forward")
+    return y, mean, rstd
+
+
+def instance_norm_backward(x, dy, mean, rstd, gamma, need_affine_grads=True):
+    """-> (dx, dgamma | None, dbeta | None)"""
+    lib = _lib.load()
+    _chk(x, "x", torch.float32)
+    _chk(dy, "dy", torch.float32, tuple(x.shape))
+    B, N, E = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.zeros(E, dtype=torch.float32, device=x.device) if need_affine_grads else None
+    db = torch.zeros(E, dtype=torch.float32, device=x.device) if need_affine_grads else None
+    _lib.check(lib.eamrl_instance_norm_backward(_ptr(x), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dg),
+                                                _ptr(db), B, N, E, _stream(x)), "eamrl_instance_norm_backward")
+    return dx, dg, db
+
+
 def batchnorm_train_(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     """BatchNorm1d with batch statistics over all rows of x [..., E], in place; running stats updated as torch does.
     -> (x, batch_mean [E], batch_var [E] (biased))."""

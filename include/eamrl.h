@@ -158,6 +158,15 @@ int eamrl_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int
 int eamrl_normalize(float* x, int64_t B, int N, int E, int kind, const float* gamma, const float* beta,
                     const float* mean, const float* var, float eps, void* stream);
 
+/* InstanceNorm1d(affine) of Normalization("instance") for the TRAINING graph  [nn/ops.py:32-56 as differentiated by
+ * reinforce.py:103-106]: forward y = (x - mean) rstd gamma + beta on x, y [B][N][E] (out of place), keeping mean / rstd
+ * [B][E]; backward dx [B][N][E] and dgamma / dbeta [E] (ACCUMULATED, may be NULL).  Plain fp32 (the rollout's own
+ * normalisation is eamrl_normalize); within 1e-6 of torch.nn.functional.instance_norm and its autograd. */
+int eamrl_instance_norm_forward(const float* x, float* y, float* mean, float* rstd, int64_t B, int N, int E, const float* gamma,
+                                const float* beta, float eps, void* stream);
+int eamrl_instance_norm_backward(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                                 float* dx, float* dgamma, float* dbeta, int64_t B, int N, int E, void* stream);
+
 /* Normalization(batch) with BATCH statistics, in place on x [rows][E] -- BatchNorm1d in training mode, what the
  * reference's encoder runs under policy.train()  [nn/ops.py:45-47, SURVEY Appendix A9].  Mean and biased variance per
  * channel in a defined order (chunks of 128 rows summed sequentially, chunk sums ascending; variance = mean of

@@ -105,6 +105,31 @@ def test_reference_trainer_step_runs_on_the_policy_and_matches_reference_gradien
                                        err_msg=str(k))
 
 
+@pytest.mark.parametrize("B,N,E", [(1, 5, 128), (3, 20, 128), (64, 100, 128), (5, 101, 64), (2, 7, 200)])
+def test_instance_norm_training_kernels_match_torch(B, N, E):
+    """eamrl_instance_norm_forward / _backward (the normalisation of the differentiable POMO encoder) against
+    torch.nn.functional.instance_norm and its autograd: values, input gradient, affine gradients."""
+    import torch.nn.functional as F
+    from eam_rl4co_amd.train import _InstanceNormFn
+
+    torch.manual_seed(B * 100 + N)
+    x = (torch.randn(B, N, E, device=DEV) * 2 + 0.5).requires_grad_()
+    g = (torch.rand(E, device=DEV) + 0.5).requires_grad_()
+    b = torch.randn(E, device=DEV).requires_grad_()
+    w = torch.randn(B, N, E, device=DEV)
+    y = _InstanceNormFn.apply(x, g, b, 1e-5)
+    (y * w).sum().backward()
+    got = (y.detach(), x.grad.clone(), g.grad.clone(), b.grad.clone())
+    for t_ in (x, g, b):
+        t_.grad = None
+    yr = F.instance_norm(x.permute(0, 2, 1), weight=g, bias=b, eps=1e-5).permute(0, 2, 1)
+    (yr * w).sum().backward()
+    ref = (yr.detach(), x.grad, g.grad, b.grad)
+    for a_, r_, nm in zip(got, ref, ("y", "dx", "dgamma", "dbeta")):
+        scale = max(float(r_.abs().max()), 1e-6)
+        assert float((a_ - r_).abs().max()) <= 2e-5 * scale + 1e-6, nm
+
+
 @pytest.mark.parametrize("env_name,N,B,ns", [("cvrp", 20, 7, 0), ("cvrp", 100, 3, 6), ("cvrp", 127, 2, 0), ("cvrptw", 20, 5, 0),
                                              ("cvrptw", 50, 2, 4), ("pctsp", 20, 6, 0), ("pctsp", 100, 2, 5), ("op", 20, 6, 0),
                                              ("op", 100, 3, 4)])
