@@ -511,7 +511,7 @@ def main():
             line["strong_scaling"] = strong
         if identical is not None:
             line["params_identical"] = identical
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # a reported baseline of the 1-GPU run only (the other ranks would wait)
             line["cpu_baseline"] = cpu_baseline(env_name, num_loc, decode_type, num_starts=S if S > 1 else 0, pomo=pomo)
             if train:
                 line["cpu_baseline"]["sample"] += " -- rollout part only (the oracle has no backward)"
