@@ -479,6 +479,26 @@ int launch_linear(const GemmArgs& g0, hipStream_t st)
 // ---------------------------------------------------------------------------------------------------
 // encoder self-attention: block = (instance, head); thread = query row
 // ---------------------------------------------------------------------------------------------------
+// The softmax denominator of the encoder attention (canonical order): four interleaved partial sums, P_g = sequential sum of
+// the weights of the keys j = g (mod 4) in ascending order, combined as Z = (P0 + P1) + (P2 + P3).  (That is the order the
+// fused encoder gets for free from its 16x16x4 score tiles, where a lane holds the keys of one residue class; a plain
+// sequential Z would cost it a third of the attention's MFMA issue slots.)  Loops over the keys keep the four sums in a
+// rotating register window: the front one receives key j and goes to the back, so after N keys the front holds class N & 3.
+template <typename T>
+struct ZRot {
+    T a, b, c, d;
+    __device__ __forceinline__ void add(T w) { const T t = a + w; a = b; b = c; c = d; d = t; }
+    __device__ __forceinline__ T total(int N) const
+    {
+        const int r = N & 3;      // a: class r, b: r + 1, c: r + 2, d: r + 3  (mod 4)
+        const T p0 = r == 0 ? a : r == 1 ? d : r == 2 ? c : b;
+        const T p1 = r == 0 ? b : r == 1 ? a : r == 2 ? d : c;
+        const T p2 = r == 0 ? c : r == 1 ? b : r == 2 ? a : d;
+        const T p3 = r == 0 ? d : r == 1 ? c : r == 2 ? b : a;
+        return (p0 + p1) + (p2 + p3);
+    }
+};
+
 template <int D>
 __global__ __launch_bounds__(128) void k_mha_encoder(const float* qkv, float* out, int N, int E, int H)
 {
@@ -506,7 +526,7 @@ __global__ __launch_bounds__(128) void k_mha_encoder(const float* qkv, float* ou
             for (int d = 0; d < D; ++d) acc = fma_(q[d], ks[j * D + d], acc);
             m = __builtin_fmaxf(m, acc * scale);
         }
-        float Z = 0.0f;
+        ZRot<float> zr{0.0f, 0.0f, 0.0f, 0.0f};
         float o[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) o[d] = 0.0f;
@@ -515,10 +535,11 @@ __global__ __launch_bounds__(128) void k_mha_encoder(const float* qkv, float* ou
 #pragma unroll
             for (int d = 0; d < D; ++d) acc = fma_(q[d], ks[j * D + d], acc);
             const float w = d_expf(acc * scale - m);
-            Z = Z + w;
+            zr.add(w);
 #pragma unroll
             for (int d = 0; d < D; ++d) o[d] = fma_(w, vs[j * D + d], o[d]);
         }
+        const float Z = zr.total(N);
         float* op = out + (b * N + i) * (int64_t)E + h * D;
 #pragma unroll
         for (int d = 0; d < D; ++d) op[d] = o[d] / Z;
@@ -581,7 +602,8 @@ __global__ __launch_bounds__(256) void k_mha_encoder_x2(const float* __restrict_
         m2.x = __builtin_fmaxf(m2.x, a2.x);
         m2.y = __builtin_fmaxf(m2.y, a2.y);
     }
-    f32x2 Z2 = splat2(0.0f), o2[D];
+    ZRot<f32x2> zr{splat2(0.0f), splat2(0.0f), splat2(0.0f), splat2(0.0f)};
+    f32x2 o2[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) o2[d] = splat2(0.0f);
     for (int j = 0; j < N; ++j) {
@@ -595,7 +617,7 @@ __global__ __launch_bounds__(256) void k_mha_encoder_x2(const float* __restrict_
             a2 = pk_fma(q2[d + 3], splat2(kk.w), a2);
         }
         const f32x2 w2 = d_expf2_nonpos(a2 - m2);
-        Z2 = Z2 + w2;
+        zr.add(w2);
 #pragma unroll
         for (int d = 0; d < D; d += 4) {
             const float4 vv = *reinterpret_cast<const float4*>(vh + j * W + d);
@@ -608,6 +630,7 @@ __global__ __launch_bounds__(256) void k_mha_encoder_x2(const float* __restrict_
     float o0[D], o1[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) { o0[d] = o2[d].x; o1[d] = o2[d].y; }
+    const f32x2 Z2 = zr.total(N);
     const float Z0 = Z2.x, Z1 = Z2.y;
     float* op0 = out + (b * N + i0) * (int64_t)E + (h0 + hh) * D;
 #pragma unroll
@@ -681,7 +704,8 @@ __global__ __launch_bounds__(256) void k_mha_encoder_tiled(const float* __restri
             m2.y = __builtin_fmaxf(m2.y, a2.y);
         }
     }
-    f32x2 Z2 = splat2(0.0f), o2[D];
+    ZRot<f32x2> zr{splat2(0.0f), splat2(0.0f), splat2(0.0f), splat2(0.0f)};
+    f32x2 o2[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) o2[d] = splat2(0.0f);
     for (int j0 = 0; j0 < N; j0 += MHA_TK) {
@@ -705,7 +729,7 @@ __global__ __launch_bounds__(256) void k_mha_encoder_tiled(const float* __restri
                 a2 = pk_fma(q2[d + 3], splat2(kk.w), a2);
             }
             const f32x2 w2 = d_expf2_nonpos(a2 - m2);
-            Z2 = Z2 + w2;
+            zr.add(w2);
 #pragma unroll
             for (int d = 0; d < D; d += 4) {
                 const float4 vv = *reinterpret_cast<const float4*>(vh + j * W + d);
@@ -716,6 +740,7 @@ __global__ __launch_bounds__(256) void k_mha_encoder_tiled(const float* __restri
             }
         }
     }
+    const f32x2 Z2 = zr.total(N);
     if (has0) {
         float* op0 = out + (b * N + i0) * (int64_t)E + (h0 + hh) * D;
 #pragma unroll
@@ -738,8 +763,6 @@ int launch_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, in
     const size_t lds = (size_t)2 * N * D * sizeof(float);
     if (D * H != E || lds > 160 * 1024 || B * H > 0x7fffffffLL) return EAMRL_E_ARG;
     dim3 grid((unsigned)(B * H)), block(128);
-    if (g_debug[7] && mha_mfma_supports(B, N, E, H, qkv, out))      // matrix-core attention: measured slower, opt-in
-        return launch_mha_mfma(qkv, out, B, N, E, H, st);
     // blocked kernel: 4 heads per block, 2 query rows per thread (needs 4 * ceil(N/2) <= 256 threads, aligned rows)
     if (D == 16 && H % 4 == 0 && 2 * (N + 1) <= 256 && !g_debug[3] && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0) {
         const size_t lds2 = (size_t)2 * N * 64 * sizeof(float);

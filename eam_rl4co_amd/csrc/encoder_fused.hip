@@ -367,17 +367,25 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
                         const f32x2 e23 = d_expf2_nonpos((f32x2){s[kt][2] - m, s[kt][3] - m});
                         s[kt] = (f32x4){e01.x, e01.y, e23.x, e23.y};
                     }
-                    f32x4 o = splat4(0.0f), z = splat4(0.0f);
+                    // Z (canonical order, encoder.hip ZRot): this lane holds the keys 4 r + G of every tile, i.e. one residue class
+                    // mod 4 in ascending order -> its partial sum P_G in 4 RTT - 1 adds, then (P0 + P1) + (P2 + P3) over the lane groups
+                    float zp = s[0][0];
+#pragma unroll
+                    for (int t = 1; t < 4 * RTT; ++t) zp = zp + s[t >> 2][t & 3];
+                    {
+                        auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(zp), __float_as_uint(zp), false, false);
+                        zp = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+                        auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(zp), __float_as_uint(zp), false, false);
+                        zp = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+                    }
+                    f32x4 o = splat4(0.0f);
 #pragma unroll
                     for (int t = 0; t < 4 * RTT; ++t)
-                        if (t < NT) {
-                            o = mfma4(vf[t], s[t >> 2][t & 3], o);
-                            z = mfma4(1.0f, s[t >> 2][t & 3], z);
-                        }
+                        if (t < NT) o = mfma4(vf[t], s[t >> 2][t & 3], o);
                     // o: lane (query j, G), reg r -> head column e = 4 G + r -> A layout (g = r, t = 4 cw + G); overwrites q
                     float* op = QA + qrow * SQ + 4 * cw + G;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) op[r * 16] = o[r] / z[r];
+                    for (int r = 0; r < 4; ++r) op[r * 16] = o[r] / zp;
                 }
             }
             ESTAMP(3);

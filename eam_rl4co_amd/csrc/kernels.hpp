@@ -26,8 +26,6 @@ int launch_ea_prize(int env, const float* locs, const float* prize, const float*
                     int S, int N, int L, int G, double mutation_rate, double crossover_rate, double selection_rate, int top_k,
                     const double* init_mut_rand, const double* init_mut_u, const double* cross_rand, const double* cross_u,
                     const double* mut_rand, const double* mut_u, hipStream_t st);
-int launch_mha_mfma(const float* qkv, float* out, int64_t B, int N, int E, int H, hipStream_t st);
-bool mha_mfma_supports(int64_t B, int N, int E, int H, const float* qkv, const float* out);
 int launch_normalize(float* x, int64_t B, int N, int E, int kind, const float* gamma, const float* beta,
                      const float* mean, const float* var, float eps, hipStream_t st);
 int launch_instnorm_train_fwd(const float* x, float* y, float* mean, float* rstd, int64_t B, int N, int E, const float* gamma,

@@ -61,7 +61,6 @@ const char* eamrl_last_error(void);
  * key 1: 1 = eamrl_am_rollout always uses the streaming kernel (never the register-resident one).
  * key 4: 1 = eamrl_linear uses 128-row tiles instead of 64-row tiles.
  * key 3: 1 = eamrl_mha_encoder uses the one-row-per-thread kernel even where the blocked one applies.
- * key 7: 1 = eamrl_mha_encoder uses the matrix-core kernel (N <= 128; bit-identical, measured slower) instead of the VALU kernels.
  * key 10: 1 = eamrl_linear configures its epilogue at run time even where a compile-time variant applies.
  * key 6: 1 = eamrl_am_rollout does not use the start-sharing kernel for multistart batches (R = S*B rows).
  * key 11: 1 = eamrl_am_rollout does not use the MFMA start-sharing kernel (TSP multistart) but the VALU ones.

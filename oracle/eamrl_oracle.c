@@ -246,7 +246,8 @@ ORC_API void orc_matmul_right(const float* x, const float* Wt, float* y, long ro
 }
 
 /* Encoder self-attention on packed qkv [B][N][3E] ("b s (three h d)"), no mask.
- * s = chain_d(q,k)*scale ; w = exp(s-max) ; Z sequential ; o = chain_j(w, v) / Z. */
+ * s = chain_d(q,k)*scale ; w = exp(s-max) ; Z = (P0 + P1) + (P2 + P3), Pg = sequential sum of w[j], j = g mod 4 ;
+ * o = chain_j(w, v) / Z. */
 ORC_API void orc_mha_encoder(const float* qkv, float* out, long B, int N, int E, int H)
 {
     const int D = E / H;
@@ -267,8 +268,11 @@ ORC_API void orc_mha_encoder(const float* qkv, float* out, long B, int N, int E,
                     s[j] = acc;
                     if (acc > m) m = acc;
                 }
-                float Z = 0.0f;
-                for (int j = 0; j < N; ++j) { s[j] = d_expf(s[j] - m); Z = Z + s[j]; }
+                /* Z: four interleaved partial sums (keys j = g mod 4, ascending) combined as (P0 + P1) + (P2 + P3) -- the
+                 * order a 16x16x4 MFMA score tile gives for free: a lane holds the keys of one residue class */
+                float P[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (int j = 0; j < N; ++j) { s[j] = d_expf(s[j] - m); P[j & 3] = P[j & 3] + s[j]; }
+                const float Z = (P[0] + P[1]) + (P[2] + P[3]);
                 for (int d = 0; d < D; ++d) {
                     float acc = 0.0f;
                     for (int j = 0; j < N; ++j)

@@ -8,7 +8,7 @@ NAME=$1; shift
 D=tools/_variants/$NAME
 mkdir -p $D
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden $*"
-for f in abi decode_step rollout_resident env_reward encoder mha_mfma evolution; do
+for f in abi decode_step rollout_resident env_reward encoder evolution; do
   if [ "$f" = decode_step ] || [ ! -f eam_rl4co_amd/lib/obj/$f.o ]; then
     /opt/rocm/bin/hipcc $FLAGS -c eam_rl4co_amd/csrc/$f.hip -o $D/$f.o &
   else
