@@ -211,7 +211,11 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             const int g = pp / E4, e = 4 * (pp - g * E4), h = e / D;
             const float* wh = l.w + h * M;
             const int n0 = g * C, n1 = min(M, n0 + C);
-            float zg = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            // Z_g in the canonical order: four partial sums by position in the chunk ((n - n0) mod 4; DU4 is a multiple of 4, so slot u
+            // of a trip is class u & 3: four independent add chains), combined as (P0 + P1) + (P2 + P3)
+            static_assert(DU4 % 4 == 0, "DU4");
+            float zc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             for (int nb = n0; nb < n1; nb += DU4) {
                 float4 vv[DU4];
                 float ww[DU4];
@@ -224,7 +228,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
                 }
 #pragma unroll
                 for (int u = 0; u < DU4; ++u) {
-                    zg = zg + ww[u];
+                    zc[u & 3] = zc[u & 3] + ww[u];        // (slots beyond n1 and masked nodes add 0)
                     a0 = fma_(ww[u], vv[u].x, a0);
                     a1 = fma_(ww[u], vv[u].y, a1);
                     a2 = fma_(ww[u], vv[u].z, a2);
@@ -233,7 +237,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
             }
             float* pa = l.partA + g * E + e;      // (partA is only 4-byte aligned for odd M)
             pa[0] = a0; pa[1] = a1; pa[2] = a2; pa[3] = a3;
-            if (e - h * D == 0) l.partZ[g * H + h] = zg;
+            if (e - h * D == 0) l.partZ[g * H + h] = (zc[0] + zc[1]) + (zc[2] + zc[3]);
         }
     }
     __syncthreads();

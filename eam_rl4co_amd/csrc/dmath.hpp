@@ -109,6 +109,32 @@ __device__ __forceinline__ f32x2 d_expf2_nonpos(f32x2 x)
     return res;
 }
 
+// The softmax denominators of the path (canonical order): four interleaved partial sums, P_r = sequential sum of the weights of
+// the nodes n = r (mod 4) in ascending order, combined as (P0 + P1) + (P2 + P3).  (The order a 16x16x4 MFMA score tile holds per
+// lane; a plain sequential sum costs the MFMA kernels a third of their attention issue slots.)  Loops keep the four sums in a
+// rotating window: the front one receives node n and goes to the back; after the nodes up to n1 (exclusive) the front holds
+// class n1 & 3 -- zeros added for padded slots only have to be counted.
+// z[k]: sum over the slots i = k (mod 4) of a run that starts at node `start` -> the canonical total.  Slot class k is node class
+// (start + k) & 3, so the node-class pairs {0,1} {2,3} are the slot pairs {0,1} {2,3} for an even start and {3,0} {1,2} for an odd
+// one -- and a + b == b + a bit for bit, so only the parity of the start matters.
+__device__ __forceinline__ float z_total_rel(float z0, float z1, float z2, float z3, int start)
+{
+    const bool odd = start & 1;
+    return (z0 + (odd ? z3 : z1)) + (z2 + (odd ? z1 : z3));
+}
+
+template <typename T>
+struct ZRot {
+    T a, b, c, d;
+    __device__ __forceinline__ void add(T w) { const T t = a + w; a = b; b = c; c = d; d = t; }
+    __device__ __forceinline__ T total(int n1) const
+    {
+        // a: class n1 & 3, b, c, d the following ones; pairs {0,1} {2,3} = {a,b} {c,d} for an even n1, {d,a} {b,c} for an odd one
+        const bool odd = n1 & 1;
+        return (a + (odd ? d : b)) + (c + (odd ? b : d));
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Counter-based Exp(1) noise for sampling without a noise tensor (the reference draws inside the step: torch.multinomial ==
 // argmax(p / q), q ~ Exp(1), utils/decoding.py:403-417).  Philox4x32-10 on the counter (node / 4, step, row) with the call's

@@ -479,26 +479,7 @@ int launch_linear(const GemmArgs& g0, hipStream_t st)
 // ---------------------------------------------------------------------------------------------------
 // encoder self-attention: block = (instance, head); thread = query row
 // ---------------------------------------------------------------------------------------------------
-// The softmax denominator of the encoder attention (canonical order): four interleaved partial sums, P_g = sequential sum of
-// the weights of the keys j = g (mod 4) in ascending order, combined as Z = (P0 + P1) + (P2 + P3).  (That is the order the
-// fused encoder gets for free from its 16x16x4 score tiles, where a lane holds the keys of one residue class; a plain
-// sequential Z would cost it a third of the attention's MFMA issue slots.)  Loops over the keys keep the four sums in a
-// rotating register window: the front one receives key j and goes to the back, so after N keys the front holds class N & 3.
-template <typename T>
-struct ZRot {
-    T a, b, c, d;
-    __device__ __forceinline__ void add(T w) { const T t = a + w; a = b; b = c; c = d; d = t; }
-    __device__ __forceinline__ T total(int N) const
-    {
-        const int r = N & 3;      // a: class r, b: r + 1, c: r + 2, d: r + 3  (mod 4)
-        const T p0 = r == 0 ? a : r == 1 ? d : r == 2 ? c : b;
-        const T p1 = r == 0 ? b : r == 1 ? a : r == 2 ? d : c;
-        const T p2 = r == 0 ? c : r == 1 ? b : r == 2 ? a : d;
-        const T p3 = r == 0 ? d : r == 1 ? c : r == 2 ? b : a;
-        return (p0 + p1) + (p2 + p3);
-    }
-};
-
+// Z of the attention rows: ZRot (dmath.hpp), the canonical (P0 + P1) + (P2 + P3) order.
 template <int D>
 __global__ __launch_bounds__(128) void k_mha_encoder(const float* qkv, float* out, int N, int E, int H)
 {

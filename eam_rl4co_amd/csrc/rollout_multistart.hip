@@ -9,8 +9,8 @@
 // The arithmetic is the canonical order of DESIGN.md 2, bit for bit what k_rollout_resident / k_decode_step / the oracle
 // compute -- the MFMA accumulates its k dimension as an ordered fma chain, so only the tiling had to be arranged:
 //   scores   s = chain_d(q, K[n]) / 4: q is pre-scaled by the power of two; S^T = K Q^T tiles (lane = query, registers = keys)
-//   glimpse  four node chunks of ceil(M / 4): one accumulator per chunk for A_g = chain_n(w, V) and one (against a row of
-//            ones) for Z_g = sequential sum of w; a k-step that straddles a chunk boundary is issued for both chunks with
+//   glimpse  four node chunks of ceil(M / 4): one accumulator per chunk for A_g = chain_n(w, V); Z_g = (P0 + P1) + (P2 + P3) with
+//            P_r the sequential sum of the weights at the chunk's positions r (mod 4) -- a lane holds exactly one such class; a k-step that straddles a chunk boundary is issued for both chunks with
 //            the other chunk's weights zeroed (fma(0, v, acc) == acc);  heads = (((A0+A1)+A2)+A3) / (((Z0+Z1)+Z2)+Z3)
 //   logits   four column chunks of 32: one accumulator per chunk (8 k-steps each), u = ((c0+c1)+c2)+c3
 //   finish   u / sqrt(E), 10 tanh, mask, / temperature, log-softmax with the lane tree (keys of a tile sit 4 per lane in
@@ -57,6 +57,20 @@ __device__ __forceinline__ float group_sum(float v)
     v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+// Sum over the four lane groups of one chunk's partial sums in the canonical order: lane group G holds the nodes 4 t + G, i.e. the
+// chunk's position class (G - start) & 3, and Z_g = (P0 + P1) + (P2 + P3) over POSITION classes.  Even chunk start: the pairs are
+// the lane groups {G, G ^ 1} (group_sum).  Odd start: {G, G ^ 3} = lanes l and l ^ 48, then the two pair sums (partner l ^ 16).
+// (v_permlane32_swap(x, x): result 0 = x of the lower half in both halves, result 1 = the upper half's; v_permlane16_swap alike per row pair.)
+__device__ __forceinline__ float group_sum_odd(float v, int lane)
+{
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const uint32_t p32 = (lane & 32) ? b[0] : b[1];                      // v of lane l ^ 32
+    auto a = __builtin_amdgcn_permlane16_swap(p32, p32, false, false);
+    const uint32_t p48 = (lane & 16) ? a[0] : a[1];                      // ... of lane l ^ 48
+    const float s = v + __uint_as_float(p48);
+    auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(c[0]) + __uint_as_float(c[1]);
 }
 __device__ __forceinline__ int group_min(int v)
 {
@@ -253,7 +267,8 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 // progress (A_g against V^T, Z_g against a row of ones), `tot` the finished ones as ((A0 + A1) + A2) + A3.
                 // K-step t holds nodes 4 t .. 4 t + 3 (this lane: 4 t + G); where it straddles a chunk boundary it is issued
                 // once per chunk with the other chunk's weights zeroed.
-                f32x4 cur_o = z4(), cur_z = z4(), tot_o = z4(), tot_z = z4();
+                f32x4 cur_o = z4(), tot_o = z4();
+                float cur_z = 0.0f, tot_z = 0.0f;        // Z_g: this lane's nodes are one residue class mod 4 -> P_gG, then the lane groups
                 int curc = 0;
                 bool first = true;
 #pragma unroll
@@ -270,23 +285,27 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                             const int c = cA + sub;
                             if (c <= cB) {                                                // (uniform)
                                 if (c != curc) {                                          // chunk curc is complete
+                                    const float zg = ((curc * C) & 1) ? group_sum_odd(cur_z, lane) : group_sum(cur_z);
                                     tot_o = first ? cur_o : tot_o + cur_o;
-                                    tot_z = first ? cur_z : tot_z + cur_z;
-                                    first = false; curc = c; cur_o = z4(); cur_z = z4();
+                                    tot_z = first ? zg : tot_z + zg;
+                                    first = false; curc = c; cur_o = z4(); cur_z = 0.0f;
                                 }
                                 const float wg = (cme == c) ? w : 0.0f;
                                 cur_o = mf(vtf[t4], wg, cur_o);
-                                cur_z = mf(1.0f, wg, cur_z);
+                                cur_z = cur_z + wg;
                             }
                         }
                     }
                 }
-                tot_o = first ? cur_o : tot_o + cur_o;
-                tot_z = first ? cur_z : tot_z + cur_z;
+                {
+                    const float zg = ((curc * C) & 1) ? group_sum_odd(cur_z, lane) : group_sum(cur_z);
+                    tot_o = first ? cur_o : tot_o + cur_o;
+                    tot_z = first ? zg : tot_z + zg;
+                }
                 // lane (query j, G), register r -> head column e = 4 G + r -> A layout (g = r, t = 4 wv + G)
                 float* hp = HT + j * TS + 4 * wv + G;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hp[r * TG] = tot_o[r] / tot_z[r];
+                for (int r = 0; r < 4; ++r) hp[r * TG] = tot_o[r] / tot_z;
             }
             MSTAMP(4);
             __syncthreads();

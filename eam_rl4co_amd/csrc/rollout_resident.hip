@@ -294,17 +294,24 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const float* wp = l.w + h * WROW + (2 * vg + c) * CP;
-                float zg = 0.0f, ag = 0.0f;
+                float ag = 0.0f;
+                // Z_g in the canonical order: four partial sums by position in the chunk (slot i mod 4: the components of the float4,
+                // four independent add chains), combined as (P0 + P1) + (P2 + P3)
+                // (as two packed adds per float4: the row's spare slots up to CP hold w = 0, so whole float4 can be added)
+                static_assert(((CR + 3) & ~3) <= CP, "the last float4 of a chunk row must lie inside its padded row");
+                f32x2 z01 = splat2(0.0f), z23 = splat2(0.0f);
 #pragma unroll
                 for (int i = 0; i < CR; i += 4) {          // slots >= C hold w = 0 (and are skipped beyond CR)
                     const float4 ww = *reinterpret_cast<const float4*>(wp + i);
-                    zg = zg + ww.x; ag = fma_(ww.x, vreg[c][i], ag);
-                    if (i + 1 < CR) { zg = zg + ww.y; ag = fma_(ww.y, vreg[c][i + 1], ag); }
-                    if (i + 2 < CR) { zg = zg + ww.z; ag = fma_(ww.z, vreg[c][i + 2], ag); }
-                    if (i + 3 < CR) { zg = zg + ww.w; ag = fma_(ww.w, vreg[c][i + 3], ag); }
+                    z01 = z01 + (f32x2){ww.x, ww.y};
+                    z23 = z23 + (f32x2){ww.z, ww.w};
+                    ag = fma_(ww.x, vreg[c][i], ag);
+                    if (i + 1 < CR) ag = fma_(ww.y, vreg[c][i + 1], ag);
+                    if (i + 2 < CR) ag = fma_(ww.z, vreg[c][i + 2], ag);
+                    if (i + 3 < CR) ag = fma_(ww.w, vreg[c][i + 3], ag);
                 }
                 l.partA[(2 * vg + c) * RE + ve] = ag;
-                if ((ve & 15) == 0) l.partZ[(2 * vg + c) * RH + h] = zg;
+                if ((ve & 15) == 0) l.partZ[(2 * vg + c) * RH + h] = (z01.x + z01.y) + (z23.x + z23.y);
             }
         }
         __syncthreads();

@@ -722,8 +722,10 @@ static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, in
         for (int n = 0; n < M; ++n) wh[n] = mask[n] ? d_expf(wh[n] - mx) : 0.0f;
         float Z = 0.0f, Rw = 0.0f;
         for (int g = 0; g < ORC_NCHUNK; ++g) {
-            float zg = 0.0f;
-            for (int n = g * C; n < M && n < (g + 1) * C; ++n) zg = zg + wh[n];
+            /* per chunk: four interleaved partial sums by position in the chunk, (n - g C) mod 4, combined as (P0 + P1) + (P2 + P3) */
+            float P[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int n = g * C; n < M && n < (g + 1) * C; ++n) P[(n - g * C) & 3] = P[(n - g * C) & 3] + wh[n];
+            const float zg = (P[0] + P[1]) + (P[2] + P[3]);
             Z = (g == 0) ? zg : Z + zg;
         }
         if (dv) {                           /* ex[] is free until the log-softmax below */
