@@ -907,24 +907,41 @@ int launch_batchnorm_train(float* x, int64_t rows, int E, const float* gamma, co
 // per call, and MIOpen's spatial batch-norm backward behind it takes 0.49 ms per call at 1024 x 100 x 128).
 // Not parity-critical (the rollout's own normalisation is k_norm_instance): plain fp32, hardware rsqrt-free 1 / sqrt.
 // ---------------------------------------------------------------------------------------------------------------------
+// block = 4 row groups x E channels (E <= 128 here; larger E loops): thread (q, e) takes the rows n = q (mod 4); the four
+// partial sums meet in LDS.  4x the loads in flight of a thread-per-channel loop.
+constexpr int IN_Q = 4;
+
 __global__ void k_instnorm_train_fwd(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mean_out,
                                      float* __restrict__ rstd_out, int N, int E, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float eps)
 {
+    extern __shared__ float red[];                    // [IN_Q][Ep]
+    const int Ep = blockDim.x / IN_Q;
+    const int q = threadIdx.x / Ep, el = threadIdx.x - q * Ep;
     const int64_t b = blockIdx.x;
     const float* xb = x + b * (int64_t)N * E;
     float* yb = y + b * (int64_t)N * E;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    for (int e0 = 0; e0 < E; e0 += Ep) {
+        const int e = e0 + el;
+        const bool on = e < E;
         float s = 0.0f;
-        for (int n = 0; n < N; ++n) s += xb[(int64_t)n * E + e];
-        const float mean = s / (float)N;
+        if (on) for (int n = q; n < N; n += IN_Q) s += xb[(int64_t)n * E + e];
+        red[q * Ep + el] = s;
+        __syncthreads();
+        const float mean = (((red[el] + red[Ep + el]) + red[2 * Ep + el]) + red[3 * Ep + el]) / (float)N;
+        __syncthreads();
         float v = 0.0f;
-        for (int n = 0; n < N; ++n) { const float d = xb[(int64_t)n * E + e] - mean; v = fmaf(d, d, v); }
-        const float rstd = 1.0f / __builtin_sqrtf(v / (float)N + eps);
-        const float g = gamma ? gamma[e] : 1.0f, bt = beta ? beta[e] : 0.0f;
-        for (int n = 0; n < N; ++n) yb[(int64_t)n * E + e] = fmaf((xb[(int64_t)n * E + e] - mean) * rstd, g, bt);
-        mean_out[b * E + e] = mean;
-        rstd_out[b * E + e] = rstd;
+        if (on) for (int n = q; n < N; n += IN_Q) { const float d = xb[(int64_t)n * E + e] - mean; v = fmaf(d, d, v); }
+        red[q * Ep + el] = v;
+        __syncthreads();
+        const float var = (((red[el] + red[Ep + el]) + red[2 * Ep + el]) + red[3 * Ep + el]) / (float)N;
+        __syncthreads();
+        const float rstd = 1.0f / __builtin_sqrtf(var + eps);
+        if (on) {
+            const float g = gamma ? gamma[e] : 1.0f, bt = beta ? beta[e] : 0.0f;
+            for (int n = q; n < N; n += IN_Q) yb[(int64_t)n * E + e] = fmaf((xb[(int64_t)n * E + e] - mean) * rstd, g, bt);
+            if (q == 0) { mean_out[b * E + e] = mean; rstd_out[b * E + e] = rstd; }
+        }
     }
 }
 
@@ -933,34 +950,52 @@ __global__ void k_instnorm_train_bwd(const float* __restrict__ x, const float* _
                                      const float* __restrict__ rstd_in, const float* __restrict__ gamma, float* __restrict__ dx,
                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int E)
 {
+    extern __shared__ float red[];                    // [2][IN_Q][Ep]
+    const int Ep = blockDim.x / IN_Q;
+    const int q = threadIdx.x / Ep, el = threadIdx.x - q * Ep;
     const int64_t b = blockIdx.x;
     const float* xb = x + b * (int64_t)N * E;
     const float* gb = dy + b * (int64_t)N * E;
     float* db = dx + b * (int64_t)N * E;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-        const float mean = mean_in[b * E + e], rstd = rstd_in[b * E + e];
+    float* red2 = red + IN_Q * Ep;
+    for (int e0 = 0; e0 < E; e0 += Ep) {
+        const int e = e0 + el;
+        const bool on = e < E;
+        const float mean = on ? mean_in[b * E + e] : 0.0f, rstd = on ? rstd_in[b * E + e] : 0.0f;
         float s1 = 0.0f, s2 = 0.0f;
-        for (int n = 0; n < N; ++n) {
-            const float g = gb[(int64_t)n * E + e];
-            const float xh = (xb[(int64_t)n * E + e] - mean) * rstd;
-            s1 += g;
-            s2 = fmaf(g, xh, s2);
+        if (on)
+            for (int n = q; n < N; n += IN_Q) {
+                const float g = gb[(int64_t)n * E + e];
+                const float xh = (xb[(int64_t)n * E + e] - mean) * rstd;
+                s1 += g;
+                s2 = fmaf(g, xh, s2);
+            }
+        red[q * Ep + el] = s1;
+        red2[q * Ep + el] = s2;
+        __syncthreads();
+        s1 = ((red[el] + red[Ep + el]) + red[2 * Ep + el]) + red[3 * Ep + el];
+        s2 = ((red2[el] + red2[Ep + el]) + red2[2 * Ep + el]) + red2[3 * Ep + el];
+        __syncthreads();
+        if (on) {
+            const float m1 = s1 / (float)N, m2 = s2 / (float)N;
+            const float gr = (gamma ? gamma[e] : 1.0f) * rstd;
+            for (int n = q; n < N; n += IN_Q) {
+                const float xh = (xb[(int64_t)n * E + e] - mean) * rstd;
+                db[(int64_t)n * E + e] = gr * ((gb[(int64_t)n * E + e] - m1) - xh * m2);
+            }
+            if (q == 0) {
+                if (dgamma) atomicAdd(dgamma + e, s2);
+                if (dbeta) atomicAdd(dbeta + e, s1);
+            }
         }
-        const float m1 = s1 / (float)N, m2 = s2 / (float)N;
-        const float gr = (gamma ? gamma[e] : 1.0f) * rstd;
-        for (int n = 0; n < N; ++n) {
-            const float xh = (xb[(int64_t)n * E + e] - mean) * rstd;
-            db[(int64_t)n * E + e] = gr * ((gb[(int64_t)n * E + e] - m1) - xh * m2);
-        }
-        if (dgamma) atomicAdd(dgamma + e, s2);
-        if (dbeta) atomicAdd(dbeta + e, s1);
     }
 }
 
 int launch_instnorm_train_fwd(const float* x, float* y, float* mean, float* rstd, int64_t B, int N, int E, const float* gamma,
                               const float* beta, float eps, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_instnorm_train_fwd, dim3((unsigned)B), dim3(E <= 1024 ? ((E + 63) / 64) * 64 : 1024), 0, st, x, y, mean, rstd,
+    const int Ep = E <= 128 ? ((E + 63) / 64) * 64 : 128;          // channels per pass; block = IN_Q x Ep threads
+    hipLaunchKernelGGL(k_instnorm_train_fwd, dim3((unsigned)B), dim3(IN_Q * Ep), IN_Q * Ep * sizeof(float), st, x, y, mean, rstd,
                        N, E, gamma, beta, eps);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
@@ -968,7 +1003,8 @@ int launch_instnorm_train_fwd(const float* x, float* y, float* mean, float* rstd
 int launch_instnorm_train_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, float* dx,
                               float* dgamma, float* dbeta, int64_t B, int N, int E, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_instnorm_train_bwd, dim3((unsigned)B), dim3(E <= 1024 ? ((E + 63) / 64) * 64 : 1024), 0, st, x, dy, mean, rstd,
+    const int Ep = E <= 128 ? ((E + 63) / 64) * 64 : 128;
+    hipLaunchKernelGGL(k_instnorm_train_bwd, dim3((unsigned)B), dim3(IN_Q * Ep), 2 * IN_Q * Ep * sizeof(float), st, x, dy, mean, rstd,
                        gamma, dx, dgamma, dbeta, N, E);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
