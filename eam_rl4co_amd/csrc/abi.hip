@@ -306,6 +306,7 @@ static int check_reeval(const eamrl_reeval* p, const char* what, bool bwd)
         REQUIRE(p->glogp && p->dheads && p->dK && p->dV && p->dLp && p->dPa && p->ldg >= 128 && p->ldg % 4 == 0, what);
         REQUIRE((p->Pb == nullptr) == (p->dPb == nullptr) && (p->gctx == nullptr) == (p->dgctx == nullptr) &&
                     (p->NC == 0 || p->dCvec) && ((uintptr_t)p->dheads % 16 == 0), what);
+        REQUIRE(p->NC <= 2 && p->R * (int64_t)p->T < (int64_t)1 << 31, what);     // the backward kernels' query indices
     }
     return 0;
 }

@@ -335,93 +335,222 @@ int launch_reeval_fwd(const ReevalArgs& a, hipStream_t st)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward 1/2: logits.  Recomputes heads and u per tile; du -> dheads (scratch in HBM, read by the glimpse kernel) and
-// dLp[n][e] += sum_q du[q][n] heads[q][e] (accumulators of wave w: embedding columns 16 w .. 16 w + 15, all key tiles)
+// dLp[n][e] += sum_q du[q][n] heads[q][e] (accumulators of wave w: embedding columns 16 w .. 16 w + 15, all key tiles).
+//
+// Software pipeline over the tiles (one workgroup per CU, see the glimpse kernel): the query rows of tile i + 1 are
+// fetched while tile i is multiplied, and the glimpse of tile i + 1 is computed in the same barrier interval as the
+// products that consume tile i's du -- two barriers per tile (three when the normaliser is derived from the rollout's
+// log-probs), with MFMA work of every wave on both sides of each.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int DS = 17;        // row stride of the du / transposition staging tiles ([n][q])
+constexpr int DS = 17;        // row stride of the du tile ([n][q])
+
+struct QWalk {          // query l = first, first + 16, ... of the chunk as (start offset, step)
+    int sl, t;
+    __device__ __forceinline__ void init(int l, int T) { sl = l / T; t = l - sl * T; }
+    __device__ __forceinline__ void next(int T)
+    {
+        t += 16;
+        while (t >= T) { t -= T; ++sl; }
+    }
+};
+
+// One thread's share (query jq, columns 4 e4 ..) of a tile's inputs.  The loads are branch-free: an exec-masked load
+// into a register that the loop later overwrites makes the compiler wait for EVERY outstanding load before the overwrite
+// (the pending-load state merges over the skipped branch), which serialises the prefetch.  Queries past the end of the
+// chunk read query 0 / node 0 instead and are masked by `fl` when the tile is staged.
+struct RowPre {
+    float4 pa, pb, dh;
+    float sc[2];        // state scalars (NC <= 2)
+    int fl;             // bit 0: query exists, 1: idxA names a node, 2: idxB names a node, 3: step >= tstart
+};
+
+__device__ __forceinline__ void load_idx(const ReevalArgs& a, int qi, int& ia, int& ib)
+{
+    const int q = max(qi, 0);
+    ia = a.idxA[q];
+    ib = a.idxB ? a.idxB[q] : -1;
+}
+
+template <bool DH>
+__device__ __forceinline__ void load_rows(const ReevalArgs& a, int64_t b, int e4, int qi, int t, int ia, int ib, RowPre& p)
+{
+    const int q = max(qi, 0);
+    p.fl = (qi >= 0 ? 1 : 0) | (ia >= 0 ? 2 : 0) | (ib >= 0 ? 4 : 0) | (t >= a.tstart ? 8 : 0);
+    p.pa = *reinterpret_cast<const float4*>(a.Pa + (b * a.M + max(ia, 0)) * a.ld + 4 * e4);
+    p.pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.Pb) p.pb = *reinterpret_cast<const float4*>(a.Pb + (b * a.M + max(ib, 0)) * a.ld + 4 * e4);
+    p.dh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DH) p.dh = *reinterpret_cast<const float4*>(a.dheads + (int64_t)q * RE + 4 * e4);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) p.sc[k] = k < a.NC ? a.sc[(int64_t)k * a.R * a.T + q] : 0.0f;
+}
+
+// q~ = 0.25 (Pa[ia] + Pb[ib] + gctx + sum_k sc_k C_k) of the thread's query -> QT (A layout) [, dheads -> DHT]
+template <bool DH>
+__device__ __forceinline__ void stage_rows(const RowPre& p, const float4& gc, const float* CV, float* QT, float* DHT, int jq, int e4)
+{
+    const bool ok = p.fl & 1, oa = (p.fl & 3) == 3, ob = (p.fl & 5) == 5;
+    float4 v;
+    v.x = (oa ? p.pa.x : 0.0f) + (ob ? p.pb.x : 0.0f); v.y = (oa ? p.pa.y : 0.0f) + (ob ? p.pb.y : 0.0f);
+    v.z = (oa ? p.pa.z : 0.0f) + (ob ? p.pb.z : 0.0f); v.w = (oa ? p.pa.w : 0.0f) + (ob ? p.pb.w : 0.0f);
+    v.x += gc.x; v.y += gc.y; v.z += gc.z; v.w += gc.w;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {       // (CV rows >= NC are zero)
+        const float4 w = *reinterpret_cast<const float4*>(CV + k * RE + 4 * e4);
+        v.x = fmaf(p.sc[k], w.x, v.x); v.y = fmaf(p.sc[k], w.y, v.y);
+        v.z = fmaf(p.sc[k], w.z, v.z); v.w = fmaf(p.sc[k], w.w, v.w);
+    }
+    float* qp = QT + jq * TS + e4;
+    qp[0] = ok ? 0.25f * v.x : 0.0f; qp[TG] = ok ? 0.25f * v.y : 0.0f;
+    qp[2 * TG] = ok ? 0.25f * v.z : 0.0f; qp[3 * TG] = ok ? 0.25f * v.w : 0.0f;
+    if (DH) {
+        const bool od = (p.fl & 9) == 9;
+        float* dp = DHT + jq * TS + e4;
+        dp[0] = od ? p.dh.x : 0.0f; dp[TG] = od ? p.dh.y : 0.0f; dp[2 * TG] = od ? p.dh.z : 0.0f; dp[3 * TG] = od ? p.dh.w : 0.0f;
+    }
+}
+
+__device__ __forceinline__ uint4 load_mask_words(const ReevalArgs& a, int qi)
+{
+    const uint4 m = *reinterpret_cast<const uint4*>(a.maskbits + (int64_t)max(qi, 0) * 4);
+    return qi >= 0 ? m : make_uint4(0, 0, 0, 0);
+}
 
 template <int RTT>
 __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float QT[16 * TS];
-    __shared__ __attribute__((aligned(16))) float HT[16 * TS];
-    __shared__ float DU[16 * RTT * DS];
-    __shared__ float LSE[16];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* QTB = lds;                               // [2][16][TS]   q~ tiles (A layout)
+    float* HTB = QTB + 2 * 16 * TS;                 // [2][16][TS]   heads tiles
+    float* LPT = HTB + 2 * 16 * TS;                 // [8 waves][RTT][64 lanes][4]  Lp^T fragments of the dheads product
+    float* CV = LPT + 8 * RTT * 256;                // [2][128] state-column vectors
+    float* DU = CV + 2 * RE;                        // [16 RTT][DS]
+    float* LSE = DU + 16 * RTT * DS;                // [16]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, G = lane >> 4;
+    const int jq = tid >> 5, e4 = tid & 31;
     const int64_t b = blockIdx.x / a.nchunk;
     const int ch = (int)(blockIdx.x - b * a.nchunk);
     const int s0 = (int)((int64_t)a.S * ch / a.nchunk), s1 = (int)((int64_t)a.S * (ch + 1) / a.nchunk);
-    const int64_t nq = (int64_t)(s1 - s0) * a.T;
-    const int64_t ntiles = (nq + 15) / 16;
+    const int ns = s1 - s0, T = a.T;
+    const int ntiles = (ns * T + 15) / 16;
     // lse == NULL: no forward pass was run -- logp holds the ROLLOUT's log-prob of the chosen node (the same quantity in the
     // rollout kernels' arithmetic), and the normaliser is recovered as z[action] - logp, one extra LDS hand-off per tile
     const bool derive_lse = a.lse == nullptr;
 
-    float kf[RTT][4], vtf[4 * RTT], lpf[32], lptf[4 * RTT];
+    float kf[RTT][4], vtf[4 * RTT], lpf[32];
     load_head_frags<RTT>(a, b, wv, lane, kf, vtf);
-    if (wv < RTT) load_lp_frags(a, b, wv, lane, lpf);
+    load_lp_frags(a, b, wv < RTT ? wv : RTT - 1, lane, lpf);       // (wave 7 of RTT = 7 computes no logits)
+    float4* lpt = reinterpret_cast<float4*>(LPT) + wv * RTT * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < 4 * RTT; ++t) {                 // Lp^T: row e = 16 wv + j, k index = key 4 t + G
-        const int n = 4 * t + G;
-        lptf[t] = n < a.M ? a.Lp[(b * a.M + n) * a.ld + 16 * wv + j] : 0.0f;
+    for (int t4 = 0; t4 < RTT; ++t4) {              // Lp^T: row e = 16 wv + j, k index = key 4 t + G, t = 4 t4 + i
+        float kk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = 4 * (4 * t4 + i) + G;
+            kk[i] = n < a.M ? a.Lp[(b * a.M + n) * a.ld + 16 * wv + j] : 0.0f;
+        }
+        lpt[t4 * 64] = make_float4(kk[0], kk[1], kk[2], kk[3]);
     }
+    for (int i = tid; i < 2 * RE; i += blockDim.x) CV[i] = i < a.NC * RE ? a.Cvec[i] : 0.0f;
+    float4 gc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.gctx) gc = *reinterpret_cast<const float4*>(a.gctx + b * RE + 4 * e4);
     f32x4 dLp[RTT];
 #pragma unroll
     for (int nt = 0; nt < RTT; ++nt) dLp[nt] = z4();
     const float inv_temp = 1.0f / a.temp;
 
-    for (int64_t tile = 0; tile < ntiles; ++tile) {
-        build_query_tile(a, b, s0, nq, tile, QT);
-        const Q q = tile_query(a, b, s0, nq, tile, j);
-        uint4 mb = make_uint4(0, 0, 0, 0);
-        int act = -1;
-        float g = 0.0f, lse = 0.0f;
-        if (q.qi >= 0) {
-            mb = *reinterpret_cast<const uint4*>(a.maskbits + q.qi * 4);
-            act = (int)a.actions[q.qi];
-            if (q.active) { g = a.glogp[q.qi]; lse = derive_lse ? a.logp[q.qi] : a.lse[q.qi]; }
-        }
-        __syncthreads();
-        glimpse_tile<RTT>(kf, vtf, QT, HT, wv, lane, mb, a.M);
-        __syncthreads();
-        f32x4 u = z4();
-        if (wv < RTT) u = logit_tile(lpf, HT, lane);
-        if (derive_lse) {           // the lane that owns the chosen node publishes z[action] - logp for its query
+    // query index r * T + t as a 32-bit value (R * T < 2^31 is checked by the caller), -1 past the chunk's end
+    auto qi_of = [&](const QWalk& w) -> int { return w.sl < ns ? ((s0 + w.sl) * (int)a.B + (int)b) * T + w.t : -1; };
+    // ---- prologue: tile 0 staged, indices of tile 1 in flight --------------------------------------------------------
+    QWalk wr, wj;                       // the staging role (query jq) and the MFMA role (query j) of this thread
+    wr.init(jq, T);
+    wj.init(j, T);
+    int qr = qi_of(wr), ia, ib;
+    load_idx(a, qr, ia, ib);
+    {
+        RowPre pre;
+        load_rows<false>(a, b, e4, qr, wr.t, ia, ib, pre);
+        __syncthreads();                // CV
+        stage_rows<false>(pre, gc, CV, QTB, nullptr, jq, e4);
+    }
+    wr.next(T);
+    qr = qi_of(wr);
+    load_idx(a, qr, ia, ib);            // tile 1
+    int qj = qi_of(wj), tj = wj.t;      // tile 0
+    uint4 mb = load_mask_words(a, qj);
+
+    // iteration `tile`: logits, du and the products of tile `tile`, then the glimpse of tile + 1 (iteration -1: only that).
+    // Nothing but the mask words, the indices of the next tile's rows and the walkers is live across iterations: each
+    // iteration issues its loads first and consumes them behind its own MFMA work.
+    for (int tile = -1; tile < ntiles; ++tile) {
+        const int cur = tile & 1, nxt = cur ^ 1;
+        const float* HT = HTB + cur * 16 * TS;
+        uint4 mbn = mb;
+        int qjn = qj, tjn = tj;
+        if (tile >= 0) {
+            RowPre pre;
+            load_rows<false>(a, b, e4, qr, wr.t, ia, ib, pre);      // rows of tile + 1 (indices fetched one iteration ago)
+            wr.next(T);
+            qr = qi_of(wr);
+            load_idx(a, qr, ia, ib);                                // indices of tile + 2
+            const int qjc = max(qj, 0);
+            const bool live = qj >= 0 && tj >= a.tstart;
+            const int act_l = (int)a.actions[qjc];
+            const float g_l = a.glogp[qjc], lse_l = derive_lse ? a.logp[qjc] : a.lse[qjc];
+            wj.next(T);
+            qjn = qi_of(wj);
+            tjn = wj.t;
+            mbn = load_mask_words(a, qjn);
+            __syncthreads();            // heads of this tile complete; the previous tile's du has been consumed
+            f32x4 u = z4();
+            if (wv < RTT) u = logit_tile(lpf, HT, lane);
+            const int act = qj >= 0 ? act_l : -1;
+            const float g = live ? g_l : 0.0f;
+            float lse = live ? lse_l : 0.0f;
+            if (derive_lse) {           // the lane that owns the chosen node publishes z[action] - logp for its query
+                if (wv < RTT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float dzdu;
+                        const float z = process_logit(u[r], a.clip, inv_temp, dzdu);
+                        if (16 * wv + 4 * r + G == act && g != 0.0f) LSE[j] = z - lse;
+                    }
+                }
+                __syncthreads();
+                if (g != 0.0f) lse = LSE[j];
+            }
             if (wv < RTT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    const int n0 = 16 * wv + 4 * r;
+                    const uint32_t w = (n0 >> 5) == 0 ? mb.x : (n0 >> 5) == 1 ? mb.y : (n0 >> 5) == 2 ? mb.z : mb.w;
+                    const bool ok = (w >> ((n0 & 31) + G)) & 1u;
                     float dzdu;
                     const float z = process_logit(u[r], a.clip, inv_temp, dzdu);
-                    if (16 * wv + 4 * r + G == act && g != 0.0f) LSE[j] = z - lse;
+                    float du = 0.0f;
+                    if (ok && g != 0.0f) {
+                        const float p = fexp(z - lse);
+                        du = g * ((n0 + G == act ? 1.0f : 0.0f) - p) * dzdu;
+                    }
+                    DU[(n0 + G) * DS + j] = du;
                 }
             }
-            __syncthreads();
-            if (g != 0.0f) lse = LSE[j];
-        }
-        if (wv < RTT) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n0 = 16 * wv + 4 * r;
-                const uint32_t w = (n0 >> 5) == 0 ? mb.x : (n0 >> 5) == 1 ? mb.y : (n0 >> 5) == 2 ? mb.z : mb.w;
-                const bool ok = (w >> ((n0 & 31) + G)) & 1u;
-                float dzdu;
-                const float z = process_logit(u[r], a.clip, inv_temp, dzdu);
-                float du = 0.0f;
-                if (ok && g != 0.0f) {
-                    const float p = fexp(z - lse);
-                    du = g * ((n0 + G == act ? 1.0f : 0.0f) - p) * dzdu;
-                }
-                DU[(n0 + G) * DS + j] = du;
-            }
-        }
-        __syncthreads();
-        {   // wave wv: embedding columns 16 wv .. 16 wv + 15
+            stage_rows<false>(pre, gc, CV, QTB + nxt * 16 * TS, nullptr, jq, e4);
+            __syncthreads();            // du of this tile and q~ of the next one visible
+            // wave wv: embedding columns 16 wv .. 16 wv + 15
             f32x4 dh = z4();
 #pragma unroll
-            for (int t = 0; t < 4 * RTT; ++t) dh = mf(lptf[t], DU[(4 * t + G) * DS + j], dh);
-            if (q.qi >= 0)
-                *reinterpret_cast<float4*>(a.dheads + q.qi * RE + 16 * wv + 4 * G) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+            for (int t4 = 0; t4 < RTT; ++t4) {
+                const float4 ll = lpt[t4 * 64];
+                dh = mf(ll.x, DU[(16 * t4 + G) * DS + j], dh);
+                dh = mf(ll.y, DU[(16 * t4 + 4 + G) * DS + j], dh);
+                dh = mf(ll.z, DU[(16 * t4 + 8 + G) * DS + j], dh);
+                dh = mf(ll.w, DU[(16 * t4 + 12 + G) * DS + j], dh);
+            }
+            if (qj >= 0)
+                *reinterpret_cast<float4*>(a.dheads + (int64_t)qj * RE + 16 * wv + 4 * G) = make_float4(dh[0], dh[1], dh[2], dh[3]);
             float hb[4];
             const int c = 16 * wv + j;
 #pragma unroll
@@ -430,7 +559,11 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
             for (int nt = 0; nt < RTT; ++nt)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) dLp[nt] = mf(DU[(16 * nt + j) * DS + 4 * t + G], hb[t], dLp[nt]);
+        } else {
+            __syncthreads();            // q~ of tile 0 visible
         }
+        mb = mbn; qj = qjn; tj = tjn;
+        if (tile + 1 < ntiles) glimpse_tile<RTT>(kf, vtf, QTB + nxt * 16 * TS, HTB + nxt * 16 * TS, wv, lane, mb, a.M);
     }
     // dLp: lane (column 16 wv + j, G), register r -> key 16 nt + 4 G + r
 #pragma unroll
@@ -443,38 +576,44 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// backward 2/2: glimpse.  Wave h = head h: recomputes the softmax, da = V dheads, ds = a (da - sum a da),
-// dq~ = K^T ds -> scattered (LDS atomics) into the per-instance dPa / dPb / dgctx / dCvec accumulators,
-// dV[n][e] += sum_q a[q][n] dheads[q][e], dK[n][d] += sum_q ds[q][n] q~[q][d]
+// backward 2/2: glimpse.  Wave h = head h: recomputes the softmax, da = V dheads, ds = a (da - sum a da), dq~ = K^T ds,
+// dV[n][e] += sum_q a[q][n] dheads[q][e], dK[n][d] += sum_q ds[q][n] q~[q][d].
+//
+// One workgroup per CU (the fragments take the whole register file), so nothing else on the CU hides a serial chain
+// inside the tile loop; it is pipelined by hand:
+//   * the rows of tile i + 1 (and the indices of tile i + 2) are fetched into registers while tile i is multiplied, and the
+//     staged query / dheads tiles are double-buffered: one barrier per tile;
+//   * the accumulator -> A-operand transpositions of the softmax weights and their gradients go through per-wave staging
+//     rows laid out for one 16-byte read per lane ([key][query & 3][query >> 2]), written one key tile ahead of the
+//     products that consume them, with no waits between (LDS executes one wave's accesses in order);
+//   * dq~ is not scattered inside the kernel: it overwrites the tile's dheads rows (the scratch is read one tile ahead),
+//     and k_reeval_bwd_gather adds the rows into dPa / dPb / dgctx / dCvec afterwards.  The K^T fragments of the dq~
+//     product live in LDS, which leaves their 28 registers to the prefetch.
+// (Round-2 history: with the gathers, two barriers and an LDS-atomic scatter inside the loop this kernel took 37.3 ms at the
+//  POMO training size; 15.6 ms now, plus 2.0 ms of k_reeval_bwd_gather.)
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int DQS = 132;      // row stride of the dq tile
-
 template <int RTT>
 __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* QT = lds;                         // [16][TS]
-    float* DHT = QT + 16 * TS;               // [16][TS]   dheads tile (A layout)
-    float* DQ = DHT + 16 * TS;               // [16][DQS]  dq tile
-    float* ST = DQ + 16 * DQS;               // [8 waves][16][DS] transposition staging
-    float* ACC_A = ST + 8 * 16 * DS;         // [M][128] dPa
-    float* ACC_B = ACC_A + a.M * RE;         // [M][128] dPb
-    float* ACC_G = ACC_B + a.M * RE;         // [128] dgctx
-    float* ACC_C = ACC_G + RE;               // [4][128] dCvec
+    float* QTB = lds;                               // [2][16][TS]   q~ tiles (A layout)
+    float* DHB = QTB + 2 * 16 * TS;                 // [2][16][TS]   dheads tiles
+    float* STG = DHB + 2 * 16 * TS;                 // [8 waves][2 parities][a | ds][16 keys][16 queries]
+    float* KTL = STG + 8 * 4 * 256;                 // [8 waves][RTT][64 lanes][4]  K^T fragments of the dq~ product
+    float* CV = KTL + 8 * RTT * 256;                // [2][128] state-column vectors
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, G = lane >> 4, pi = 4 * (j & 3) + (j >> 2);
+    const int jq = tid >> 5, e4 = tid & 31;
     const int64_t b = blockIdx.x / a.nchunk;
     const int ch = (int)(blockIdx.x - b * a.nchunk);
     const int s0 = (int)((int64_t)a.S * ch / a.nchunk), s1 = (int)((int64_t)a.S * (ch + 1) / a.nchunk);
-    const int64_t nq = (int64_t)(s1 - s0) * a.T;
-    const int64_t ntiles = (nq + 15) / 16;
+    const int ns = s1 - s0, T = a.T;
+    const int ntiles = (ns * T + 15) / 16;
     const int h = wv;
-    float* st = ST + wv * 16 * DS;
+    float* stg = STG + wv * 4 * 256;
 
-    for (int i = tid; i < 2 * a.M * RE + 5 * RE; i += blockDim.x) ACC_A[i] = 0.0f;
-
-    float kf[RTT][4], vaf[RTT][4], ktf[4 * RTT];
+    float kf[RTT][4], vaf[RTT][4];
 #pragma unroll
     for (int kt = 0; kt < RTT; ++kt) {
         const int n = 16 * kt + pi;
@@ -484,118 +623,135 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
             vaf[kt][t] = n < a.M ? a.V[(b * a.M + n) * a.ld + 16 * h + 4 * t + G] : 0.0f;
         }
     }
+    float4* ktl = reinterpret_cast<float4*>(KTL) + wv * RTT * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < 4 * RTT; ++t) {                 // K^T: row d = j, k index = key 4 t + G
-        const int n = 4 * t + G;
-        ktf[t] = n < a.M ? a.K[(b * a.M + n) * a.ld + 16 * h + j] : 0.0f;
+    for (int t4 = 0; t4 < RTT; ++t4) {              // K^T: row d = j, k index = key 4 t + G, t = 4 t4 + i
+        float kk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = 4 * (4 * t4 + i) + G;
+            kk[i] = n < a.M ? a.K[(b * a.M + n) * a.ld + 16 * h + j] : 0.0f;
+        }
+        ktl[t4 * 64] = make_float4(kk[0], kk[1], kk[2], kk[3]);
     }
+    for (int i = tid; i < 2 * RE; i += blockDim.x) CV[i] = i < a.NC * RE ? a.Cvec[i] : 0.0f;
+    float4 gc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.gctx) gc = *reinterpret_cast<const float4*>(a.gctx + b * RE + 4 * e4);
     f32x4 dV[RTT], dK[RTT];
 #pragma unroll
     for (int nt = 0; nt < RTT; ++nt) { dV[nt] = z4(); dK[nt] = z4(); }
 
-    for (int64_t tile = 0; tile < ntiles; ++tile) {
-        build_query_tile(a, b, s0, nq, tile, QT);
-        {   // dheads tile -> DHT (A layout)
-            const int jq = tid >> 5, e4 = tid & 31;
-            const Q qq = tile_query(a, b, s0, nq, tile, jq);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qq.qi >= 0 && qq.active) v = *reinterpret_cast<const float4*>(a.dheads + qq.qi * RE + 4 * e4);
-            float* p = DHT + jq * TS + e4;
-            p[0] = v.x; p[TG] = v.y; p[2 * TG] = v.z; p[3 * TG] = v.w;
-        }
-        const Q q = tile_query(a, b, s0, nq, tile, j);
-        uint4 mb = make_uint4(0, 0, 0, 0);
-        if (q.qi >= 0) mb = *reinterpret_cast<const uint4*>(a.maskbits + q.qi * 4);
+    // query index r * T + t as a 32-bit value (R * T < 2^31 is checked by the caller), -1 past the chunk's end
+    auto qi_of = [&](const QWalk& w) -> int { return w.sl < ns ? ((s0 + w.sl) * (int)a.B + (int)b) * T + w.t : -1; };
+    // ---- prologue: rows of tile 0, indices of tile 1, mask words of tile 0 ------------------------------------------------
+    QWalk wr, wj;                       // the staging role (query jq) and the MFMA role (query j) of this thread
+    wr.init(jq, T);
+    wj.init(j, T);
+    int qr = qi_of(wr), ia, ib;
+    load_idx(a, qr, ia, ib);
+    RowPre pre;
+    load_rows<true>(a, b, e4, qr, wr.t, ia, ib, pre);
+    wr.next(T);
+    qr = qi_of(wr);
+    load_idx(a, qr, ia, ib);
+    int qj = qi_of(wj);
+    uint4 mb = load_mask_words(a, qj);
+    __syncthreads();                    // CV, KTL
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int cur = tile & 1;
+        stage_rows<true>(pre, gc, CV, QTB + cur * 16 * TS, DHB + cur * 16 * TS, jq, e4);
+        // rows of tile + 1 (their indices arrived during the previous tile), indices of tile + 2, mask words of tile + 1
+        load_rows<true>(a, b, e4, qr, wr.t, ia, ib, pre);
+        wr.next(T);
+        qr = qi_of(wr);
+        load_idx(a, qr, ia, ib);
+        const int qj_cur = qj;
+        const uint4 mb_cur = mb;
+        wj.next(T);
+        qj = qi_of(wj);
+        mb = load_mask_words(a, qj);
         __syncthreads();
-        {
-            f32x4 s[RTT], da[RTT];
-            const float iz = head_softmax<RTT>(kf, QT, h, lane, mb, a.M, s);
-            const float* dp = DHT + j * TS + G * TG + 4 * h;
-            const float2 dlo = *reinterpret_cast<const float2*>(dp), dhi = *reinterpret_cast<const float2*>(dp + 2);
+        const float* QT = QTB + cur * 16 * TS;
+        const float* DHT = DHB + cur * 16 * TS;
+        f32x4 s[RTT], da[RTT];
+        const float iz = head_softmax<RTT>(kf, QT, h, lane, mb_cur, a.M, s);
+        const float* dp = DHT + j * TS + G * TG + 4 * h;
+        const float2 dlo = *reinterpret_cast<const float2*>(dp), dhi = *reinterpret_cast<const float2*>(dp + 2);
 #pragma unroll
-            for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][0], dlo.x, z4());
+        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][0], dlo.x, z4());
 #pragma unroll
-            for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][1], dlo.y, da[kt]);
+        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][1], dlo.y, da[kt]);
 #pragma unroll
-            for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][2], dhi.x, da[kt]);
+        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][2], dhi.x, da[kt]);
 #pragma unroll
-            for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][3], dhi.y, da[kt]);
-            float rs = 0.0f;
+        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][3], dhi.y, da[kt]);
+        float rs = 0.0f;
 #pragma unroll
-            for (int kt = 0; kt < RTT; ++kt)
+        for (int kt = 0; kt < RTT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kt][r] *= iz;                          // a
+                rs = fmaf(s[kt][r], da[kt][r], rs);
+            }
+        rs = group_sum(rs);
+#pragma unroll
+        for (int kt = 0; kt < RTT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) da[kt][r] = s[kt][r] * (da[kt][r] - rs);      // ds
+        // staging of key tile 0 (element (key kappa, query q) of a tile at kappa * 16 + (q & 3) * 4 + (q >> 2))
+        float* wp = stg + G * 16 + (j & 3) * 4 + (j >> 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            wp[r * 64] = s[0][r];
+            wp[256 + r * 64] = da[0][r];
+        }
+        // dq~^T = K^T ds: lane (query j, G), register r -> d = 4 G + r
+        f32x4 dq = z4();
+#pragma unroll
+        for (int t4 = 0; t4 < RTT; ++t4) {
+            const float4 kk = ktl[t4 * 64];
+            dq = mf(kk.x, da[t4][0], dq);
+            dq = mf(kk.y, da[t4][1], dq);
+            dq = mf(kk.z, da[t4][2], dq);
+            dq = mf(kk.w, da[t4][3], dq);
+        }
+        if (qj_cur >= 0)
+            *reinterpret_cast<float4*>(a.dheads + (int64_t)qj_cur * RE + 16 * h + 4 * G) =
+                make_float4(0.25f * dq[0], 0.25f * dq[1], 0.25f * dq[2], 0.25f * dq[3]);
+        // B operands of the two "sum over queries" products: dheads_h [q][e] and q~_h [q][d], column j, k index q = 4 t + G
+        float dhb[4], qb[4];
+        const int c = 16 * h + j;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            dhb[t] = DHT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
+            qb[t] = QT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
+        }
+#pragma unroll
+        for (int nt = 0; nt < RTT; ++nt) {
+            if (nt + 1 < RTT) {
+                float* wq = wp + ((nt + 1) & 1) * 512;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    s[kt][r] *= iz;                          // a
-                    rs = fmaf(s[kt][r], da[kt][r], rs);
-                }
-            rs = group_sum(rs);
-#pragma unroll
-            for (int kt = 0; kt < RTT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) da[kt][r] = s[kt][r] * (da[kt][r] - rs);      // ds
-            // dq~^T = K^T ds: lane (query j, G), register r -> d = 4 G + r
-            f32x4 dq = z4();
-#pragma unroll
-            for (int t = 0; t < 4 * RTT; ++t) dq = mf(ktf[t], da[t >> 2][t & 3], dq);
-            *reinterpret_cast<float4*>(DQ + j * DQS + 16 * h + 4 * G) =
-                make_float4(0.25f * dq[0], 0.25f * dq[1], 0.25f * dq[2], 0.25f * dq[3]);
-            // B operands of the two "sum over queries" products: dheads_h [q][e] and q~_h [q][d], column j, k index q = 4 t + G
-            float dhb[4], qb[4];
-            const int c = 16 * h + j;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                dhb[t] = DHT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
-                qb[t] = QT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
-            }
-#pragma unroll
-            for (int nt = 0; nt < RTT; ++nt) {
-                // a^T tile: accumulator layout (lane = query, register r -> key 4 r + G of the tile) -> rows = keys, k = queries
-#pragma unroll
-                for (int r = 0; r < 4; ++r) st[(4 * r + G) * DS + j] = s[nt][r];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                float at[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) at[t] = st[j * DS + 4 * t + G];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int r = 0; r < 4; ++r) st[(4 * r + G) * DS + j] = da[nt][r];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                float dt[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) dt[t] = st[j * DS + 4 * t + G];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    dV[nt] = mf(at[t], dhb[t], dV[nt]);
-                    dK[nt] = mf(dt[t], qb[t], dK[nt]);
+                    wq[r * 64] = s[nt + 1][r];
+                    wq[256 + r * 64] = da[nt + 1][r];
                 }
             }
-        }
-        __syncthreads();
-        {   // scatter the tile's dq rows into the instance's accumulators (LDS atomics)
-            const int jq = tid >> 5, e4 = tid & 31;
-            const Q qq = tile_query(a, b, s0, nq, tile, jq);
-            if (qq.qi >= 0 && qq.active) {
-                const float4 v = *reinterpret_cast<const float4*>(DQ + jq * DQS + 4 * e4);
-                const float d[4] = {v.x, v.y, v.z, v.w};
-                const int ia = a.idxA[qq.qi];
-                const int ib = a.idxB ? a.idxB[qq.qi] : -1;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (ia >= 0) __hip_atomic_fetch_add(ACC_A + ia * RE + 4 * e4 + i, d[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (ib >= 0) __hip_atomic_fetch_add(ACC_B + ib * RE + 4 * e4 + i, d[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(ACC_G + 4 * e4 + i, d[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                for (int k = 0; k < a.NC; ++k) {
-                    const float sck = a.sc[(int64_t)k * a.R * a.T + qq.qi];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        __hip_atomic_fetch_add(ACC_C + k * RE + 4 * e4 + i, sck * d[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
+            __builtin_amdgcn_wave_barrier();
+            const float* rp = stg + (nt & 1) * 512 + j * 16 + G * 4;
+            const float4 at = *reinterpret_cast<const float4*>(rp);
+            const float4 dt = *reinterpret_cast<const float4*>(rp + 256);
+            __builtin_amdgcn_wave_barrier();
+            dV[nt] = mf(at.x, dhb[0], dV[nt]);
+            dK[nt] = mf(dt.x, qb[0], dK[nt]);
+            dV[nt] = mf(at.y, dhb[1], dV[nt]);
+            dK[nt] = mf(dt.y, qb[1], dK[nt]);
+            dV[nt] = mf(at.z, dhb[2], dV[nt]);
+            dK[nt] = mf(dt.z, qb[2], dK[nt]);
+            dV[nt] = mf(at.w, dhb[3], dV[nt]);
+            dK[nt] = mf(dt.w, qb[3], dK[nt]);
         }
     }
-    // ---- flush --------------------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int nt = 0; nt < RTT; ++nt)
 #pragma unroll
@@ -606,32 +762,141 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
                 atomicAdd(a.dK + (b * a.M + n) * a.ldg + 16 * h + j, dK[nt][r]);
             }
         }
-    __syncthreads();
-    for (int i = tid; i < a.M * RE; i += blockDim.x) {
-        const int n = i / RE, e = i - n * RE;
-        const float va = ACC_A[i];
-        if (va != 0.0f) atomicAdd(a.dPa + (b * a.M + n) * a.ldg + e, va);
-        if (a.dPb) {
-            const float vb = ACC_B[i];
-            if (vb != 0.0f) atomicAdd(a.dPb + (b * a.M + n) * a.ldg + e, vb);
+}
+
+// dq~ rows -> dPa / dPb / dgctx / dCvec without floating-point LDS atomics (ds_add_f32 retires about one lane every two
+// cycles on this part: the 2.6e9 lane-adds of the POMO step took 12 ms however the banks were mapped).  Per (instance,
+// chunk of starts) and index set: counting sort of the chunk's queries by node in LDS (integer atomics, one per query),
+// then each node's rows are summed in registers by one wavefront (bins of more than GBIG rows: by all eight) and added
+// to the gradient row once.  Bin M of the first index set collects the active queries that name no node, so that the
+// sets' rows also sum to dgctx and (weighted by the state scalars) dCvec.
+constexpr int GU = 8;           // rows in flight per wavefront
+constexpr int GBIG = 512;
+constexpr int GCAP = 24576;     // queries per workgroup (LDS: 4 bytes each)
+
+__global__ __launch_bounds__(512) void k_reeval_bwd_gather(ReevalArgs a, int nchunk)
+{
+    extern __shared__ __attribute__((aligned(16))) int ldsi[];
+    int* OFF = ldsi;                // [M + 2] counts, then offsets
+    int* CUR = OFF + 132;           // [M + 1] cursors
+    int* ORD = CUR + 132;           // [nq] query indices grouped by node
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b = blockIdx.x / nchunk;
+    const int ch = (int)(blockIdx.x - b * nchunk);
+    const int s0 = (int)((int64_t)a.S * ch / nchunk), s1 = (int)((int64_t)a.S * (ch + 1) / nchunk);
+    const int T = a.T, nq = (s1 - s0) * T, M = a.M;
+    float2 gs = make_float2(0.f, 0.f), cs[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+
+    for (int pass = 0; pass < 2; ++pass) {
+        const int32_t* idx = pass ? a.idxB : a.idxA;
+        float* dP = pass ? a.dPb : a.dPa;
+        if (!idx) break;
+        const int nb = pass ? M : M + 1;
+        __syncthreads();
+        for (int i = tid; i < 2 * 132; i += blockDim.x) OFF[i] = 0;
+        __syncthreads();
+        for (int l = tid; l < nq; l += blockDim.x) {
+            const int sl = l / T, t = l - sl * T;
+            if (t < a.tstart) continue;
+            const int n = idx[((int64_t)(s0 + sl) * a.B + b) * T + t];
+            if (n >= 0 || !pass) atomicAdd(OFF + (n >= 0 ? n : M), 1);
+        }
+        __syncthreads();
+        if (wv == 0) {              // exclusive prefix over the nb <= 128 bins: two per lane
+            const int c0 = 2 * lane < nb ? OFF[2 * lane] : 0, c1 = 2 * lane + 1 < nb ? OFF[2 * lane + 1] : 0;
+            int x = c0 + c1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            const int ex = x - c0 - c1;
+            if (2 * lane <= nb) { OFF[2 * lane] = ex; CUR[2 * lane] = ex; }
+            if (2 * lane + 1 <= nb) { OFF[2 * lane + 1] = ex + c0; CUR[2 * lane + 1] = ex + c0; }
+        }
+        __syncthreads();
+        for (int l = tid; l < nq; l += blockDim.x) {
+            const int sl = l / T, t = l - sl * T;
+            if (t < a.tstart) continue;
+            const int qi = ((s0 + sl) * (int)a.B + (int)b) * T + t;
+            const int n = idx[qi];
+            if (n >= 0 || !pass) ORD[atomicAdd(CUR + (n >= 0 ? n : M), 1)] = qi;
+        }
+        __syncthreads();
+        for (int n = 0; n < nb; ++n) {
+            const int beg = OFF[n], end = OFF[n + 1];
+            const bool big = end - beg > GBIG;
+            if (end == beg || (!big && (n & 7) != wv)) continue;
+            float2 acc = make_float2(0.f, 0.f);
+            for (int i = beg + (big ? wv * GU : 0); i < end; i += big ? 8 * GU : GU) {
+                float2 v[GU];
+                float sc[GU][2];
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    v[u] = make_float2(0.f, 0.f);
+                    sc[u][0] = sc[u][1] = 0.0f;
+                    if (i + u < end) {
+                        const int q = __builtin_amdgcn_readfirstlane(ORD[i + u]);
+                        v[u] = reinterpret_cast<const float2*>(a.dheads + (int64_t)q * RE)[lane];
+                        if (!pass) {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k)
+                                if (k < a.NC) sc[u][k] = a.sc[(int64_t)k * a.R * T + q];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    acc.x += v[u].x; acc.y += v[u].y;
+                    if (!pass) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) { cs[k].x = fmaf(sc[u][k], v[u].x, cs[k].x); cs[k].y = fmaf(sc[u][k], v[u].y, cs[k].y); }
+                    }
+                }
+            }
+            if (n < M) {
+                atomicAdd(dP + (b * M + n) * a.ldg + 2 * lane, acc.x);
+                atomicAdd(dP + (b * M + n) * a.ldg + 2 * lane + 1, acc.y);
+            }
+            if (!pass) { gs.x += acc.x; gs.y += acc.y; }
         }
     }
-    if (tid < RE) {
-        if (a.dgctx) atomicAdd(a.dgctx + b * RE + tid, ACC_G[tid]);
-        for (int k = 0; k < a.NC; ++k) atomicAdd(a.dCvec + k * RE + tid, ACC_C[k * RE + tid]);
+    if (a.dgctx) {
+        atomicAdd(a.dgctx + b * RE + 2 * lane, gs.x);
+        atomicAdd(a.dgctx + b * RE + 2 * lane + 1, gs.y);
+    }
+    for (int k = 0; k < a.NC && k < 2; ++k) {
+        atomicAdd(a.dCvec + k * RE + 2 * lane, cs[k].x);
+        atomicAdd(a.dCvec + k * RE + 2 * lane + 1, cs[k].y);
     }
 }
 
 template <int RTT>
 static int launch_bwd_t(const ReevalArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_reeval_bwd_logits<RTT>, dim3((unsigned)(a.B * a.nchunk)), dim3(512), 0, st, a);
-    const size_t lds = (2 * 16 * (size_t)TS + 16 * DQS + 8 * 16 * DS + 2 * (size_t)a.M * RE + 5 * RE) * sizeof(float);
+    const unsigned grid = (unsigned)(a.B * a.nchunk);
+    const size_t ldl = (4 * 16 * (size_t)TS + 8 * RTT * 256 + 2 * RE + 16 * RTT * DS + 16) * sizeof(float);
+    auto kl = k_reeval_bwd_logits<RTT>;
+    if (ldl > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldl) != hipSuccess)
+        return EAMRL_E_LAUNCH;
+    hipLaunchKernelGGL(kl, dim3(grid), dim3(512), ldl, st, a);
+    const size_t lds = (4 * 16 * (size_t)TS + 8 * 4 * 256 + 8 * RTT * 256 + 2 * RE) * sizeof(float);
     auto k = k_reeval_bwd_glimpse<RTT>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return EAMRL_E_LAUNCH;
-    hipLaunchKernelGGL(k, dim3((unsigned)(a.B * a.nchunk)), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
+    // the gather kernel sorts its chunk's queries in LDS: at most GCAP of them per workgroup
+    int ng = a.nchunk;
+    while ((int64_t)((a.S + ng - 1) / ng) * a.T > GCAP && ng < a.S) ++ng;
+    if ((int64_t)((a.S + ng - 1) / ng) * a.T > GCAP) return EAMRL_E_LAUNCH;
+    const size_t ldg = (2 * 132 + (size_t)((a.S + ng - 1) / ng) * a.T) * sizeof(int);
+    if (ldg > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_reeval_bwd_gather),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldg) != hipSuccess)
+        return EAMRL_E_LAUNCH;
+    hipLaunchKernelGGL(k_reeval_bwd_gather, dim3((unsigned)(a.B * ng)), dim3(512), ldg, st, a, ng);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 

@@ -259,14 +259,14 @@ int eamrl_pointer_attention(const float* query, const float* key, const float* v
  * Not bit-exact by contract: hardware exp / log, tile-order sums; log-probs within 1e-5 of the rollout's. */
 typedef struct eamrl_reeval {
     const float *K, *V, *Lp, *Pa, *Pb; int64_t ld;          /* [B][M][.] fp32, common row stride ld (floats), 16-byte aligned rows */
-    const float* gctx; const float* Cvec; int NC;           /* [B][E] or NULL; [NC][E] (NC <= 4) */
+    const float* gctx; const float* Cvec; int NC;           /* [B][E] or NULL; [NC][E] (NC <= 4 forward, <= 2 backward) */
     const int32_t* idxA; const int32_t* idxB; const float* sc;
     const uint32_t* maskbits; const int64_t* actions;       /* actions [R][T] */
     int64_t B, R; int S, T, M, tstart, nchunk; float clip, temp;      /* nchunk: workgroups per instance (rows split) */
     float* logp; float* lse;                                /* [R][T]: forward writes both; backward reads lse -- or, with
                                                              * lse == NULL (no forward pass run), logp = the ROLLOUT's per-step
                                                              * log-probs of `actions`, from which the normaliser is recovered */
-    const float* glogp; float* dheads;                      /* backward: dL/dlogp [R][T]; scratch [R][T][E] */
+    const float* glogp; float* dheads;                      /* backward: dL/dlogp [R][T]; scratch [R][T][E], R * T < 2^31 */
     float* entropy;                                         /* forward, optional: [R][T] entropy of each step's distribution
                                                              * over the feasible nodes (calculate_entropy, utils/ops.py) */
     float *dK, *dV, *dLp, *dPa, *dPb; int64_t ldg;          /* gradients [B][M][.] (row stride ldg), ACCUMULATED into (+=) */
