@@ -73,6 +73,8 @@ PROTOTYPES = {
     "eamrl_linear": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
     "eamrl_linear_bn": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp],
     "eamrl_matmul_right": [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
+    "eamrl_linear_wgrad_scratch": [_i64, _i32, _i32],
+    "eamrl_linear_wgrad": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
     "eamrl_mha_encoder": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "eamrl_normalize": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp],
     "eamrl_batchnorm_train": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i64, _vp],
@@ -109,7 +111,7 @@ PROTOTYPES = {
                            _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eamrl_ea_tsp_run": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp],
 }
-_RESTYPES = {"eamrl_last_error": C.c_char_p}
+_RESTYPES = {"eamrl_last_error": C.c_char_p, "eamrl_linear_wgrad_scratch": C.c_int64}
 
 _lib = None
 

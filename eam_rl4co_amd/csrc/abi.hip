@@ -208,6 +208,25 @@ __attribute__((visibility("default"))) int eamrl_matmul_right(const float* x, in
     return launched(launch_linear(g, (hipStream_t)stream), "eamrl_matmul_right");
 }
 
+__attribute__((visibility("default"))) int64_t eamrl_linear_wgrad_scratch(int64_t rows, int out_dim, int in_dim)
+{
+    if (rows < 0 || !linear_wgrad_supports(out_dim, in_dim)) return -1;
+    return linear_wgrad_scratch(rows, out_dim, in_dim);
+}
+
+__attribute__((visibility("default"))) int eamrl_linear_wgrad(const float* dy, int64_t ldy, const float* x, int64_t ldx,
+                                                             int64_t rows, int out_dim, int in_dim, float* dW, float* db,
+                                                             float* scratch, int64_t scratch_floats, void* stream)
+{
+    REQUIRE(dy && x && dW && scratch, "eamrl_linear_wgrad");
+    REQUIRE(rows >= 0 && linear_wgrad_supports(out_dim, in_dim) && ldy >= out_dim && ldx >= in_dim, "eamrl_linear_wgrad");
+    REQUIRE(ldy % 4 == 0 && ldx % 4 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dW % 16 == 0 &&
+                (uintptr_t)scratch % 16 == 0 && (!db || (uintptr_t)db % 16 == 0), "eamrl_linear_wgrad");
+    REQUIRE(scratch_floats >= linear_wgrad_scratch(rows, out_dim, in_dim), "eamrl_linear_wgrad");
+    return launched(launch_linear_wgrad(dy, ldy, x, ldx, rows, out_dim, in_dim, dW, db, scratch, (hipStream_t)stream),
+                    "eamrl_linear_wgrad");
+}
+
 __attribute__((visibility("default"))) int eamrl_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H,
                                                             void* stream)
 {

@@ -42,6 +42,11 @@ bool encoder_fused_supports(int M, int E, int H, int FFdim, int nlayers);
 int launch_encoder_fused(const float* h_in, float* h_out, int64_t B, int M, int nlayers, int norm, float eps,
                          const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache, hipStream_t st);
 int launch_pack_mfma_b(const float* W, float* Wp, int N, int K, hipStream_t st);
+// Linear weight gradient (train_gemm.hip)
+bool linear_wgrad_supports(int out_dim, int in_dim);
+int64_t linear_wgrad_scratch(int64_t rows, int out_dim, int in_dim);
+int launch_linear_wgrad(const float* dy, int64_t ldy, const float* x, int64_t ldx, int64_t rows, int out_dim, int in_dim,
+                        float* dW, float* db, float* scratch, hipStream_t st);
 // teacher-forced re-evaluation (reeval.hip)
 typedef eamrl_reeval ReevalArgs;
 bool reeval_supports(int M, int E, int H);

@@ -118,6 +118,33 @@ def matmul_right(x, Wt, out=None):
     return out
 
 
+def linear_wgrad_supported(out_dim: int, in_dim: int) -> bool:
+    return _lib.load().eamrl_linear_wgrad_scratch(0, int(out_dim), int(in_dim)) >= 0
+
+
+def linear_wgrad(dy, x, need_bias=True):
+    """dW [out, in] = dy^T x over all rows, db [out] = column sums of dy (eamrl_linear_wgrad); dy [..., out], x [..., in]."""
+    lib = _lib.load()
+    dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+    for nm, t_ in (("dy", dy2), ("x", x2)):
+        _need_gpu(t_, nm)
+        if t_.dtype != torch.float32 or t_.stride(-1) != 1:
+            raise TypeError(f"linear_wgrad: {nm} must be fp32 with unit inner stride")
+    rows, out_dim = dy2.shape
+    if x2.shape[0] != rows:
+        raise ValueError("linear_wgrad: row mismatch")
+    in_dim = x2.shape[1]
+    need = lib.eamrl_linear_wgrad_scratch(rows, out_dim, in_dim)
+    if need < 0:
+        raise ValueError(f"linear_wgrad: shape {out_dim} x {in_dim} not supported (multiples of 128)")
+    dW = torch.empty(out_dim, in_dim, dtype=torch.float32, device=dy.device)
+    db = torch.empty(out_dim, dtype=torch.float32, device=dy.device) if need_bias else None
+    scratch = torch.empty(max(int(need), 4), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.eamrl_linear_wgrad(_ptr(dy2), dy2.stride(0), _ptr(x2), x2.stride(0), rows, out_dim, in_dim, _ptr(dW), _ptr(db),
+                                      _ptr(scratch), scratch.numel(), _stream(dy)), "eamrl_linear_wgrad")
+    return dW, db
+
+
 def mha_encoder(qkv, num_heads):
     lib = _lib.load()
     _chk(qkv, "qkv", torch.float32)

@@ -55,6 +55,46 @@ class _InstanceNormFn(torch.autograd.Function):
         return dx, (dg if ctx.affine[0] else None), (db if ctx.affine[1] else None), None
 
 
+class _LinearFn(torch.autograd.Function):
+    """torch.nn.Linear (+ ReLU) of the training graph on the package's own GEMMs: forward eamrl_linear (the rollout's kernel),
+    input gradient eamrl_matmul_right, weight / bias gradient eamrl_linear_wgrad.  hipBLASLt runs these fp32 shapes
+    (rows = B * N, 128 .. 512 columns) at 29-40 TFLOP/s; the fp32-MFMA kernels here at 70-95."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, residual):
+        from . import ops
+
+        xc = x if x.stride(-1) == 1 else x.contiguous()
+        y = ops.linear(xc, weight, bias, relu=relu, residual=None if residual is None else residual.contiguous())
+        ctx.save_for_backward(xc, weight, y if relu else None)
+        ctx.relu, ctx.has_bias = relu, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+
+        x, weight, y = ctx.saved_tensors
+        g = dy.contiguous()
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0.0)
+        dx = ops.matmul_right(g, weight) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW, db = ops.linear_wgrad(g, x, need_bias=ctx.has_bias)
+        return dx, dW, db, None, (dy if ctx.needs_input_grad[4] else None)
+
+
+def _linear(x, weight, bias=None, relu=False, residual=None):
+    """[residual +] F.linear (+ F.relu) -- on the native GEMMs where they apply (CUDA fp32, both dims multiples of 128)."""
+    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_contiguous()
+            and weight.shape[0] % 128 == 0 and weight.shape[1] % 128 == 0 and os.environ.get("EAMRL_TORCH_LINEAR", "0") != "1"):
+        return _LinearFn.apply(x, weight, bias, relu, residual)
+    y = F.linear(x, weight, bias)
+    y = F.relu(y) if relu else y
+    return y if residual is None else residual + y
+
+
 def _normalize(norm: nn.Module, x: torch.Tensor, training: bool) -> torch.Tensor:
     n = norm.normalizer
     if isinstance(n, nn.BatchNorm1d):
@@ -95,13 +135,13 @@ def encode_autograd(policy, td):
         mha, ffn = layer[0].module, layer[2].module
         B, N, E = h.shape
         H = mha.num_heads
-        qkv = F.linear(h, mha.Wqkv.weight, mha.Wqkv.bias).view(B, N, 3, H, E // H).permute(2, 0, 3, 1, 4)
+        qkv = _linear(h, mha.Wqkv.weight, mha.Wqkv.bias).view(B, N, 3, H, E // H).permute(2, 0, 3, 1, 4)
         att = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).permute(0, 2, 1, 3).reshape(B, N, E)
-        h = _normalize(layer[1], h + F.linear(att, mha.out_proj.weight, mha.out_proj.bias), training)
+        h = _normalize(layer[1], _linear(att, mha.out_proj.weight, mha.out_proj.bias, residual=h), training)
         x = h
         for lin in ffn.lins[:-1]:
-            x = F.relu(F.linear(x, lin.weight, lin.bias))
-        h = _normalize(layer[3], h + F.linear(x, ffn.lins[-1].weight, ffn.lins[-1].bias), training)
+            x = _linear(x, lin.weight, lin.bias, relu=True)
+        h = _normalize(layer[3], _linear(x, ffn.lins[-1].weight, ffn.lins[-1].bias, residual=h), training)
     return h
 
 
@@ -267,7 +307,7 @@ def decoder_tensors(policy, td):
     context (encoder + `_precompute_cache` with autograd) and the decoder's own parameters.  -> dict name -> tensor."""
     dec = policy.decoder
     emb = encode_autograd(policy, td)
-    K, V, L = F.linear(emb, dec.project_node_embeddings.weight).chunk(3, dim=-1)
+    K, V, L = _linear(emb, dec.project_node_embeddings.weight).chunk(3, dim=-1)
     t = {"emb": emb, "K": K, "V": V, "L": L, "Wctx": dec.context_embedding.project_context.weight,
          "Wout": dec.pointer.project_out.weight}
     if dec.use_graph_context:
@@ -476,9 +516,9 @@ def _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip, r
     columns) as small autograd GEMMs on the decoder tensors `t`, everything per (row, step) in the HIP kernels."""
     E = t["emb"].shape[-1]
     Wctx = t["Wctx"]
-    Lp = torch.matmul(t["L"], t["Wout"])
-    Pa = F.linear(t["emb"], Wctx[:, :E])
-    Pb = F.linear(t["emb"], Wctx[:, E:2 * E]) if policy.env_name == "tsp" else None
+    Lp = _linear(t["L"], t["Wout"].t().contiguous())
+    Pa = _linear(t["emb"], Wctx[:, :E].contiguous())
+    Pb = _linear(t["emb"], Wctx[:, E:2 * E].contiguous()) if policy.env_name == "tsp" else None
     meta = replay_states(policy, td, actions, S, multistart)
     if policy.env_name == "tsp":
         cvec = F.linear(t["placeholder"][None], Wctx) if meta["placeholder"] else None            # [1, E]

@@ -148,6 +148,16 @@ int eamrl_linear_bn(const float* x, int64_t ldx, const float* W, int64_t ldw, co
 int eamrl_matmul_right(const float* x, int64_t ldx, const float* Wt, float* y, int64_t ldy, int64_t rows,
                        int in_dim, int out_dim, void* stream);
 
+/* Weight and bias gradient of torch.nn.Linear for the training graph (the encoder's and the cache projections' Linears as
+ * differentiated by loss.backward() of the REINFORCE / POMO / EAM trainers  [models/rl/reinforce/reinforce.py:62-64,103-106;
+ * zoo/pomo/model.py:103-112; zoo/earl/model.py:179-195]):  dW[o][i] = sum_r dy[r][o] x[r][i]  ([out_dim][in_dim], written,
+ * not accumulated), db[o] = sum_r dy[r][o] (or NULL).  out_dim and in_dim multiples of 128; rows of dy / x 16-byte aligned.
+ * scratch: eamrl_linear_wgrad_scratch(rows, out_dim, in_dim) floats (-1: shape not supported).  Tile-order sums (not part
+ * of the bit-exact rollout path). */
+int64_t eamrl_linear_wgrad_scratch(int64_t rows, int out_dim, int in_dim);
+int eamrl_linear_wgrad(const float* dy, int64_t ldy, const float* x, int64_t ldx, int64_t rows, int out_dim, int in_dim,
+                       float* dW, float* db, float* scratch, int64_t scratch_floats, void* stream);
+
 /* Encoder self-attention on packed qkv [B][N][3E] ("b s (three h d)"), no mask -> out [B][N][E]
  * [nn/attention.py:112-136 MultiHeadAttention.forward]. */
 int eamrl_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H, void* stream);

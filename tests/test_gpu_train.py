@@ -9,6 +9,7 @@ for line around the policy call, backpropagate, and compare with gradients recor
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from _util import cfg_for, golden, golden_weights, instance_of
 from test_gpu_parity import DEV, assert_bits_equal, make_policy, make_td, t
@@ -312,6 +313,54 @@ def test_batchnorm_train_kernel_bit_exact(oracle):
         _, mt, vt = ops.batchnorm_train_(xt, t(g), t(b), rmt, rvt, 0.1, 1e-5)
         for got, want, what in ((xt, y, "y"), (mt, m, "mean"), (vt, v, "var"), (rmt, orm, "running_mean"), (rvt, orv, "running_var")):
             assert_bits_equal(got, want, f"{what} rows={rows} E={E}")
+
+
+@pytest.mark.parametrize("rows,out_dim,in_dim,strided", [
+    (1, 128, 128, False), (15, 128, 128, False), (64, 384, 128, False), (1000, 512, 128, False), (777, 128, 512, False),
+    (6400, 384, 128, True), (102400, 128, 128, False),
+])
+def test_linear_weight_gradient_kernel_matches_torch(rows, out_dim, in_dim, strided):
+    """eamrl_linear_wgrad (fp32 MFMA over the rows, chunked, fixed-order reduction) against dy^T x in float64."""
+    from eam_rl4co_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(rows + out_dim)
+    if strided:      # operands as column slices of wider tensors (the K | V | L cache projections)
+        dy = torch.randn(rows, out_dim + 128, generator=g).to(DEV)[:, 128:]
+        x = torch.randn(rows, in_dim + 256, generator=g).to(DEV)[:, 128:128 + in_dim]
+    else:
+        dy, x = torch.randn(rows, out_dim, generator=g).to(DEV), torch.randn(rows, in_dim, generator=g).to(DEV)
+    dW, db = ops.linear_wgrad(dy, x)
+    ref_w, ref_b = dy.double().t() @ x.double(), dy.double().sum(0)
+    scale = float(ref_w.abs().max())
+    assert float((dW.double() - ref_w).abs().max()) <= 2e-6 * max(scale, 1.0) * max(1.0, rows ** 0.5 / 8)
+    assert float((db.double() - ref_b).abs().max()) <= 2e-6 * max(float(ref_b.abs().max()), 1.0) * max(1.0, rows ** 0.5 / 8)
+    dW2, none = ops.linear_wgrad(dy, x, need_bias=False)
+    assert none is None and torch.equal(dW2, dW)             # fixed-order reduction: bitwise reproducible
+    assert not ops.linear_wgrad_supported(96, 128) and ops.linear_wgrad_supported(384, 128)
+
+
+@pytest.mark.parametrize("relu,with_res", [(False, False), (True, False), (False, True)])
+def test_linear_autograd_function_matches_torch(relu, with_res):
+    from eam_rl4co_amd.train import _linear
+
+    torch.manual_seed(11)
+    x0 = torch.randn(7, 33, 128, device=DEV)
+    W0, b0 = torch.randn(512, 128, device=DEV) * 0.1, torch.randn(512, device=DEV)
+    w = torch.randn(7, 33, 512, device=DEV)
+    res = []
+    r0 = torch.randn(7, 33, 512, device=DEV)
+    for native in (True, False):
+        x, W, b = x0.clone().requires_grad_(), W0.clone().requires_grad_(), b0.clone().requires_grad_()
+        r = r0.clone().requires_grad_() if with_res else None
+        if native:
+            y = _linear(x, W, b, relu=relu, residual=r)
+        else:
+            y = F.relu(F.linear(x, W, b)) if relu else F.linear(x, W, b)
+            y = y + r if with_res else y
+        (y * w).sum().backward()
+        res.append((y.detach(), x.grad, W.grad, b.grad) + ((r.grad,) if with_res else ()))
+    for got, want in zip(res[0], res[1]):
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("cfg,env_name,N,B,ns,ms", [

@@ -113,8 +113,6 @@ def bench_train(iters):
         runner = ea.EA(env, dict(num_generations=3, mutation_rate=0.1, crossover_rate=0.6, selection_rate=0.2))
         gen = torch.Generator(device="cuda").manual_seed(5)
         td = env.reset(batch_size=[B]).to("cuda")
-        parts = {}
-
         def step():
             t0 = time.perf_counter()
             res = train.eam_loss(pol, env, td, runner, num_starts=S, generator=gen)
@@ -123,19 +121,18 @@ def bench_train(iters):
             res["loss"].backward()
             opt.step()
             torch.cuda.synchronize(); t2 = time.perf_counter()
-            parts["forward (rollout + EA + re-evaluation)"] = parts.get("forward (rollout + EA + re-evaluation)", 0) + t1 - t0
-            parts["backward + Adam"] = parts.get("backward + Adam", 0) + t2 - t1
+            return (t1 - t0) * 1e3, (t2 - t1) * 1e3
 
         for _ in range(4):          # the first steps pay one-time costs (library tuning of the new shapes, Adam state)
             step()
-        parts.clear()
-        n = max(3, iters // 4)
-        for _ in range(n):
-            step()
-        tot = sum(parts.values()) / n * 1e3
+        # median of the steps: the evolved tours change the step count T from step to step, and a first-seen shape pays a
+        # one-time allocation / library set-up (tens of ms) that a mean over a few steps would smear over them
+        ts = sorted((step() for _ in range(max(9, iters // 2))), key=lambda p: p[0] + p[1])
+        fwd, bwd = ts[len(ts) // 2]
+        tot = fwd + bwd
         print(f"EAM training step {env_name}{N} B={B} S={S} (POMO policy): {tot:8.1f} ms  "
-              + "  ".join(f"{k} {v / n * 1e3:.1f} ms" for k, v in parts.items())
-              + f"  = {B * S * N / tot * 1e3 / 1e6:.1f} M sampled env-steps/s incl. the update")
+              f"forward (rollout + EA + re-evaluation) {fwd:.1f} ms  backward + Adam {bwd:.1f} ms"
+              f"  = {B * S * N / tot * 1e3 / 1e6:.1f} M sampled env-steps/s incl. the update (median of {len(ts)} steps)")
 
 
 def main():
