@@ -302,9 +302,47 @@ _STATE_KEYS = {"cvrp": ("demand", "vehicle_capacity"), "sdvrp": ("demand", "vehi
                "op": ("locs", "max_length"), "pctsp": ("real_prize", "prize_required"), "tsp": ()}
 
 
+class shared_decoder_tensors:
+    """Within this context, re-evaluations of the SAME instances under the SAME parameters share one differentiable
+    encoder pass (`decoder_tensors`): the EAM step evaluates the sampled and the improved tours of a batch one after the
+    other (zoo/earl/model.py:179-195 runs the whole policy, encoder included, twice), and both losses are summed before
+    the one backward -- so one encoder graph serves both, with identical gradients up to summation order.  Opt-in,
+    because a graph that has already been backpropagated through cannot serve a second backward."""
+
+    def __init__(self, policy):
+        self.policy = policy
+
+    def __enter__(self):
+        self.policy._shared_dt = {}
+        return self
+
+    def __exit__(self, *exc):
+        self.policy._shared_dt = None
+        return False
+
+
+def _graph_key(policy, td):
+    """Identity of (instances, parameters, mode): storage address, in-place version and shape of every input tensor, the sums
+    of the same over the parameters (an optimizer step or load_state_dict changes them) and, in eval mode, the buffers (the
+    running statistics of batch norm are read only then; in train mode every native rollout updates them in place)."""
+    ins = tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in sorted(td.items(), key=lambda kv: kv[0])
+                if torch.is_tensor(v))
+    ver = ptr = 0
+    for p_ in list(policy.parameters()) + ([] if policy.training else list(policy.buffers())):
+        ver += p_._version
+        ptr += p_.data_ptr()
+    return ins, ver, ptr, policy.training, torch.is_grad_enabled()
+
+
 def decoder_tensors(policy, td):
     """The differentiable tensors the decode steps read: node embeddings, glimpse key / value, logit key, graph
     context (encoder + `_precompute_cache` with autograd) and the decoder's own parameters.  -> dict name -> tensor."""
+    shared = getattr(policy, "_shared_dt", None)
+    key = None
+    if shared is not None:
+        key = _graph_key(policy, td)
+        if key in shared:
+            return shared[key]
     dec = policy.decoder
     emb = encode_autograd(policy, td)
     K, V, L = _linear(emb, dec.project_node_embeddings.weight).chunk(3, dim=-1)
@@ -316,6 +354,9 @@ def decoder_tensors(policy, td):
         t["placeholder"] = dec.context_embedding.W_placeholder
     if policy.env_name == "sdvrp":
         t["dyn"] = dec.dynamic_embedding.projection.weight
+    if shared is not None:
+        shared.clear()              # one entry: the step's instances
+        shared[key] = t
     return t
 
 
@@ -625,10 +666,15 @@ def eam_loss(policy, env, td, ea, num_starts: int, improve: bool = True, draws=N
        treated as 2B instances (model.py:226-244, reinforce.py:103-106).
 
     Returns dict(loss, reward, improved_reward, log_likelihood, improved_log_likelihood, actions, improved_actions)."""
-    from .evolution import evolution_worker
-
     S = int(num_starts)
     assert S > 1, "the EAM step uses the multistart (shared) baseline"
+    with shared_decoder_tensors(policy):        # one differentiable encoder pass for the sampled and the improved tours
+        return _eam_loss(policy, env, td, ea, S, improve, draws, generator)
+
+
+def _eam_loss(policy, env, td, ea, S, improve, draws, generator):
+    from .evolution import evolution_worker
+
     with torch.enable_grad():
         out = policy(td, env, phase="train", decode_type="multistart_sampling", num_starts=S)
     actions, reward, ll = out["actions"], out["reward"], out["log_likelihood"]

@@ -222,12 +222,24 @@ def test_eam_shared_step_restated_runs_on_the_policy(env_name, cfg, N):
         return orig_forward(td_, env_, **kw)
 
     pol2.forward = with_noise
+    calls, enc = [], train.encode_autograd
+    train.encode_autograd = lambda *a, **k: (calls.append(1), enc(*a, **k))[1]
     try:
         res = train.eam_loss(pol2, env, td.clone(), runner, num_starts=S, generator=gen)
     finally:
         pol2.forward = orig_forward
+        train.encode_autograd = enc
     assert torch.equal(res["improved_actions"], improved_actions)
     np.testing.assert_allclose(float(res["loss"].detach()), float(loss.detach()), rtol=1e-6)
+    # ... in which the sampled and the improved tours share ONE differentiable encoder pass (train.shared_decoder_tensors):
+    # same gradients as the two separate graphs above
+    assert len(calls) == 1 and pol2._shared_dt is None
+    res["loss"].backward()
+    gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
+    for k, p_ in pol2.named_parameters():
+        if k in grads:
+            rel = float((p_.grad.double() - grads[k].double()).norm()) / max(float(grads[k].double().norm()), 1e-2 * gnorm)
+            assert rel <= 1e-4, (k, rel)
 
 
 @pytest.mark.parametrize("cfg,env_name,ns", [("am_tsp", "tsp", 0), ("am_cvrp", "cvrp", 0), ("am_cvrp", "cvrp", 5),
