@@ -764,7 +764,19 @@ class AttentionModelPolicy(nn.Module):
         if isinstance(self.encoder, AttentionModelEncoder) and isinstance(self.decoder, AttentionModelDecoder):
             Bq, Mq = td["action_mask"].shape
             spec = self.decoder._fused_cache_spec(Bq, Mq, td["action_mask"].device)
-        hidden, init_embeds = self.encoder(td, cache_spec=spec) if spec is not None else self.encoder(td)
+        shared, ekey, ent = getattr(self, "_shared_dt", None), None, None
+        if shared is not None and spec is not None:     # train.shared_decoder_tensors: same instances, same parameters
+            from .train import _graph_key
+
+            ekey = _graph_key(self, td)
+            ent = shared.get("native")
+            ent = ent if ent is not None and ent[0] == ekey else None
+        if ent is not None:
+            hidden, init_embeds, spec = ent[1:]
+        else:
+            hidden, init_embeds = self.encoder(td, cache_spec=spec) if spec is not None else self.encoder(td)
+            if ekey is not None and spec.get("filled"):
+                shared["native"] = (ekey, hidden, init_embeds, spec)
         cache = self.decoder._precompute_cache(hidden, num_starts=S, prefilled=spec)
 
         # pre-decoder hook (decoding.py:284-332): multistart picks the first node, state replicated S times

@@ -303,8 +303,8 @@ _STATE_KEYS = {"cvrp": ("demand", "vehicle_capacity"), "sdvrp": ("demand", "vehi
 
 
 class shared_decoder_tensors:
-    """Within this context, re-evaluations of the SAME instances under the SAME parameters share one differentiable
-    encoder pass (`decoder_tensors`): the EAM step evaluates the sampled and the improved tours of a batch one after the
+    """Within this context, policy calls on the SAME instances under the SAME parameters share one differentiable
+    encoder pass (`decoder_tensors`) and one native encoder + cache launch (`AttentionModelPolicy._enqueue`): the EAM step evaluates the sampled and the improved tours of a batch one after the
     other (zoo/earl/model.py:179-195 runs the whole policy, encoder included, twice), and both losses are summed before
     the one backward -- so one encoder graph serves both, with identical gradients up to summation order.  Opt-in,
     because a graph that has already been backpropagated through cannot serve a second backward."""
@@ -341,8 +341,9 @@ def decoder_tensors(policy, td):
     key = None
     if shared is not None:
         key = _graph_key(policy, td)
-        if key in shared:
-            return shared[key]
+        ent = shared.get("graph")
+        if ent is not None and ent[0] == key:
+            return ent[1]
     dec = policy.decoder
     emb = encode_autograd(policy, td)
     K, V, L = _linear(emb, dec.project_node_embeddings.weight).chunk(3, dim=-1)
@@ -355,8 +356,7 @@ def decoder_tensors(policy, td):
     if policy.env_name == "sdvrp":
         t["dyn"] = dec.dynamic_embedding.projection.weight
     if shared is not None:
-        shared.clear()              # one entry: the step's instances
-        shared[key] = t
+        shared["graph"] = (key, t)
     return t
 
 

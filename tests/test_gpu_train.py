@@ -380,6 +380,9 @@ def test_linear_autograd_function_matches_torch(relu, with_res):
     ("pomo_tsp", "tsp", 50, 4, 50, None), ("pomo_tsp", "tsp", 100, 3, 10, None), ("am_tsp", "tsp", 112, 2, 0, None),
     ("am_cvrp", "cvrp", 20, 5, 0, None), ("am_cvrp", "cvrp", 50, 3, 6, None), ("am_cvrp", "cvrp", 100, 2, 3, None),
     ("am_pctsp", "pctsp", 20, 4, 0, None), ("am_op", "op", 20, 4, 4, None), ("am_cvrptw", "cvrptw", 20, 4, 0, None),
+    # the gather kernel's cooperative bins (the depot of CVRP names > 512 queries of an instance) and its own chunking
+    # (more than 24,576 queries of an instance: 250 samples x 100 steps)
+    ("am_cvrp", "cvrp", 50, 2, 50, None), ("am_tsp", "tsp", 100, 1, 250, False),
 ])
 def test_native_reevaluation_matches_autograd(cfg, env_name, N, B, ns, ms):
     """eamrl_reeval_forward / _backward (fp32 MFMA kernels) against the PyTorch-autograd re-evaluation of the same actions:
