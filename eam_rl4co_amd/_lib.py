@@ -42,7 +42,8 @@ class Reeval(C.Structure):
                 ("idxA", _vp), ("idxB", _vp), ("sc", _vp), ("maskbits", _vp), ("actions", _vp),
                 ("B", _i64), ("R", _i64), ("S", C.c_int32), ("T", C.c_int32), ("M", C.c_int32), ("tstart", C.c_int32),
                 ("nchunk", C.c_int32), ("clip", _f32), ("temp", _f32),
-                ("logp", _vp), ("lse", _vp), ("glogp", _vp), ("dheads", _vp), ("entropy", _vp),
+                ("logp", _vp), ("lse", _vp), ("glogp", _vp), ("dheads", _vp), ("heads", _vp), ("heads_T", C.c_int32),
+                ("entropy", _vp),
                 ("dK", _vp), ("dV", _vp), ("dLp", _vp), ("dPa", _vp), ("dPb", _vp), ("ldg", _i64),
                 ("dgctx", _vp), ("dCvec", _vp)]
 
@@ -51,7 +52,7 @@ class State(C.Structure):
     """struct eamrl_state"""
     _fields_ = [("first", _vp), ("cur", _vp), ("istep", _vp), ("used", _vp), ("vcap", _vp), ("demand", _vp),
                 ("mask", _vp), ("visited", _vp), ("done", _vp), ("rem", _vp), ("locs", _vp),
-                ("time", _vp), ("tw", _vp), ("dur", _vp)]
+                ("time", _vp), ("tw", _vp), ("dur", _vp), ("heads_out", _vp)]
 
 
 # name -> argtypes (all return int unless listed in _RESTYPES); mirrors include/eamrl.h one to one

@@ -326,6 +326,7 @@ static int check_reeval(const eamrl_reeval* p, const char* what, bool bwd)
         REQUIRE((p->Pb == nullptr) == (p->dPb == nullptr) && (p->gctx == nullptr) == (p->dgctx == nullptr) &&
                     (p->NC == 0 || p->dCvec) && ((uintptr_t)p->dheads % 16 == 0), what);
         REQUIRE(p->NC <= 2 && p->R * (int64_t)p->T < (int64_t)1 << 31, what);     // the backward kernels' query indices
+        REQUIRE(!p->heads || (p->heads_T > 0 && (uintptr_t)p->heads % 16 == 0), what);
     }
     return 0;
 }
@@ -433,6 +434,7 @@ static int fill_args(const char* what, int env, const eamrl_cache* c, const eamr
     a.first = s->first; a.cur = s->cur; a.istep = s->istep; a.used = s->used; a.vcap = s->vcap; a.demand = s->demand;
     a.mask = s->mask; a.visited = s->visited; a.done = s->done;
     a.rem = s->rem; a.dyn = c->dyn; a.locs = s->locs; a.time = s->time; a.tw = s->tw; a.dur = s->dur;
+    a.heads_out = s->heads_out;
     a.seed = 0; a.seed_dev = nullptr; a.use_rng = 0;
     a.R = R; a.mode = mode; a.noise = noise; a.given = given; a.clip = clip; a.temp = temp; a.top_k = top_k; a.top_p = top_p; a.status = status;
     return 0;
@@ -502,7 +504,7 @@ __attribute__((visibility("default"))) int eamrl_rollout_rng_native(int env, con
     if (!cache_host || R <= 0 || g_debug[11]) return 0;
     DecArgs a{};
     a.B = cache_host->B; a.M = cache_host->M; a.E = cache_host->E; a.H = cache_host->H; a.ld = cache_host->ld; a.R = R;
-    return rollout_ms_mfma_supports(env, a) ? 1 : 0;
+    return rollout_ms_mfma_supports(env, a, true) ? 1 : 0;
 }
 
 __attribute__((visibility("default"))) int eamrl_am_rollout_seeded(int env, const eamrl_cache* cache_host,

@@ -25,6 +25,7 @@ struct DecArgs {
     int top_k; float top_p;      // process_logits filtering (0 = off); handled by the step / streaming kernels
     int64_t* action; float* logp; float* logprobs_all; float* logits_raw;
     int32_t* steps_out; uint32_t* status;
+    float* heads_out;   // optional [R][t_max][E]: the glimpse output of every decode step (start-sharing MFMA kernel only)
 };
 
 // LDS carve for one row handled by one workgroup.

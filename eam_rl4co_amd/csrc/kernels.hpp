@@ -96,7 +96,7 @@ int launch_rollout_stream(int env, const DecArgs& a, hipStream_t st);
 void launch_rollout_pad(int env, const DecArgs& a, hipStream_t st);   // final state of rows that finished early
 int launch_rollout_resident(int env, const DecArgs& a, hipStream_t st);
 bool rollout_resident_supports(int env, const DecArgs& a);
-bool rollout_ms_mfma_supports(int env, const DecArgs& a);
+bool rollout_ms_mfma_supports(int env, const DecArgs& a, bool shape_only = false);
 int launch_rollout_ms_mfma(int env, const DecArgs& a, hipStream_t st);
 int launch_exp1_noise(uint64_t seed, const uint64_t* seed_dev, float* noise, int64_t R, int T, int M, hipStream_t st);
 int launch_ea_tsp(const float* locs, int64_t* pop, float* fitness, int64_t B, int S, int N, int G, double mutation_rate,

@@ -416,7 +416,7 @@ __device__ __forceinline__ uint4 load_mask_words(const ReevalArgs& a, int qi)
     return qi >= 0 ? m : make_uint4(0, 0, 0, 0);
 }
 
-template <int RTT>
+template <int RTT, bool HEADS>
 __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
     const bool derive_lse = a.lse == nullptr;
 
     float kf[RTT][4], vtf[4 * RTT], lpf[32];
-    load_head_frags<RTT>(a, b, wv, lane, kf, vtf);
+    if (!HEADS) load_head_frags<RTT>(a, b, wv, lane, kf, vtf);
     load_lp_frags(a, b, wv < RTT ? wv : RTT - 1, lane, lpf);       // (wave 7 of RTT = 7 computes no logits)
     float4* lpt = reinterpret_cast<float4*>(LPT) + wv * RTT * 64 + lane;
 #pragma unroll
@@ -463,21 +463,40 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
 
     // query index r * T + t as a 32-bit value (R * T < 2^31 is checked by the caller), -1 past the chunk's end
     auto qi_of = [&](const QWalk& w) -> int { return w.sl < ns ? ((s0 + w.sl) * (int)a.B + (int)b) * T + w.t : -1; };
+    // HEADS: the rollout kept every step's glimpse output (eamrl_state.heads_out) -- the tile's heads rows are fetched
+    // instead of the query rows and nothing of the glimpse is recomputed
+    auto load_heads = [&](const QWalk& w, RowPre& p) {
+        const int qi = qi_of(w);
+        const int64_t r = (int64_t)(s0 + min(w.sl, ns - 1)) * a.B + b;
+        const int th = max(w.t - a.tstart, 0);
+        p.fl = (qi >= 0 ? 1 : 0) | (w.t >= a.tstart && th < a.heads_T ? 8 : 0);
+        p.dh = *reinterpret_cast<const float4*>(a.heads + (r * a.heads_T + min(th, a.heads_T - 1)) * RE + 4 * e4);
+    };
+    auto stage_heads = [&](const RowPre& p, int buf) {
+        const bool ok = (p.fl & 9) == 9;
+        float* dp = HTB + buf * 16 * TS + jq * TS + e4;
+        dp[0] = ok ? p.dh.x : 0.0f; dp[TG] = ok ? p.dh.y : 0.0f; dp[2 * TG] = ok ? p.dh.z : 0.0f; dp[3 * TG] = ok ? p.dh.w : 0.0f;
+    };
     // ---- prologue: tile 0 staged, indices of tile 1 in flight --------------------------------------------------------
     QWalk wr, wj;                       // the staging role (query jq) and the MFMA role (query j) of this thread
     wr.init(jq, T);
     wj.init(j, T);
-    int qr = qi_of(wr), ia, ib;
-    load_idx(a, qr, ia, ib);
+    int qr = qi_of(wr), ia = -1, ib = -1;
     {
         RowPre pre;
-        load_rows<false>(a, b, e4, qr, wr.t, ia, ib, pre);
-        __syncthreads();                // CV
-        stage_rows<false>(pre, gc, CV, QTB, nullptr, jq, e4);
+        if (HEADS) {
+            load_heads(wr, pre);
+            stage_heads(pre, 0);
+        } else {
+            load_idx(a, qr, ia, ib);
+            load_rows<false>(a, b, e4, qr, wr.t, ia, ib, pre);
+            __syncthreads();            // CV
+            stage_rows<false>(pre, gc, CV, QTB, nullptr, jq, e4);
+        }
     }
     wr.next(T);
     qr = qi_of(wr);
-    load_idx(a, qr, ia, ib);            // tile 1
+    if (!HEADS) load_idx(a, qr, ia, ib);    // tile 1
     int qj = qi_of(wj), tj = wj.t;      // tile 0
     uint4 mb = load_mask_words(a, qj);
 
@@ -491,10 +510,15 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
         int qjn = qj, tjn = tj;
         if (tile >= 0) {
             RowPre pre;
-            load_rows<false>(a, b, e4, qr, wr.t, ia, ib, pre);      // rows of tile + 1 (indices fetched one iteration ago)
-            wr.next(T);
-            qr = qi_of(wr);
-            load_idx(a, qr, ia, ib);                                // indices of tile + 2
+            if (HEADS) {
+                load_heads(wr, pre);                                // heads rows of tile + 1
+                wr.next(T);
+            } else {
+                load_rows<false>(a, b, e4, qr, wr.t, ia, ib, pre);  // rows of tile + 1 (indices fetched one iteration ago)
+                wr.next(T);
+                qr = qi_of(wr);
+                load_idx(a, qr, ia, ib);                            // indices of tile + 2
+            }
             const int qjc = max(qj, 0);
             const bool live = qj >= 0 && tj >= a.tstart;
             const int act_l = (int)a.actions[qjc];
@@ -537,7 +561,8 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
                     DU[(n0 + G) * DS + j] = du;
                 }
             }
-            stage_rows<false>(pre, gc, CV, QTB + nxt * 16 * TS, nullptr, jq, e4);
+            if (HEADS) stage_heads(pre, nxt);
+            else stage_rows<false>(pre, gc, CV, QTB + nxt * 16 * TS, nullptr, jq, e4);
             __syncthreads();            // du of this tile and q~ of the next one visible
             // wave wv: embedding columns 16 wv .. 16 wv + 15
             f32x4 dh = z4();
@@ -563,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
             __syncthreads();            // q~ of tile 0 visible
         }
         mb = mbn; qj = qjn; tj = tjn;
-        if (tile + 1 < ntiles) glimpse_tile<RTT>(kf, vtf, QTB + nxt * 16 * TS, HTB + nxt * 16 * TS, wv, lane, mb, a.M);
+        if (!HEADS && tile + 1 < ntiles) glimpse_tile<RTT>(kf, vtf, QTB + nxt * 16 * TS, HTB + nxt * 16 * TS, wv, lane, mb, a.M);
     }
     // dLp: lane (column 16 wv + j, G), register r -> key 16 nt + 4 G + r
 #pragma unroll
@@ -877,7 +902,7 @@ static int launch_bwd_t(const ReevalArgs& a, hipStream_t st)
 {
     const unsigned grid = (unsigned)(a.B * a.nchunk);
     const size_t ldl = (4 * 16 * (size_t)TS + 8 * RTT * 256 + 2 * RE + 16 * RTT * DS + 16) * sizeof(float);
-    auto kl = k_reeval_bwd_logits<RTT>;
+    auto kl = a.heads ? k_reeval_bwd_logits<RTT, true> : k_reeval_bwd_logits<RTT, false>;
     if (ldl > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldl) != hipSuccess)
         return EAMRL_E_LAUNCH;

@@ -304,8 +304,17 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 }
                 // lane (query j, G), register r -> head column e = 4 G + r -> A layout (g = r, t = 4 wv + G)
                 float* hp = HT + j * TS + 4 * wv + G;
+                float hv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hp[r * TG] = tot_o[r] / tot_z;
+                for (int r = 0; r < 4; ++r) {
+                    hv[r] = tot_o[r] / tot_z;
+                    hp[r * TG] = hv[r];
+                }
+                if (a.heads_out && sq < S) {     // training: keep the step's glimpse output for the backward (zeros for a done row)
+                    const int64_t row = (int64_t)sq * a.B + b;
+                    *reinterpret_cast<float4*>(a.heads_out + (row * a.t_max + t) * 128 + 16 * wv + 4 * G) =
+                        live ? make_float4(hv[0], hv[1], hv[2], hv[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             MSTAMP(4);
             __syncthreads();
@@ -547,6 +556,13 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
 #endif
     // ---- final state -------------------------------------------------------------------------------------------------------------
     __syncthreads();
+    if (a.heads_out) {          // the steps this instance did not take: zeros (the caller's buffer is not initialised)
+        const int per = (a.t_max - t) * 32;              // float4 per row
+        for (int s = s_lo; s < s_hi; ++s) {
+            float4* hz = reinterpret_cast<float4*>(a.heads_out + (((int64_t)s * a.B + b) * a.t_max + t) * 128);
+            for (int i = tid; i < per; i += blockDim.x) hz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     for (int s = s_lo + tid; s < s_hi; s += blockDim.x) {
         const int64_t r = (int64_t)s * a.B + b;
         for (int n = 0; n < M; ++n) a.mask[r * M + n] = (s_bits[s][n >> 5] >> (n & 31)) & 1u;
@@ -607,10 +623,11 @@ extern "C" __attribute__((visibility("default"))) int eamrl_debug_read_ms_stamps
 }
 #endif
 
-bool rollout_ms_mfma_supports(int env, const DecArgs& a)
+// shape_only: the question eamrl_rollout_rng_native asks before the state exists (cache shape and row count alone)
+bool rollout_ms_mfma_supports(int env, const DecArgs& a, bool shape_only)
 {
     if ((env != EAMRL_ENV_TSP && env != EAMRL_ENV_CVRP) || a.E != ME || a.H != MH || a.M < 2 || a.M > 112 || a.ld % 4 != 0) return false;
-    if (env == EAMRL_ENV_CVRP && (g_debug[14] || !a.visited || !a.used || !a.vcap || !a.demand)) return false;
+    if (env == EAMRL_ENV_CVRP && (g_debug[14] || (!shape_only && (!a.visited || !a.used || !a.vcap || !a.demand)))) return false;
     if (a.R % a.B != 0) return false;
     const int64_t S = a.R / a.B;
     return S >= 2 && S <= SMAX && a.top_k == 0 && !(a.top_p > 0.0f && a.top_p < 1.0f);

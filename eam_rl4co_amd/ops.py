@@ -371,7 +371,7 @@ class ReevalPlan:
     None; idxA / idxB int32 [R, T]; sc [NC, R, T]; maskbits int32 [R, T, 4]; actions int64 [R, T]."""
 
     def __init__(self, buf, has_pb, gctx, cvec, idxA, idxB, sc, maskbits, actions, S, tstart, clip, temp, rollout_logp=None,
-                 slots=None, E=None, want_entropy=False):
+                 slots=None, E=None, want_entropy=False, rollout_heads=None):
         _chk(buf, "operands", torch.float32)
         # slots: {"K", "V", "Lp", "Pa"[, "Pb"]} -> E-wide column block of buf (default: side by side in that order); with it
         # the plan reads a decoder cache (ops.DecodeCache.buf) in place
@@ -400,6 +400,15 @@ class ReevalPlan:
         self.nchunk = max(1, min(self.S, -(-512 // self.B)))
         # rollout_logp [R, T]: the per-step log-probs the rollout kernel produced for exactly these actions.  Then no
         # forward pass is needed for the gradient: forward() hands them back and the backward recovers the normaliser.
+        # rollout_heads [R, Th, E]: every decode step's glimpse output as the rollout kernel computed it (RolloutState.heads):
+        # the backward reads them instead of recomputing the glimpse (row r, step t at [r, t - tstart])
+        self.heads = None
+        if rollout_heads is not None:
+            _chk(rollout_heads, "rollout heads", torch.float32)
+            if rollout_heads.dim() != 3 or rollout_heads.shape[0] != R or rollout_heads.shape[2] != self.E \
+                    or rollout_heads.shape[1] < T - int(tstart):
+                raise ValueError("reeval: rollout heads must be [R, >= T - tstart, E]")
+            self.heads = rollout_heads
         if rollout_logp is not None:
             _chk(rollout_logp, "rollout log-probs", torch.float32, (R, T))
             self.logp, self.lse = rollout_logp, None
@@ -449,6 +458,8 @@ class ReevalPlan:
         E4 = self.E * 4
         base = dbuf.data_ptr()
         s.glogp, s.dheads = _ptr(glogp), _ptr(dheads)
+        if self.heads is not None:
+            s.heads, s.heads_T = _ptr(self.heads), self.heads.shape[1]
         s.dK, s.dV, s.dLp, s.dPa = (C.c_void_p(base + i * E4) for i in range(4))
         s.dPb = C.c_void_p(base + 4 * E4) if self.has_pb else None
         s.ldg = dbuf.shape[2]
@@ -1012,6 +1023,7 @@ class RolloutState:
         s.rem = _ptr(getattr(self, "rem", None))
         s.locs = _ptr(getattr(self, "locs", None))
         s.time, s.tw, s.dur = (_ptr(getattr(self, k, None)) for k in ("time", "tw", "dur"))
+        s.heads_out = _ptr(getattr(self, "heads_out", None))       # [R, t_max, E] or None (eamrl_state.heads_out)
         return s
 
 
@@ -1100,8 +1112,16 @@ def _rollout_outputs(R, t_max, dev):
     return actions, logps, flags
 
 
+def _capture_heads(st, cache, cs, R, t_max, want_heads):
+    """Training: a [R, t_max, E] buffer for the steps' glimpse outputs where the kernel chosen for this shape writes it
+    (eamrl_state.heads_out; st.heads afterwards, None otherwise)."""
+    st.heads = st.heads_out = None
+    if want_heads and _lib.load().eamrl_rollout_rng_native(ENVS[st.env_name], C.byref(cs), R):
+        st.heads = st.heads_out = torch.empty(R, int(t_max), cache.E, dtype=torch.float32, device=st.mask.device)
+
+
 def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0,
-            t_max=None, top_k=0, top_p=0.0, seed=None, seed_dev=None, return_flags=False):
+            t_max=None, top_k=0, top_p=0.0, seed=None, seed_dev=None, return_flags=False, want_heads=False):
     """Whole decode loop in one launch.  -> (actions [R,t_max], logps [R,t_max], info int32[2] = (steps, status)).
     Sampling takes its Exp(1) noise from `noise` [R, T, M] or, with `seed` (XOR the device word `seed_dev`), from the counter-based
     generator -- in place where the kernel supports it (TSP multistart), else through a scratch tensor of the same draws.
@@ -1118,7 +1138,10 @@ def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, giv
             noise = exp1_noise(seed, R, int(t_max), M, dev, seed_dev)      # the filtering (streaming) kernel reads a tensor
         else:
             actions, logps, info = _rollout_outputs(R, int(t_max), dev)
-            cs, ss = cache.struct(), st.struct()
+            cs = cache.struct()
+            _capture_heads(st, cache, cs, R, t_max, want_heads)
+            ss = st.struct()
+            st.heads_out = None
             native = lib.eamrl_rollout_rng_native(ENVS[st.env_name], C.byref(cs), R)
             scratch = None if native else torch.empty(R, t_max, M, dtype=torch.float32, device=dev)
             _lib.check(lib.eamrl_am_rollout_seeded(ENVS[st.env_name], C.byref(cs), C.byref(ss), R,
@@ -1145,7 +1168,10 @@ def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, giv
         if noise is None:
             t_max = min(t_max, t_given) if st.env_name != "tsp" else t_max
     actions, logps, info = _rollout_outputs(R, int(t_max), dev)          # info: [steps, status, -, -]
-    cs, ss = cache.struct(), st.struct()
+    cs = cache.struct()
+    _capture_heads(st, cache, cs, R, t_max, want_heads and not (top_k or (0.0 < top_p < 1.0)))
+    ss = st.struct()
+    st.heads_out = None
     steps_ptr = C.c_void_p(info.data_ptr())
     status_ptr = C.c_void_p(info.data_ptr() + 4)
     _lib.check(lib.eamrl_am_rollout(ENVS[st.env_name], C.byref(cs), C.byref(ss), R, MODES[mode], _ptr(noise),

@@ -665,6 +665,7 @@ class AttentionModelPolicy(nn.Module):
         test phases run under no_grad in the reference's trainers and are not re-evaluated here."""
         want_grad = (torch.is_grad_enabled() and phase == "train" and not torch.is_inference_mode_enabled()
                      and any(q.requires_grad for q in self.parameters()))
+        self._want_heads = want_grad and os.environ.get("EAMRL_REEVAL_RECOMPUTE_HEADS", "0") != "1"
         with torch.no_grad():
             p = self._enqueue(td, env, phase, calc_reward, return_actions, return_entropy, return_hidden,
                               return_init_embeds, return_sum_log_likelihood, actions, max_steps, **decoding_kwargs)
@@ -685,9 +686,10 @@ class AttentionModelPolicy(nn.Module):
         fl = p.get("final_logp")
         if fl is not None and (fl.shape != p["final_actions"].shape or os.environ.get("EAMRL_REEVAL_FORWARD", "0") == "1"):
             fl = None
+        fh = p.get("final_heads") if fl is not None else None       # (heads are only used together with the rollout's log-probs)
         re = evaluate_log_likelihood(self, p["td"], p["env"], p["final_actions"], num_starts=p["S"],
                                      multistart=bool(p["pre"]), temperature=p["temperature"],
-                                     tanh_clipping=p["tanh_clipping"], rollout_logp=fl)
+                                     tanh_clipping=p["tanh_clipping"], rollout_logp=fl, rollout_heads=fh)
         td_mask = p["td"].get("mask", None) if hasattr(p["td"], "get") else None
         if td_mask is not None:
             re = re.masked_fill(~td_mask, 0)
@@ -827,9 +829,11 @@ class AttentionModelPolicy(nn.Module):
                                                                     temperature, t_max, top_k, top_p)
             info = None
         else:
+            # training (multistart): the start-sharing kernel also keeps every step's glimpse output for the backward
             acts, lps, info = ops.rollout(st, cache, mode, noise=noise, given=given, clip=tanh_clipping,
                                           temp=temperature, t_max=t_max, top_k=top_k, top_p=top_p, seed=seed, seed_dev=seed_dev,
-                                          return_flags=True)          # int32[4]: steps, status, 2 free validity counters
+                                          return_flags=True,          # int32[4]: steps, status, 2 free validity counters
+                                          want_heads=bool(getattr(self, "_want_heads", False)) and bool(pre_actions))
         # Everything below is enqueued on the PADDED [R, t_max] arrays before the rollout's single host sync:
         # padding is depot visits with log-prob 0, which change neither the tour length (zero-length legs, and
         # x + 0 is exact in the lane tree), nor the log-likelihood sum, nor validity.
@@ -878,7 +882,7 @@ class AttentionModelPolicy(nn.Module):
                     actions_pad=actions_pad, logp_pad=logp_pad, reward_pad=reward_pad, ll_pad=ll_pad,
                     all_logp=all_logp, entropy_native=entropy_native, init_embeds=init_embeds, return_actions=return_actions,
                     return_entropy=return_entropy, return_hidden=return_hidden, return_init_embeds=return_init_embeds,
-                    return_sum_log_likelihood=return_sum_log_likelihood)
+                    return_sum_log_likelihood=return_sum_log_likelihood, final_heads=getattr(st, "heads", None))
 
     def _finish(self, p: dict) -> dict:
         vals = p["flags"].tolist()               # the rollout's single device->host sync

@@ -537,7 +537,7 @@ class _NativeReeval(torch.autograd.Function):
         plan = ops.ReevalPlan(buf, Pb is not None, None if gctx is None else gctx.detach().contiguous(),
                               None if cvec is None else cvec.detach().contiguous(), meta["idxA"], meta["idxB"], meta["sc"],
                               meta["maskbits"], meta["actions"], meta["S"], meta["tstart"], meta["clip"], meta["temp"],
-                              rollout_logp=meta.get("rollout_logp"))
+                              rollout_logp=meta.get("rollout_logp"), rollout_heads=meta.get("rollout_heads"))
         ctx.plan = plan
         ctx.has = (Pb is not None, gctx is not None, cvec is not None)
         return plan.forward()
@@ -552,7 +552,7 @@ class _NativeReeval(torch.autograd.Function):
                 dc if ctx.has[2] else None, None)
 
 
-def _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip, rollout_logp=None):
+def _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip, rollout_logp=None, rollout_heads=None):
     """Differentiable log-probs [R, T]: the weight folds (Lp = L Wout, Pa / Pb = emb x halves of project_context, state
     columns) as small autograd GEMMs on the decoder tensors `t`, everything per (row, step) in the HIP kernels."""
     E = t["emb"].shape[-1]
@@ -568,11 +568,14 @@ def _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip, r
     meta.update(actions=actions.contiguous(), S=S, clip=float(clip), temp=float(temperature))
     if rollout_logp is not None:
         meta["rollout_logp"] = rollout_logp.detach().to(torch.float32).contiguous()
+        if rollout_heads is not None:           # the rollout kernel's glimpse outputs of these very steps: not recomputed
+            meta["rollout_heads"] = rollout_heads.detach()
     return _NativeReeval.apply(t["K"], t["V"], Lp, Pa, Pb, t.get("gctx"), cvec, meta)
 
 
 def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, temperature=None, tanh_clipping=None,
-                            chunk_rows: int = 4096, multistart=None, checkpoint=None, native=None, rollout_logp=None):
+                            chunk_rows: int = 4096, multistart=None, checkpoint=None, native=None, rollout_logp=None,
+                            rollout_heads=None):
     """Differentiable per-step log-probabilities of `actions` [R, T] (R = B or S*B rows in (s b) order).  native
     (default: where supported -- TSP / CVRP / PCTSP / OP / CVRPTW, graphs up to 112 nodes): forward and backward of the
     decode steps run in the HIP re-evaluation kernels; otherwise (and as the cross-check) PyTorch autograd ops.  multistart
@@ -595,7 +598,7 @@ def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, tempe
     if native is None:
         native = native_reeval_supported(policy, M)
     if native:
-        return _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip, rollout_logp)
+        return _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip, rollout_logp, rollout_heads)
     static = {k: td[k] for k in _STATE_KEYS[env_name]}
     # rows are processed in chunks of whole start-groups so that memory stays bounded ([rows, H, T, M] scores)
     starts_per_chunk = max(1, chunk_rows // B)

@@ -277,6 +277,9 @@ typedef struct eamrl_reeval {
                                                              * lse == NULL (no forward pass run), logp = the ROLLOUT's per-step
                                                              * log-probs of `actions`, from which the normaliser is recovered */
     const float* glogp; float* dheads;                      /* backward: dL/dlogp [R][T]; scratch [R][T][E], R * T < 2^31 */
+    const float* heads; int heads_T;                        /* backward, optional: the rollout's glimpse outputs [R][heads_T][E]
+                                                             * (eamrl_state.heads_out) of exactly these actions, decode step
+                                                             * t - tstart of row r at (r * heads_T + t - tstart) * E; NULL: recomputed */
     float* entropy;                                         /* forward, optional: [R][T] entropy of each step's distribution
                                                              * over the feasible nodes (calculate_entropy, utils/ops.py) */
     float *dK, *dV, *dLp, *dPa, *dPb; int64_t ldg;          /* gradients [B][M][.] (row stride ldg), ACCUMULATED into (+=) */
@@ -333,6 +336,10 @@ typedef struct eamrl_state {
     float* time;       /* [R] CVRPTW current_time, else NULL */
     const float* tw;   /* [B][M][2] CVRPTW time windows (start, end) as f32, else NULL */
     const float* dur;  /* [B][M] CVRPTW service durations, else NULL */
+    float* heads_out;  /* optional, eamrl_am_rollout / _seeded only: [R][t_max][E], the glimpse output ("heads", the input of the
+                        * logit projection, nn/attention.py:282-301) of every decode step -- the training graph's backward
+                        * (eamrl_reeval.heads) then does not recompute it.  Written only where eamrl_rollout_rng_native() is 1
+                        * (the start-sharing kernel); rows that are done, and steps after an instance's last, get zeros. */
 } eamrl_state;
 
 /* One decode step for R rows = AttentionModelDecoder.forward + DecodingStrategy.step

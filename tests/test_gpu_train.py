@@ -327,6 +327,43 @@ def test_batchnorm_train_kernel_bit_exact(oracle):
             assert_bits_equal(got, want, f"{what} rows={rows} E={E}")
 
 
+@pytest.mark.parametrize("cfg,env_name,N,B,ns", [("pomo_tsp", "tsp", 50, 5, 50), ("pomo_tsp", "tsp", 100, 3, 100),
+                                                 ("am_cvrp", "cvrp", 50, 4, 20), ("am_cvrp", "cvrp", 100, 2, 100)])
+def test_backward_with_the_rollouts_heads_equals_recomputation(cfg, env_name, N, B, ns, monkeypatch):
+    """policy.forward(phase="train") on a multistart batch: the start-sharing rollout kernel keeps every step's glimpse output
+    (eamrl_state.heads_out) and the logits-backward kernel reads it instead of recomputing the glimpse -- same gradients as with
+    EAMRL_REEVAL_RECOMPUTE_HEADS=1 (done CVRP rows and the steps after an instance's last have zero heads and zero gradient)."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import ops
+
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=N + 1)
+    torch.manual_seed(N + B)
+    td = env.reset(batch_size=[B]).to(DEV)
+    pol = make_policy(cfg).train()
+    noise = torch.empty(B * ns, (2 * N + 2 if env_name == "cvrp" else N), td["locs"].shape[1], device=DEV).exponential_(1)
+    seen, plan_init = [], ops.ReevalPlan.__init__
+
+    def spy(self, *a, **k):
+        seen.append(k.get("rollout_heads") is not None)
+        return plan_init(self, *a, **k)
+
+    monkeypatch.setattr(ops.ReevalPlan, "__init__", spy)
+    res = []
+    for recompute in ("0", "1"):
+        monkeypatch.setenv("EAMRL_REEVAL_RECOMPUTE_HEADS", recompute)
+        pol.zero_grad()
+        out = pol(td.clone(), env, phase="train", decode_type="multistart_sampling", num_starts=ns, noise=noise)
+        w = torch.randn(out["log_likelihood"].shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+        (out["log_likelihood"] * w).sum().backward()
+        res.append((out["actions"], {k: p.grad.clone() for k, p in pol.named_parameters() if p.grad is not None}))
+    assert seen == [True, False]
+    assert torch.equal(res[0][0], res[1][0])
+    gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in res[1][1].values())))
+    for k, ref in res[1][1].items():
+        rel = float((res[0][1][k].double() - ref.double()).norm()) / max(float(ref.double().norm()), 1e-2 * gnorm)
+        assert rel <= 2e-5, (k, rel)
+
+
 @pytest.mark.parametrize("rows,out_dim,in_dim,strided", [
     (1, 128, 128, False), (15, 128, 128, False), (64, 384, 128, False), (1000, 512, 128, False), (777, 128, 512, False),
     (6400, 384, 128, True), (102400, 128, 128, False),
