@@ -446,11 +446,14 @@ def main():
             flops = algorithmic_flops_per_query_step(M) * batch * S * T
             tf = flops / (kern * 1e-3) / 1e12
             roofline_decode = {
-                "kernel": "k_rollout_resident (decode loop, K/V/Lp read once per rollout into VGPRs)",
+                "kernel": ("k_rollout_ms_mfma (decode loop of all starts of an instance on fp32 MFMA, K/V/Lp as register fragments)"
+                           if S > 1 and env_name in ("tsp", "cvrp") and M <= 112 else
+                           "k_rollout_resident (decode loop, K/V/Lp read once per rollout into VGPRs)"),
                 "bound": "hbm", "achieved": round(rb / (kern * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(rb / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(rb), "kernel_ms": round(kern, 4),
-                "issue_bound": {"bound": "fp32 valu issue", "achieved": round(tf, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "issue_bound": {"bound": "mfma" if S > 1 and env_name in ("tsp", "cvrp") and M <= 112 else "fp32 valu issue",
+                                "achieved": round(tf, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(tf / F32_PEAK_TFLOPS, 4),
                                 "note": "the kernel is instruction-issue / latency bound, not HBM bound (DESIGN.md 4): useful "
                                         "flops 6*M*E + 6*E*E per row-step against the fp32 peak"},

@@ -434,7 +434,9 @@ class ReevalPlan:
 
     def forward(self):
         if self.lse is None and not self.want_entropy:
-            return self.logp
+            # a new tensor object: autograd makes the Function's output point at its node, and the node holds this plan --
+            # returning self.logp itself would close a reference cycle that only the cyclic collector frees
+            return self.logp.view_as(self.logp)
         lib = _lib.load()
         if self.want_entropy:
             self.entropy = torch.empty(self.R, self.T, dtype=torch.float32, device=self.buf.device)

@@ -546,6 +546,7 @@ class _NativeReeval(torch.autograd.Function):
     def backward(ctx, g):
         plan = ctx.plan
         dbuf, dg, dc = plan.backward(g)
+        plan.heads = None           # 5 .. 10 GB at the POMO sizes: not kept for as long as the graph object lives
         E = plan.E
         sl = [dbuf[..., i * E:(i + 1) * E] for i in range(5 if ctx.has[0] else 4)]
         return (sl[0], sl[1], sl[2], sl[3], sl[4] if ctx.has[0] else None, dg if ctx.has[1] else None,
