@@ -77,6 +77,8 @@ PROTOTYPES = {
     "eamrl_linear_wgrad_scratch": [_i64, _i32, _i32],
     "eamrl_linear_wgrad": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
     "eamrl_mha_encoder": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "eamrl_mha_encoder_backward_supported": [_i32, _i32, _i32],
+    "eamrl_mha_encoder_backward": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "eamrl_normalize": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp],
     "eamrl_batchnorm_train": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _i64, _vp],
     "eamrl_pointer_attention": [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],

@@ -208,6 +208,20 @@ __attribute__((visibility("default"))) int eamrl_matmul_right(const float* x, in
     return launched(launch_linear(g, (hipStream_t)stream), "eamrl_matmul_right");
 }
 
+__attribute__((visibility("default"))) int eamrl_mha_encoder_backward_supported(int N, int E, int H)
+{
+    return mha_encoder_bwd_supports(N, E, H) ? 1 : 0;
+}
+
+__attribute__((visibility("default"))) int eamrl_mha_encoder_backward(const float* qkv, const float* dout, float* dqkv, int64_t B,
+                                                                     int N, int E, int H, void* stream)
+{
+    REQUIRE(qkv && dout && dqkv && B >= 0, "eamrl_mha_encoder_backward");
+    REQUIRE(mha_encoder_bwd_supports(N, E, H), "eamrl_mha_encoder_backward");
+    REQUIRE((uintptr_t)qkv % 16 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)dqkv % 16 == 0, "eamrl_mha_encoder_backward");
+    return launched(launch_mha_encoder_bwd(qkv, dout, dqkv, B, N, (hipStream_t)stream), "eamrl_mha_encoder_backward");
+}
+
 __attribute__((visibility("default"))) int64_t eamrl_linear_wgrad_scratch(int64_t rows, int out_dim, int in_dim)
 {
     if (rows < 0 || !linear_wgrad_supports(out_dim, in_dim)) return -1;

@@ -52,6 +52,8 @@ typedef eamrl_reeval ReevalArgs;
 bool reeval_supports(int M, int E, int H);
 int launch_reeval_fwd(const ReevalArgs& a, hipStream_t st);
 int launch_reeval_bwd(const ReevalArgs& a, hipStream_t st);
+bool mha_encoder_bwd_supports(int N, int E, int H);
+int launch_mha_encoder_bwd(const float* qkv, const float* dout, float* dqkv, int64_t B, int N, hipStream_t st);
 int launch_pack_mask_bits(const uint8_t* mask, uint32_t* bits, int64_t R, int M, int T, int t, hipStream_t st);
 int launch_tsp_mask_bits(const int64_t* actions, uint32_t* bits, int64_t R, int M, int T, hipStream_t st);
 int launch_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, hipStream_t st);

@@ -934,6 +934,196 @@ int launch_reeval_bwd(const ReevalArgs& a, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Encoder self-attention backward (MultiHeadAttention.forward, rl4co/models/nn/attention.py:112-136, under loss.backward()):
+// qkv [B][N][3E] packed "b s (three h d)", dO [B][N][E] -> dqkv [B][N][3E].  The same five products as the glimpse backward
+// above with the instance's own N nodes as queries (no mask, scale 1/4 folded into the staged q): wave h = head h,
+//   a = softmax(K q~),  da = V dO,  ds = a (da - sum a da),  dq = 0.25 K^T ds,  dV += a^T dO,  dK += ds^T q~
+// over the ceil(N / 16) query tiles of the instance; one workgroup owns an instance, so dK / dV / dq are stored, not added.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RTT>
+__global__ __launch_bounds__(512, 2) void k_mha_encoder_bwd(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                            float* __restrict__ dqkv, int N)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* QTB = lds;                               // [2][16][TS]   q~ tiles (A layout)
+    float* DHB = QTB + 2 * 16 * TS;                 // [2][16][TS]   dO tiles
+    float* STG = DHB + 2 * 16 * TS;                 // [8 waves][2 parities][a | ds][16 keys][16 queries]
+    float* KTL = STG + 8 * 4 * 256;                 // [8 waves][RTT][64 lanes][4]  K^T fragments of the dq product
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, G = lane >> 4, pi = 4 * (j & 3) + (j >> 2);
+    const int jq = tid >> 5, e4 = tid & 31;
+    const int64_t b = blockIdx.x;
+    const int h = wv;
+    const int ntiles = (N + 15) / 16;
+    const float* qkvb = qkv + b * N * (3 * RE);
+    float* stg = STG + wv * 4 * 256;
+
+    float kf[RTT][4], vaf[RTT][4];
+#pragma unroll
+    for (int kt = 0; kt < RTT; ++kt) {
+        const int n = 16 * kt + pi;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            kf[kt][t] = n < N ? qkvb[(int64_t)n * (3 * RE) + RE + 16 * h + 4 * t + G] : 0.0f;
+            vaf[kt][t] = n < N ? qkvb[(int64_t)n * (3 * RE) + 2 * RE + 16 * h + 4 * t + G] : 0.0f;
+        }
+    }
+    float4* ktl = reinterpret_cast<float4*>(KTL) + wv * RTT * 64 + lane;
+#pragma unroll
+    for (int t4 = 0; t4 < RTT; ++t4) {              // K^T: row d = j, k index = key 4 t + G, t = 4 t4 + i
+        float kk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = 4 * (4 * t4 + i) + G;
+            kk[i] = n < N ? qkvb[(int64_t)n * (3 * RE) + RE + 16 * h + j] : 0.0f;
+        }
+        ktl[t4 * 64] = make_float4(kk[0], kk[1], kk[2], kk[3]);
+    }
+    uint4 mb;                                       // keys n < N
+    {
+        auto word = [&](int w) -> uint32_t { const int r = N - 32 * w; return r >= 32 ? 0xffffffffu : r <= 0 ? 0u : (1u << r) - 1u; };
+        mb = make_uint4(word(0), word(1), word(2), word(3));
+    }
+    f32x4 dV[RTT], dK[RTT];
+#pragma unroll
+    for (int nt = 0; nt < RTT; ++nt) { dV[nt] = z4(); dK[nt] = z4(); }
+
+    auto fetch = [&](int tile, float4& q, float4& d) {
+        const int n = 16 * tile + jq;
+        const int nc = n < N ? n : 0;
+        const float4 vq = *reinterpret_cast<const float4*>(qkvb + (int64_t)nc * (3 * RE) + 4 * e4);
+        const float4 vd = *reinterpret_cast<const float4*>(dout + (b * N + nc) * RE + 4 * e4);
+        const bool ok = n < N && tile < ntiles;
+        q = ok ? vq : make_float4(0.f, 0.f, 0.f, 0.f);
+        d = ok ? vd : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float4 pq, pd;
+    fetch(0, pq, pd);
+    __syncthreads();                    // KTL
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int cur = tile & 1;
+        {
+            float* qp = QTB + cur * 16 * TS + jq * TS + e4;
+            qp[0] = 0.25f * pq.x; qp[TG] = 0.25f * pq.y; qp[2 * TG] = 0.25f * pq.z; qp[3 * TG] = 0.25f * pq.w;
+            float* dp = DHB + cur * 16 * TS + jq * TS + e4;
+            dp[0] = pd.x; dp[TG] = pd.y; dp[2 * TG] = pd.z; dp[3 * TG] = pd.w;
+        }
+        fetch(tile + 1 < ntiles ? tile + 1 : tile, pq, pd);
+        __syncthreads();
+        const float* QT = QTB + cur * 16 * TS;
+        const float* DHT = DHB + cur * 16 * TS;
+        f32x4 s[RTT], da[RTT];
+        const float iz = head_softmax<RTT>(kf, QT, h, lane, mb, N, s);
+        const float* dp = DHT + j * TS + G * TG + 4 * h;
+        const float2 dlo = *reinterpret_cast<const float2*>(dp), dhi = *reinterpret_cast<const float2*>(dp + 2);
+#pragma unroll
+        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][0], dlo.x, z4());
+#pragma unroll
+        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][1], dlo.y, da[kt]);
+#pragma unroll
+        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][2], dhi.x, da[kt]);
+#pragma unroll
+        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][3], dhi.y, da[kt]);
+        float rs = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < RTT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kt][r] *= iz;                          // a
+                rs = fmaf(s[kt][r], da[kt][r], rs);
+            }
+        rs = group_sum(rs);
+#pragma unroll
+        for (int kt = 0; kt < RTT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) da[kt][r] = s[kt][r] * (da[kt][r] - rs);      // ds
+        float* wp = stg + G * 16 + (j & 3) * 4 + (j >> 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            wp[r * 64] = s[0][r];
+            wp[256 + r * 64] = da[0][r];
+        }
+        f32x4 dq = z4();
+#pragma unroll
+        for (int t4 = 0; t4 < RTT; ++t4) {
+            const float4 kk = ktl[t4 * 64];
+            dq = mf(kk.x, da[t4][0], dq);
+            dq = mf(kk.y, da[t4][1], dq);
+            dq = mf(kk.z, da[t4][2], dq);
+            dq = mf(kk.w, da[t4][3], dq);
+        }
+        if (16 * tile + j < N)          // lane (query j, G), register r -> d = 4 G + r
+            *reinterpret_cast<float4*>(dqkv + (b * N + 16 * tile + j) * (3 * RE) + 16 * h + 4 * G) =
+                make_float4(0.25f * dq[0], 0.25f * dq[1], 0.25f * dq[2], 0.25f * dq[3]);
+        float dhb[4], qb[4];
+        const int c = 16 * h + j;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            dhb[t] = DHT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
+            qb[t] = QT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
+        }
+#pragma unroll
+        for (int nt = 0; nt < RTT; ++nt) {
+            if (nt + 1 < RTT) {
+                float* wq = wp + ((nt + 1) & 1) * 512;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    wq[r * 64] = s[nt + 1][r];
+                    wq[256 + r * 64] = da[nt + 1][r];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float* rp = stg + (nt & 1) * 512 + j * 16 + G * 4;
+            const float4 at = *reinterpret_cast<const float4*>(rp);
+            const float4 dt = *reinterpret_cast<const float4*>(rp + 256);
+            __builtin_amdgcn_wave_barrier();
+            dV[nt] = mf(at.x, dhb[0], dV[nt]);
+            dK[nt] = mf(dt.x, qb[0], dK[nt]);
+            dV[nt] = mf(at.y, dhb[1], dV[nt]);
+            dK[nt] = mf(dt.y, qb[1], dK[nt]);
+            dV[nt] = mf(at.z, dhb[2], dV[nt]);
+            dK[nt] = mf(dt.z, qb[2], dK[nt]);
+            dV[nt] = mf(at.w, dhb[3], dV[nt]);
+            dK[nt] = mf(dt.w, qb[3], dK[nt]);
+        }
+    }
+    // dV / dK: lane (column 16 h + j, G), register r -> key 16 nt + 4 G + r
+#pragma unroll
+    for (int nt = 0; nt < RTT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = 16 * nt + 4 * G + r;
+            if (n < N) {
+                dqkv[(b * N + n) * (3 * RE) + RE + 16 * h + j] = dK[nt][r];
+                dqkv[(b * N + n) * (3 * RE) + 2 * RE + 16 * h + j] = dV[nt][r];
+            }
+        }
+}
+
+template <int RTT>
+static int launch_mha_bwd_t(const float* qkv, const float* dout, float* dqkv, int64_t B, int N, hipStream_t st)
+{
+    const size_t ldsz = (4 * 16 * (size_t)TS + 8 * 4 * 256 + 8 * RTT * 256) * sizeof(float);
+    auto k = k_mha_encoder_bwd<RTT>;
+    if (ldsz > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz) != hipSuccess)
+        return EAMRL_E_LAUNCH;
+    hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(512), ldsz, st, qkv, dout, dqkv, N);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+bool mha_encoder_bwd_supports(int N, int E, int H) { return N >= 1 && N <= 112 && E == RE && H == RH; }
+
+int launch_mha_encoder_bwd(const float* qkv, const float* dout, float* dqkv, int64_t B, int N, hipStream_t st)
+{
+    if (B <= 0) return 0;
+    if (N <= 32) return launch_mha_bwd_t<2>(qkv, dout, dqkv, B, N, st);
+    if (N <= 64) return launch_mha_bwd_t<4>(qkv, dout, dqkv, B, N, st);
+    return launch_mha_bwd_t<7>(qkv, dout, dqkv, B, N, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // feasibility masks as bit sets: bits[(r * T + t) * 4 + (n >> 5)] |= mask[r][n] << (n & 31)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void k_pack_mask_bits(const uint8_t* __restrict__ mask, uint32_t* __restrict__ bits, int64_t R, int M, int T, int t)

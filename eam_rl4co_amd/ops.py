@@ -154,6 +154,22 @@ def mha_encoder(qkv, num_heads):
     return out
 
 
+def mha_encoder_backward_supported(N: int, E: int, H: int) -> bool:
+    return bool(_lib.load().eamrl_mha_encoder_backward_supported(int(N), int(E), int(H)))
+
+
+def mha_encoder_backward(qkv, dout, num_heads):
+    """dqkv [B, N, 3E] of mha_encoder(qkv) for the output gradient dout [B, N, E] (eamrl_mha_encoder_backward)."""
+    lib = _lib.load()
+    _chk(qkv, "qkv", torch.float32)
+    B, N, E3 = qkv.shape
+    _chk(dout, "dout", torch.float32, (B, N, E3 // 3))
+    dqkv = torch.empty_like(qkv)
+    _lib.check(lib.eamrl_mha_encoder_backward(_ptr(qkv), _ptr(dout), _ptr(dqkv), B, N, E3 // 3, num_heads, _stream(qkv)),
+               "eamrl_mha_encoder_backward")
+    return dqkv
+
+
 def normalize_(x, kind, gamma, beta, mean=None, var=None, eps=1e-5):
     lib = _lib.load()
     _chk(x, "x", torch.float32)

@@ -162,6 +162,13 @@ int eamrl_linear_wgrad(const float* dy, int64_t ldy, const float* x, int64_t ldx
  * [nn/attention.py:112-136 MultiHeadAttention.forward]. */
 int eamrl_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H, void* stream);
 
+/* Gradient of eamrl_mha_encoder for the training graph (MultiHeadAttention.forward under loss.backward(),
+ * nn/attention.py:112-136): qkv [B][N][3E] as given to the forward, dout [B][N][E] -> dqkv [B][N][3E] (written).  The softmax
+ * is recomputed (hardware exp; tile-order sums: held to 1e-5 of torch's scaled_dot_product_attention gradient, not part of
+ * the bit-exact path).  N <= 112, E = 128, H = 8 (eamrl_mha_encoder_backward_supported). */
+int eamrl_mha_encoder_backward_supported(int N, int E, int H);
+int eamrl_mha_encoder_backward(const float* qkv, const float* dout, float* dqkv, int64_t B, int N, int E, int H, void* stream);
+
 /* Normalization.forward in place on x [B][N][E]  [nn/ops.py:32-56].
  * BATCH_EVAL uses running stats (mean, var); INSTANCE ignores them (may be NULL). */
 int eamrl_normalize(float* x, int64_t B, int N, int E, int kind, const float* gamma, const float* beta,

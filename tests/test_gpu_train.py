@@ -392,6 +392,30 @@ def test_training_steps_do_not_accumulate_device_memory():
     assert max(after[2:]) - after[1] < heads_bytes // 2, after
 
 
+@pytest.mark.parametrize("B,N", [(3, 20), (2, 21), (5, 50), (2, 64), (3, 100), (1, 101), (2, 112), (1, 1), (1, 17)])
+def test_encoder_attention_backward_kernel_matches_torch(B, N):
+    """eamrl_mha_encoder_backward against autograd through scaled_dot_product_attention on the same packed qkv."""
+    from eam_rl4co_amd.train import _self_attention
+
+    g = torch.Generator(device="cpu").manual_seed(B * 131 + N)
+    qkv0 = (torch.randn(B, N, 384, generator=g) * 1.5).to(DEV)
+    w = torch.randn(B, N, 128, generator=g).to(DEV)
+    res = []
+    for native in (True, False):
+        qkv = qkv0.clone().requires_grad_()
+        if native:
+            y = _self_attention(qkv, B, N, 128, 8)
+        else:
+            q = qkv.double().view(B, N, 3, 8, 16).permute(2, 0, 3, 1, 4)
+            y = F.scaled_dot_product_attention(q[0], q[1], q[2]).permute(0, 2, 1, 3).reshape(B, N, 128)
+        (y * w.to(y.dtype)).sum().backward()
+        res.append((y.detach().double(), qkv.grad.double()))
+    assert type(res[0][0]) is torch.Tensor
+    np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), rtol=0, atol=2e-6 * float(res[1][0].abs().max()))
+    scale = float(res[1][1].abs().max())
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * scale
+
+
 @pytest.mark.parametrize("rows,out_dim,in_dim,strided", [
     (1, 128, 128, False), (15, 128, 128, False), (64, 384, 128, False), (1000, 512, 128, False), (777, 128, 512, False),
     (6400, 384, 128, True), (102400, 128, 128, False),
