@@ -692,10 +692,12 @@ def reinforce_loss(policy, env, td, baseline: str = "shared", num_starts: int = 
             "native_log_likelihood": ll.detach()}
 
 
-def eam_loss(policy, env, td, ea, num_starts: int, improve: bool = True, draws=None, generator=None):
+def eam_loss(policy, env, td, ea, num_starts: int, improve: bool = True, draws=None, generator=None, return_entropy: bool = True):
     """One EAM training step of the fork with the POMO (shared) baseline (rl4co/models/zoo/earl/model.py:129-247):
 
-    1. sampled multistart rollout, `policy(td, env, phase="train", num_starts=S)` (log-likelihood with grad);
+    1. sampled multistart rollout, `policy(td, env, phase="train", num_starts=S)` (log-likelihood with grad); with
+       return_entropy=True also the entropy of the sampled tours, as the reference's first call asks for (model.py:150-156;
+       it only logs it) -- res["entropy"];
     2. the sampled tours are improved by the evolutionary operators on the GPU (`evolution_worker`; the reference
        ships them to CPU threads, model.py:166-171) and get their start column back (`_align_improved_actions`);
     3. the improved tours are evaluated by `policy(td, env, phase="train", actions=improved)` (model.py:189-195);
@@ -706,17 +708,19 @@ def eam_loss(policy, env, td, ea, num_starts: int, improve: bool = True, draws=N
     S = int(num_starts)
     assert S > 1, "the EAM step uses the multistart (shared) baseline"
     with shared_decoder_tensors(policy):        # one differentiable encoder pass for the sampled and the improved tours
-        return _eam_loss(policy, env, td, ea, S, improve, draws, generator)
+        return _eam_loss(policy, env, td, ea, S, improve, draws, generator, return_entropy)
 
 
-def _eam_loss(policy, env, td, ea, S, improve, draws, generator):
+def _eam_loss(policy, env, td, ea, S, improve, draws, generator, return_entropy=False):
     from .evolution import evolution_worker
 
     with torch.enable_grad():
-        out = policy(td, env, phase="train", decode_type="multistart_sampling", num_starts=S)
+        out = policy(td, env, phase="train", decode_type="multistart_sampling", num_starts=S, return_entropy=return_entropy)
     actions, reward, ll = out["actions"], out["reward"], out["log_likelihood"]
     rs, lls = [unbatchify(reward, S)], [unbatchify(ll, S)]
     res = {"reward": reward, "log_likelihood": ll, "actions": actions}
+    if return_entropy:
+        res["entropy"] = out["entropy"]
     if improve:
         with torch.no_grad():
             improved, _ = evolution_worker(actions, td, ea, env, draws=draws, generator=generator)

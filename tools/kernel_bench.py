@@ -115,7 +115,8 @@ def bench_train(iters):
         td = env.reset(batch_size=[B]).to("cuda")
         def step():
             t0 = time.perf_counter()
-            res = train.eam_loss(pol, env, td, runner, num_starts=S, generator=gen)
+            res = train.eam_loss(pol, env, td, runner, num_starts=S, generator=gen,
+                                 return_entropy=os.environ.get("EAM_ENTROPY", "1") == "1")   # (the reference's step asks for it)
             torch.cuda.synchronize(); t1 = time.perf_counter()
             opt.zero_grad()
             res["loss"].backward()
