@@ -600,6 +600,95 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
         }
 }
 
+// One tile (16 queries) of attention backward for head h, shared by the glimpse backward (queries = decode steps) and the
+// encoder self-attention backward (queries = the instance's nodes): recomputes a = softmax(K q~ | mask), then
+//   da = V dO,  ds = a (da - sum a da),  dq~ = K^T ds (handed to store_dq as soon as it exists, so that its global store
+//   runs behind the remaining products: lane (query j, G), register r -> column 4 G + r),
+//   dV += a^T dO,  dK += ds^T q~   (accumulators: lane (column 16 h + j, G), register r -> key 16 nt + 4 G + r).
+// QT / DHT: the staged q~ and dO tiles (A layout); stg: this wave's 4 x 256-float transposition rows; ktl: this lane's K^T
+// fragments in LDS ([t4] at stride 64 float4).
+template <int RTT, typename StoreDq>
+__device__ __forceinline__ void attention_bwd_tile(const float (&kf)[RTT][4], const float (&vaf)[RTT][4], const float4* ktl,
+                                                   const float* QT, const float* DHT, float* stg, int h, int lane,
+                                                   const uint4& mb, int M, f32x4 (&dV)[RTT], f32x4 (&dK)[RTT], StoreDq store_dq)
+{
+    const int j = lane & 15, G = lane >> 4;
+    f32x4 s[RTT], da[RTT];
+    const float iz = head_softmax<RTT>(kf, QT, h, lane, mb, M, s);
+    const float* dp = DHT + j * TS + G * TG + 4 * h;
+    const float2 dlo = *reinterpret_cast<const float2*>(dp), dhi = *reinterpret_cast<const float2*>(dp + 2);
+#pragma unroll
+    for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][0], dlo.x, z4());
+#pragma unroll
+    for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][1], dlo.y, da[kt]);
+#pragma unroll
+    for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][2], dhi.x, da[kt]);
+#pragma unroll
+    for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][3], dhi.y, da[kt]);
+    float rs = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < RTT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[kt][r] *= iz;                          // a
+            rs = fmaf(s[kt][r], da[kt][r], rs);
+        }
+    rs = group_sum(rs);
+#pragma unroll
+    for (int kt = 0; kt < RTT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) da[kt][r] = s[kt][r] * (da[kt][r] - rs);      // ds
+    // staging of key tile 0 (element (key kappa, query q) of a tile at kappa * 16 + (q & 3) * 4 + (q >> 2))
+    float* wp = stg + G * 16 + (j & 3) * 4 + (j >> 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        wp[r * 64] = s[0][r];
+        wp[256 + r * 64] = da[0][r];
+    }
+    f32x4 dq = z4();
+#pragma unroll
+    for (int t4 = 0; t4 < RTT; ++t4) {
+        const float4 kk = ktl[t4 * 64];
+        dq = mf(kk.x, da[t4][0], dq);
+        dq = mf(kk.y, da[t4][1], dq);
+        dq = mf(kk.z, da[t4][2], dq);
+        dq = mf(kk.w, da[t4][3], dq);
+    }
+    store_dq(dq);
+    // B operands of the two "sum over queries" products: dO_h [q][e] and q~_h [q][d], column j, k index q = 4 t + G
+    float dhb[4], qb[4];
+    const int c = 16 * h + j;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        dhb[t] = DHT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
+        qb[t] = QT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
+    }
+#pragma unroll
+    for (int nt = 0; nt < RTT; ++nt) {
+        if (nt + 1 < RTT) {
+            float* wq = wp + ((nt + 1) & 1) * 512;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                wq[r * 64] = s[nt + 1][r];
+                wq[256 + r * 64] = da[nt + 1][r];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float* rp = stg + (nt & 1) * 512 + j * 16 + G * 4;
+        const float4 at = *reinterpret_cast<const float4*>(rp);
+        const float4 dt = *reinterpret_cast<const float4*>(rp + 256);
+        __builtin_amdgcn_wave_barrier();
+        dV[nt] = mf(at.x, dhb[0], dV[nt]);
+        dK[nt] = mf(dt.x, qb[0], dK[nt]);
+        dV[nt] = mf(at.y, dhb[1], dV[nt]);
+        dK[nt] = mf(dt.y, qb[1], dK[nt]);
+        dV[nt] = mf(at.z, dhb[2], dV[nt]);
+        dK[nt] = mf(dt.z, qb[2], dK[nt]);
+        dV[nt] = mf(at.w, dhb[3], dV[nt]);
+        dK[nt] = mf(dt.w, qb[3], dK[nt]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // backward 2/2: glimpse.  Wave h = head h: recomputes the softmax, da = V dheads, ds = a (da - sum a da), dq~ = K^T ds,
 // dV[n][e] += sum_q a[q][n] dheads[q][e], dK[n][d] += sum_q ds[q][n] q~[q][d].
@@ -699,83 +788,11 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
         __syncthreads();
         const float* QT = QTB + cur * 16 * TS;
         const float* DHT = DHB + cur * 16 * TS;
-        f32x4 s[RTT], da[RTT];
-        const float iz = head_softmax<RTT>(kf, QT, h, lane, mb_cur, a.M, s);
-        const float* dp = DHT + j * TS + G * TG + 4 * h;
-        const float2 dlo = *reinterpret_cast<const float2*>(dp), dhi = *reinterpret_cast<const float2*>(dp + 2);
-#pragma unroll
-        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][0], dlo.x, z4());
-#pragma unroll
-        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][1], dlo.y, da[kt]);
-#pragma unroll
-        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][2], dhi.x, da[kt]);
-#pragma unroll
-        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][3], dhi.y, da[kt]);
-        float rs = 0.0f;
-#pragma unroll
-        for (int kt = 0; kt < RTT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[kt][r] *= iz;                          // a
-                rs = fmaf(s[kt][r], da[kt][r], rs);
-            }
-        rs = group_sum(rs);
-#pragma unroll
-        for (int kt = 0; kt < RTT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) da[kt][r] = s[kt][r] * (da[kt][r] - rs);      // ds
-        // staging of key tile 0 (element (key kappa, query q) of a tile at kappa * 16 + (q & 3) * 4 + (q >> 2))
-        float* wp = stg + G * 16 + (j & 3) * 4 + (j >> 2);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            wp[r * 64] = s[0][r];
-            wp[256 + r * 64] = da[0][r];
-        }
-        // dq~^T = K^T ds: lane (query j, G), register r -> d = 4 G + r
-        f32x4 dq = z4();
-#pragma unroll
-        for (int t4 = 0; t4 < RTT; ++t4) {
-            const float4 kk = ktl[t4 * 64];
-            dq = mf(kk.x, da[t4][0], dq);
-            dq = mf(kk.y, da[t4][1], dq);
-            dq = mf(kk.z, da[t4][2], dq);
-            dq = mf(kk.w, da[t4][3], dq);
-        }
-        if (qj_cur >= 0)
-            *reinterpret_cast<float4*>(a.dheads + (int64_t)qj_cur * RE + 16 * h + 4 * G) =
-                make_float4(0.25f * dq[0], 0.25f * dq[1], 0.25f * dq[2], 0.25f * dq[3]);
-        // B operands of the two "sum over queries" products: dheads_h [q][e] and q~_h [q][d], column j, k index q = 4 t + G
-        float dhb[4], qb[4];
-        const int c = 16 * h + j;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            dhb[t] = DHT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
-            qb[t] = QT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
-        }
-#pragma unroll
-        for (int nt = 0; nt < RTT; ++nt) {
-            if (nt + 1 < RTT) {
-                float* wq = wp + ((nt + 1) & 1) * 512;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    wq[r * 64] = s[nt + 1][r];
-                    wq[256 + r * 64] = da[nt + 1][r];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const float* rp = stg + (nt & 1) * 512 + j * 16 + G * 4;
-            const float4 at = *reinterpret_cast<const float4*>(rp);
-            const float4 dt = *reinterpret_cast<const float4*>(rp + 256);
-            __builtin_amdgcn_wave_barrier();
-            dV[nt] = mf(at.x, dhb[0], dV[nt]);
-            dK[nt] = mf(dt.x, qb[0], dK[nt]);
-            dV[nt] = mf(at.y, dhb[1], dV[nt]);
-            dK[nt] = mf(dt.y, qb[1], dK[nt]);
-            dV[nt] = mf(at.z, dhb[2], dV[nt]);
-            dK[nt] = mf(dt.z, qb[2], dK[nt]);
-            dV[nt] = mf(at.w, dhb[3], dV[nt]);
-            dK[nt] = mf(dt.w, qb[3], dK[nt]);
-        }
+        attention_bwd_tile<RTT>(kf, vaf, ktl, QT, DHT, stg, h, lane, mb_cur, a.M, dV, dK, [&](const f32x4& dq) {
+            if (qj_cur >= 0)        // dq~ takes the place of the tile's dheads row (read one tile ahead)
+                *reinterpret_cast<float4*>(a.dheads + (int64_t)qj_cur * RE + 16 * h + 4 * G) =
+                    make_float4(0.25f * dq[0], 0.25f * dq[1], 0.25f * dq[2], 0.25f * dq[3]);
+        });
     }
 #pragma unroll
     for (int nt = 0; nt < RTT; ++nt)
@@ -1013,80 +1030,11 @@ __global__ __launch_bounds__(512, 2) void k_mha_encoder_bwd(const float* __restr
         __syncthreads();
         const float* QT = QTB + cur * 16 * TS;
         const float* DHT = DHB + cur * 16 * TS;
-        f32x4 s[RTT], da[RTT];
-        const float iz = head_softmax<RTT>(kf, QT, h, lane, mb, N, s);
-        const float* dp = DHT + j * TS + G * TG + 4 * h;
-        const float2 dlo = *reinterpret_cast<const float2*>(dp), dhi = *reinterpret_cast<const float2*>(dp + 2);
-#pragma unroll
-        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][0], dlo.x, z4());
-#pragma unroll
-        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][1], dlo.y, da[kt]);
-#pragma unroll
-        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][2], dhi.x, da[kt]);
-#pragma unroll
-        for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][3], dhi.y, da[kt]);
-        float rs = 0.0f;
-#pragma unroll
-        for (int kt = 0; kt < RTT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[kt][r] *= iz;                          // a
-                rs = fmaf(s[kt][r], da[kt][r], rs);
-            }
-        rs = group_sum(rs);
-#pragma unroll
-        for (int kt = 0; kt < RTT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) da[kt][r] = s[kt][r] * (da[kt][r] - rs);      // ds
-        float* wp = stg + G * 16 + (j & 3) * 4 + (j >> 2);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            wp[r * 64] = s[0][r];
-            wp[256 + r * 64] = da[0][r];
-        }
-        f32x4 dq = z4();
-#pragma unroll
-        for (int t4 = 0; t4 < RTT; ++t4) {
-            const float4 kk = ktl[t4 * 64];
-            dq = mf(kk.x, da[t4][0], dq);
-            dq = mf(kk.y, da[t4][1], dq);
-            dq = mf(kk.z, da[t4][2], dq);
-            dq = mf(kk.w, da[t4][3], dq);
-        }
-        if (16 * tile + j < N)          // lane (query j, G), register r -> d = 4 G + r
-            *reinterpret_cast<float4*>(dqkv + (b * N + 16 * tile + j) * (3 * RE) + 16 * h + 4 * G) =
-                make_float4(0.25f * dq[0], 0.25f * dq[1], 0.25f * dq[2], 0.25f * dq[3]);
-        float dhb[4], qb[4];
-        const int c = 16 * h + j;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            dhb[t] = DHT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
-            qb[t] = QT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
-        }
-#pragma unroll
-        for (int nt = 0; nt < RTT; ++nt) {
-            if (nt + 1 < RTT) {
-                float* wq = wp + ((nt + 1) & 1) * 512;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    wq[r * 64] = s[nt + 1][r];
-                    wq[256 + r * 64] = da[nt + 1][r];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const float* rp = stg + (nt & 1) * 512 + j * 16 + G * 4;
-            const float4 at = *reinterpret_cast<const float4*>(rp);
-            const float4 dt = *reinterpret_cast<const float4*>(rp + 256);
-            __builtin_amdgcn_wave_barrier();
-            dV[nt] = mf(at.x, dhb[0], dV[nt]);
-            dK[nt] = mf(dt.x, qb[0], dK[nt]);
-            dV[nt] = mf(at.y, dhb[1], dV[nt]);
-            dK[nt] = mf(dt.y, qb[1], dK[nt]);
-            dV[nt] = mf(at.z, dhb[2], dV[nt]);
-            dK[nt] = mf(dt.z, qb[2], dK[nt]);
-            dV[nt] = mf(at.w, dhb[3], dV[nt]);
-            dK[nt] = mf(dt.w, qb[3], dK[nt]);
-        }
+        attention_bwd_tile<RTT>(kf, vaf, ktl, QT, DHT, stg, h, lane, mb, N, dV, dK, [&](const f32x4& dq) {
+            if (16 * tile + j < N)      // lane (query j, G), register r -> d = 4 G + r
+                *reinterpret_cast<float4*>(dqkv + (b * N + 16 * tile + j) * (3 * RE) + 16 * h + 4 * G) =
+                    make_float4(0.25f * dq[0], 0.25f * dq[1], 0.25f * dq[2], 0.25f * dq[3]);
+        });
     }
     // dV / dK: lane (column 16 h + j, G), register r -> key 16 nt + 4 G + r
 #pragma unroll

@@ -667,8 +667,11 @@ class AttentionModelPolicy(nn.Module):
                      and any(q.requires_grad for q in self.parameters()))
         self._want_heads = want_grad and os.environ.get("EAMRL_REEVAL_RECOMPUTE_HEADS", "0") != "1"
         with torch.no_grad():
-            p = self._enqueue(td, env, phase, calc_reward, return_actions, return_entropy, return_hidden,
-                              return_init_embeds, return_sum_log_likelihood, actions, max_steps, **decoding_kwargs)
+            try:
+                p = self._enqueue(td, env, phase, calc_reward, return_actions, return_entropy, return_hidden,
+                                  return_init_embeds, return_sum_log_likelihood, actions, max_steps, **decoding_kwargs)
+            finally:
+                self._want_heads = False        # (GraphedRollout calls _enqueue directly)
             if "out" in p:          # beam search is host-driven and arrives finished (inference only)
                 return p["out"]
             out = self._finish(p)
