@@ -460,7 +460,7 @@ class ReevalPlan:
                 self.logp = torch.empty(self.R, self.T, dtype=torch.float32, device=self.buf.device)
         s = self._struct()
         _lib.check(lib.eamrl_reeval_forward(C.byref(s), _stream(self.buf)), "eamrl_reeval_forward")
-        return self.logp
+        return self.logp.view_as(self.logp)         # (a new tensor object, see above)
 
     def backward(self, glogp):
         """-> (dbuf [B, M, P*E], dgctx or None, dcvec or None)"""

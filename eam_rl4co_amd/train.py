@@ -337,10 +337,11 @@ _STATE_KEYS = {"cvrp": ("demand", "vehicle_capacity"), "sdvrp": ("demand", "vehi
 
 class shared_decoder_tensors:
     """Within this context, policy calls on the SAME instances under the SAME parameters share one differentiable
-    encoder pass (`decoder_tensors`) and one native encoder + cache launch (`AttentionModelPolicy._enqueue`): the EAM step evaluates the sampled and the improved tours of a batch one after the
-    other (zoo/earl/model.py:179-195 runs the whole policy, encoder included, twice), and both losses are summed before
-    the one backward -- so one encoder graph serves both, with identical gradients up to summation order.  Opt-in,
-    because a graph that has already been backpropagated through cannot serve a second backward."""
+    encoder pass (`decoder_tensors`) and one native encoder + cache launch (`AttentionModelPolicy._enqueue`): the EAM
+    step evaluates the sampled and the improved tours of a batch one after the other (zoo/earl/model.py:179-195 runs the
+    whole policy, encoder included, twice), and both losses are summed before the one backward -- so one encoder graph
+    serves both, with identical gradients up to summation order.  Opt-in, because a graph that has already been
+    backpropagated through cannot serve a second backward."""
 
     def __init__(self, policy):
         self.policy = policy
