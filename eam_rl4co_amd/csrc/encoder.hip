@@ -905,45 +905,62 @@ int launch_batchnorm_train(float* x, int64_t rows, int E, const float* gamma, co
 // mean / 1/std per (instance, channel), and the backward.  Thread = channel, sequential over the instance's nodes, rows read
 // as 4 E-byte coalesced runs -- on the [B][N][E] layout as it is (torch's instance_norm wants [B][E][N]: two transposed copies
 // per call, and MIOpen's spatial batch-norm backward behind it takes 0.49 ms per call at 1024 x 100 x 128).
-// Not parity-critical (the rollout's own normalisation is k_norm_instance): plain fp32, hardware rsqrt-free 1 / sqrt.
 // ---------------------------------------------------------------------------------------------------------------------
-// block = 4 row groups x E channels (E <= 128 here; larger E loops): thread (q, e) takes the rows n = q (mod 4); the four
-// partial sums meet in LDS.  4x the loads in flight of a thread-per-channel loop.
-constexpr int IN_Q = 4;
-
-__global__ void k_instnorm_train_fwd(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mean_out,
-                                     float* __restrict__ rstd_out, int N, int E, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, float eps)
+// Forward: the SAME arithmetic as k_norm_instance, bit for bit (sum and variance sequentially over the nodes in node order,
+// variance as the fma chain of (x - mean)^2, y = fma((x - mean) * rstd, gamma, beta)): with it the training graph's encoder
+// reproduces the rollout's embeddings exactly, so that one encoder pass can serve both (policy.forward, phase "train").
+// The instance's [N][E] tile is staged in LDS by all threads (coalesced float4 loads), then thread = channel walks its column
+// (LDS reads pipeline; the global-memory version of the same walk waits a full memory latency per 8 rows).
+__global__ __launch_bounds__(256) void k_instnorm_train_fwd(const float* __restrict__ x, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int N, int E,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, int in_lds)
 {
-    extern __shared__ float red[];                    // [IN_Q][Ep]
-    const int Ep = blockDim.x / IN_Q;
-    const int q = threadIdx.x / Ep, el = threadIdx.x - q * Ep;
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [N][E] when in_lds, then mean [E] | rstd [E]
     const int64_t b = blockIdx.x;
     const float* xb = x + b * (int64_t)N * E;
     float* yb = y + b * (int64_t)N * E;
-    for (int e0 = 0; e0 < E; e0 += Ep) {
-        const int e = e0 + el;
-        const bool on = e < E;
+    const int total = N * E;
+    if (in_lds) {
+        if ((E & 3) == 0) {
+            for (int i = threadIdx.x; i < total / 4; i += blockDim.x)
+                reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(xb)[i];
+        } else {
+            for (int i = threadIdx.x; i < total; i += blockDim.x) tile[i] = xb[i];
+        }
+        __syncthreads();
+    }
+    const float* src = in_lds ? tile : xb;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
         float s = 0.0f;
-        if (on) for (int n = q; n < N; n += IN_Q) s += xb[(int64_t)n * E + e];
-        red[q * Ep + el] = s;
-        __syncthreads();
-        const float mean = (((red[el] + red[Ep + el]) + red[2 * Ep + el]) + red[3 * Ep + el]) / (float)N;
-        __syncthreads();
+        for (int n = 0; n < N; ++n) s = s + src[n * E + e];
+        const float mean = s / (float)N;
         float v = 0.0f;
-        if (on) for (int n = q; n < N; n += IN_Q) { const float d = xb[(int64_t)n * E + e] - mean; v = fmaf(d, d, v); }
-        red[q * Ep + el] = v;
-        __syncthreads();
-        const float var = (((red[el] + red[Ep + el]) + red[2 * Ep + el]) + red[3 * Ep + el]) / (float)N;
-        __syncthreads();
-        const float rstd = 1.0f / __builtin_sqrtf(var + eps);
-        if (on) {
+        for (int n = 0; n < N; ++n) { const float d = src[n * E + e] - mean; v = fma_(d, d, v); }
+        const float rstd = 1.0f / __builtin_sqrtf(v / (float)N + eps);
+        mean_out[b * E + e] = mean;
+        rstd_out[b * E + e] = rstd;
+        if (in_lds) {
+            tile[total + e] = mean;
+            tile[total + E + e] = rstd;
+        } else {
             const float g = gamma ? gamma[e] : 1.0f, bt = beta ? beta[e] : 0.0f;
-            for (int n = q; n < N; n += IN_Q) yb[(int64_t)n * E + e] = fmaf((xb[(int64_t)n * E + e] - mean) * rstd, g, bt);
-            if (q == 0) { mean_out[b * E + e] = mean; rstd_out[b * E + e] = rstd; }
+            for (int n = 0; n < N; ++n) yb[(int64_t)n * E + e] = fma_((src[n * E + e] - mean) * rstd, g, bt);
+        }
+    }
+    if (in_lds) {                   // the elementwise pass with all threads (coalesced stores)
+        __syncthreads();
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int e = i % E;
+            const float g = gamma ? gamma[e] : 1.0f, bt = beta ? beta[e] : 0.0f;
+            yb[i] = fma_((tile[i] - tile[total + e]) * tile[total + E + e], g, bt);
         }
     }
 }
+
+// Backward: block = 4 row groups x E channels (E <= 128 here; larger E loops): thread (q, e) takes the rows n = q (mod 4); the
+// four partial sums meet in LDS.  4x the loads in flight of a thread-per-channel loop.  (Not parity-critical.)
+constexpr int IN_Q = 4;
 
 // dx = gamma rstd (dy - mean_n(dy) - xhat mean_n(dy xhat));  dgamma += sum_n dy xhat;  dbeta += sum_n dy
 __global__ void k_instnorm_train_bwd(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean_in,
@@ -994,9 +1011,13 @@ __global__ void k_instnorm_train_bwd(const float* __restrict__ x, const float* _
 int launch_instnorm_train_fwd(const float* x, float* y, float* mean, float* rstd, int64_t B, int N, int E, const float* gamma,
                               const float* beta, float eps, hipStream_t st)
 {
-    const int Ep = E <= 128 ? ((E + 63) / 64) * 64 : 128;          // channels per pass; block = IN_Q x Ep threads
-    hipLaunchKernelGGL(k_instnorm_train_fwd, dim3((unsigned)B), dim3(IN_Q * Ep), IN_Q * Ep * sizeof(float), st, x, y, mean, rstd,
-                       N, E, gamma, beta, eps);
+    const size_t bytes = ((size_t)N * E + 2 * (size_t)E) * sizeof(float);
+    const int in_lds = bytes <= 96 * 1024;
+    auto k = k_instnorm_train_fwd;
+    if (in_lds && bytes > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return EAMRL_E_LAUNCH;
+    hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(256), in_lds ? bytes : 0, st, x, y, mean, rstd, N, E, gamma, beta, eps, in_lds);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 

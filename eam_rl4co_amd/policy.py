@@ -666,16 +666,48 @@ class AttentionModelPolicy(nn.Module):
         want_grad = (torch.is_grad_enabled() and phase == "train" and not torch.is_inference_mode_enabled()
                      and any(q.requires_grad for q in self.parameters()))
         self._want_heads = want_grad and os.environ.get("EAMRL_REEVAL_RECOMPUTE_HEADS", "0") != "1"
+        own_shared = False
+        try:
+            if want_grad:
+                own_shared = self._one_encoder_pass(td, return_init_embeds)
+            with torch.no_grad():
+                try:
+                    p = self._enqueue(td, env, phase, calc_reward, return_actions, return_entropy, return_hidden,
+                                      return_init_embeds, return_sum_log_likelihood, actions, max_steps, **decoding_kwargs)
+                finally:
+                    self._want_heads = False        # (GraphedRollout calls _enqueue directly)
+                if "out" in p:          # beam search is host-driven and arrives finished (inference only)
+                    return p["out"]
+                out = self._finish(p)
+            return self._attach_grad(out, p) if want_grad else out
+        finally:
+            if own_shared:
+                self._shared_dt = None
+
+    def _one_encoder_pass(self, td, return_init_embeds) -> bool:
+        """Training: where the differentiable encoder of the gradient graph reproduces the native encoder bit for bit
+        (train.graph_encoder_equals_native), it is built FIRST and its embeddings feed the rollout -- one encoder pass per step
+        instead of the fused kernel for the rollout plus the graph's own forward.  The graph and the embeddings are handed
+        on through the `shared_decoder_tensors` slots (`_enqueue` skips the encoder, `_attach_grad` finds the graph).
+        -> whether this call opened the slots itself (and has to close them)."""
+        from . import train
+
+        if not (isinstance(self.encoder, AttentionModelEncoder) and isinstance(self.decoder, AttentionModelDecoder)
+                and hasattr(td, "items") and train.graph_encoder_equals_native(self, td)):
+            return False
+        own = getattr(self, "_shared_dt", None) is None
+        if own:
+            self._shared_dt = {}
         with torch.no_grad():
-            try:
-                p = self._enqueue(td, env, phase, calc_reward, return_actions, return_entropy, return_hidden,
-                                  return_init_embeds, return_sum_log_likelihood, actions, max_steps, **decoding_kwargs)
-            finally:
-                self._want_heads = False        # (GraphedRollout calls _enqueue directly)
-            if "out" in p:          # beam search is host-driven and arrives finished (inference only)
-                return p["out"]
-            out = self._finish(p)
-        return self._attach_grad(out, p) if want_grad else out
+            ekey = train._graph_key(self, td)           # (the key `_enqueue` computes, under no_grad)
+        ent = self._shared_dt.get("native")
+        if ent is None or ent[0] != ekey:
+            with torch.enable_grad():
+                t = train.decoder_tensors(self, td)
+            with torch.no_grad():
+                init_embeds = self.encoder.init_embedding(td) if return_init_embeds else None
+            self._shared_dt["native"] = (ekey, t["emb"].detach(), init_embeds, None)
+        return own
 
     def _attach_grad(self, out: dict, p: dict) -> dict:
         from .train import evaluate_log_likelihood
@@ -777,7 +809,9 @@ class AttentionModelPolicy(nn.Module):
             ent = shared.get("native")
             ent = ent if ent is not None and ent[0] == ekey else None
         if ent is not None:
-            hidden, init_embeds, spec = ent[1:]
+            hidden, init_embeds, spec = ent[1:]         # (spec None: embeddings of the training graph, cache GEMMs below)
+            if init_embeds is None and return_init_embeds:
+                init_embeds = self.encoder.init_embedding(td)
         else:
             hidden, init_embeds = self.encoder(td, cache_spec=spec) if spec is not None else self.encoder(td)
             if ekey is not None and spec.get("filled"):

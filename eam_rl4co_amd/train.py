@@ -164,6 +164,14 @@ def encode_autograd(policy, td):
         else:
             feat = torch.cat((locs[:, 1:], td["demand"][..., None]), -1)
         h = torch.cat((depot, F.linear(feat, ie.init_embed.weight, ie.init_embed.bias)), 1)
+    if locs.is_cuda:
+        # the VALUE of the rollout's own init embedding (its kernels' rounding), the gradient of the expression above:
+        # x + (y - y) is exactly x.  With that, the Linears / attention / instance norms below being the rollout's kernels,
+        # the embeddings of this graph equal the native encoder's bit for bit (instance-norm policies;
+        # test_training_graph_encoder_equals_native_encoder) and one encoder pass can serve rollout and gradient.
+        with torch.no_grad():
+            h_native = ie(td)
+        h = h_native + (h - h.detach())
     training = policy.training
     for layer in enc.net.layers:
         mha, ffn = layer[0].module, layer[2].module
@@ -366,6 +374,30 @@ def _graph_key(policy, td):
         ver += p_._version
         ptr += p_.data_ptr()
     return ins, ver, ptr, policy.training, torch.is_grad_enabled()
+
+
+def graph_encoder_equals_native(policy, td) -> bool:
+    """True where `encode_autograd` reproduces the native encoder's embeddings bit for bit: instance-norm layers (their
+    training forward kernel sums in the rollout's order; batch norm goes through torch's batch_norm), every Linear, the
+    self-attention and the norms on this library's kernels (none of the EAMRL_TORCH_* switches), fp32 on the GPU."""
+    if any(os.environ.get(k, "0") == "1" for k in ("EAMRL_TORCH_LINEAR", "EAMRL_TORCH_ATTENTION", "EAMRL_TORCH_INSTANCE_NORM",
+                                                  "EAMRL_SEPARATE_ENCODER_PASSES")):
+        return False
+    locs = td["locs"]
+    enc = getattr(policy, "encoder", None)
+    layers = getattr(getattr(enc, "net", None), "layers", None)
+    if layers is None or not locs.is_cuda or locs.dtype != torch.float32 or locs.shape[1] > 112:
+        return False
+    for layer in layers:
+        mha, ffn = layer[0].module, layer[2].module
+        E = mha.Wqkv.weight.shape[1]
+        if E != 128 or mha.num_heads != 8 or len(ffn.lins) != 2 or ffn.lins[0].weight.shape[0] % 128:
+            return False
+        for norm in (layer[1], layer[3]):
+            n = norm.normalizer
+            if not isinstance(n, nn.InstanceNorm1d) or n.weight is None or n.bias is None:
+                return False
+    return True
 
 
 def decoder_tensors(policy, td):

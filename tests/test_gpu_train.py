@@ -416,6 +416,25 @@ def test_encoder_attention_backward_kernel_matches_torch(B, N):
     assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("cfg,env_name,N,B", [("pomo_tsp", "tsp", 20, 7), ("pomo_tsp", "tsp", 100, 5), ("pomo_tsp", "tsp", 50, 64)])
+def test_training_graph_encoder_equals_native_encoder(cfg, env_name, N, B):
+    """The differentiable encoder of the training graph (train.encode_autograd: eamrl_linear, eamrl_mha_encoder and
+    eamrl_instance_norm_forward behind autograd Functions) reproduces the native encoder's embeddings bit for bit for
+    instance-norm policies -- the fused kernel's, which in turn equal the oracle's."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd.train import encode_autograd
+
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=N)
+    torch.manual_seed(N + B)
+    td = env.reset(batch_size=[B]).to(DEV)
+    pol = make_policy(cfg).train()
+    with torch.no_grad():
+        native, _ = pol.encoder(td)
+    graph = encode_autograd(pol, td)
+    assert graph.requires_grad
+    assert_bits_equal(graph.detach(), native.cpu().numpy(), "embeddings")
+
+
 @pytest.mark.parametrize("rows,out_dim,in_dim,strided", [
     (1, 128, 128, False), (15, 128, 128, False), (64, 384, 128, False), (1000, 512, 128, False), (777, 128, 512, False),
     (6400, 384, 128, True), (102400, 128, 128, False),
