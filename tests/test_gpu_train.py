@@ -6,6 +6,8 @@ reference's trainers run on it unchanged.  The tests restate `REINFORCE.calculat
 for line around the policy call, backpropagate, and compare with gradients recorded from the reference itself
 (`tests/golden/make_golden.py train`: the reference policy in train() mode, sampling with recorded noise).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -416,23 +418,45 @@ def test_encoder_attention_backward_kernel_matches_torch(B, N):
     assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * scale
 
 
-@pytest.mark.parametrize("cfg,env_name,N,B", [("pomo_tsp", "tsp", 20, 7), ("pomo_tsp", "tsp", 100, 5), ("pomo_tsp", "tsp", 50, 64)])
-def test_training_graph_encoder_equals_native_encoder(cfg, env_name, N, B):
+@pytest.mark.parametrize("env_name,N,B,layers,gctx", [
+    ("tsp", 20, 7, 6, False), ("tsp", 100, 5, 6, False), ("tsp", 50, 64, 6, False), ("tsp", 21, 3, 3, True),
+    ("cvrp", 20, 6, 6, False), ("cvrp", 100, 3, 6, False), ("pctsp", 20, 4, 3, True), ("op", 20, 4, 3, True),
+    ("cvrptw", 20, 4, 3, True), ("sdvrp", 20, 4, 3, True),
+])
+def test_training_graph_encoder_equals_native_encoder(env_name, N, B, layers, gctx):
     """The differentiable encoder of the training graph (train.encode_autograd: eamrl_linear, eamrl_mha_encoder and
-    eamrl_instance_norm_forward behind autograd Functions) reproduces the native encoder's embeddings bit for bit for
-    instance-norm policies -- the fused kernel's, which in turn equal the oracle's."""
+    eamrl_instance_norm_forward behind autograd Functions, the init embedding's value from the native kernel) reproduces
+    the native encoder's embeddings bit for bit for instance-norm policies -- the fused kernel's, which in turn equal the
+    oracle's.  That is what lets one encoder pass serve rollout and gradient (AttentionModelPolicy._one_encoder_pass)."""
     import eam_rl4co_amd as ea
-    from eam_rl4co_amd.train import encode_autograd
+    from eam_rl4co_amd.train import encode_autograd, graph_encoder_equals_native
 
     env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=N)
     torch.manual_seed(N + B)
     td = env.reset(batch_size=[B]).to(DEV)
-    pol = make_policy(cfg).train()
+    pol = ea.AttentionModelPolicy(env_name=env_name, num_encoder_layers=layers, normalization="instance",
+                                  use_graph_context=gctx).to(DEV).train()
+    assert graph_encoder_equals_native(pol, td)
     with torch.no_grad():
         native, _ = pol.encoder(td)
     graph = encode_autograd(pol, td)
     assert graph.requires_grad
     assert_bits_equal(graph.detach(), native.cpu().numpy(), "embeddings")
+    # ... and a training forward built on it gives the rollout of the two-pass version, bit for bit
+    res = []
+    for separate in ("0", "1"):
+        os.environ["EAMRL_SEPARATE_ENCODER_PASSES"] = separate
+        try:
+            torch.manual_seed(5)
+            out = pol(td.clone(), env, phase="train", decode_type="sampling")
+        finally:
+            os.environ.pop("EAMRL_SEPARATE_ENCODER_PASSES", None)
+        assert out["log_likelihood"].requires_grad
+        res.append(out)
+    assert torch.equal(res[0]["actions"], res[1]["actions"]) and torch.equal(res[0]["reward"], res[1]["reward"])
+    assert torch.equal(res[0]["log_likelihood"].detach(), res[1]["log_likelihood"].detach())
+    if env_name in ("tsp", "cvrp"):     # batch-norm policies keep the two passes (torch's batch_norm in the graph)
+        assert not graph_encoder_equals_native(make_policy("am_" + env_name), td)
 
 
 @pytest.mark.parametrize("rows,out_dim,in_dim,strided", [
