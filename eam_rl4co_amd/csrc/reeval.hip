@@ -533,14 +533,16 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
             const int act = qj >= 0 ? act_l : -1;
             const float g = live ? g_l : 0.0f;
             float lse = live ? lse_l : 0.0f;
+            float zr[4] = {0.f, 0.f, 0.f, 0.f}, dz[4] = {0.f, 0.f, 0.f, 0.f};
+            if (wv < RTT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zr[r] = process_logit(u[r], a.clip, inv_temp, dz[r]);
+            }
             if (derive_lse) {           // the lane that owns the chosen node publishes z[action] - logp for its query
                 if (wv < RTT) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float dzdu;
-                        const float z = process_logit(u[r], a.clip, inv_temp, dzdu);
-                        if (16 * wv + 4 * r + G == act && g != 0.0f) LSE[j] = z - lse;
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * wv + 4 * r + G == act && g != 0.0f) LSE[j] = zr[r] - lse;
                 }
                 __syncthreads();
                 if (g != 0.0f) lse = LSE[j];
@@ -551,12 +553,10 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
                     const int n0 = 16 * wv + 4 * r;
                     const uint32_t w = (n0 >> 5) == 0 ? mb.x : (n0 >> 5) == 1 ? mb.y : (n0 >> 5) == 2 ? mb.z : mb.w;
                     const bool ok = (w >> ((n0 & 31) + G)) & 1u;
-                    float dzdu;
-                    const float z = process_logit(u[r], a.clip, inv_temp, dzdu);
                     float du = 0.0f;
                     if (ok && g != 0.0f) {
-                        const float p = fexp(z - lse);
-                        du = g * ((n0 + G == act ? 1.0f : 0.0f) - p) * dzdu;
+                        const float p = fexp(zr[r] - lse);
+                        du = g * ((n0 + G == act ? 1.0f : 0.0f) - p) * dz[r];
                     }
                     DU[(n0 + G) * DS + j] = du;
                 }
