@@ -333,6 +333,7 @@ static int check_reeval(const eamrl_reeval* p, const char* what, bool bwd)
     REQUIRE(p->B > 0 && p->S > 0 && p->T > 0 && p->R == p->B * p->S && p->nchunk >= 1 && p->nchunk <= p->S, what);
     REQUIRE(p->ld >= 128 && p->ld % 4 == 0 && p->NC >= 0 && p->NC <= 4 && (p->NC == 0 || (p->Cvec && p->sc)), what);
     REQUIRE(p->temp > 0.0f && p->tstart >= 0, what);
+    REQUIRE(!p->heads || (p->heads_T > 0 && (uintptr_t)p->heads % 16 == 0), what);
     REQUIRE(((uintptr_t)p->Pa % 16 == 0) && (!p->Pb || (uintptr_t)p->Pb % 16 == 0) && (!p->gctx || (uintptr_t)p->gctx % 16 == 0) &&
                 (!p->Cvec || (uintptr_t)p->Cvec % 16 == 0) && ((uintptr_t)p->maskbits % 16 == 0), what);
     if (bwd) {
@@ -340,7 +341,7 @@ static int check_reeval(const eamrl_reeval* p, const char* what, bool bwd)
         REQUIRE((p->Pb == nullptr) == (p->dPb == nullptr) && (p->gctx == nullptr) == (p->dgctx == nullptr) &&
                     (p->NC == 0 || p->dCvec) && ((uintptr_t)p->dheads % 16 == 0), what);
         REQUIRE(p->NC <= 2 && p->R * (int64_t)p->T < (int64_t)1 << 31, what);     // the backward kernels' query indices
-        REQUIRE(!p->heads || (p->heads_T > 0 && (uintptr_t)p->heads % 16 == 0), what);
+
     }
     return 0;
 }

@@ -226,7 +226,8 @@ __device__ __forceinline__ float process_logit(float u, float clip, float inv_te
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: logp[r][t], lse[r][t]
 // ---------------------------------------------------------------------------------------------------------------------
-template <int RTT>
+// HEADS: the rollout's glimpse outputs (eamrl_reeval.heads) are staged instead of recomputed (training: the entropy pass)
+template <int RTT, bool HEADS>
 __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
 {
     __shared__ __attribute__((aligned(16))) float QT[16 * TS];
@@ -242,12 +243,12 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
     const int64_t ntiles = (nq + 15) / 16;
 
     float kf[RTT][4], vtf[4 * RTT], lpf[32];
-    load_head_frags<RTT>(a, b, wv, lane, kf, vtf);
+    if (!HEADS) load_head_frags<RTT>(a, b, wv, lane, kf, vtf);
     if (wv < RTT) load_lp_frags(a, b, wv, lane, lpf);
     const float inv_temp = 1.0f / a.temp;
 
     for (int64_t tile = 0; tile < ntiles; ++tile) {
-        build_query_tile(a, b, s0, nq, tile, QT);
+        if (!HEADS) build_query_tile(a, b, s0, nq, tile, QT);
         const Q q = tile_query(a, b, s0, nq, tile, j);
         uint4 mb = make_uint4(0, 0, 0, 0);
         int act = -1;
@@ -255,8 +256,20 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
             mb = *reinterpret_cast<const uint4*>(a.maskbits + q.qi * 4);
             act = (int)a.actions[q.qi];
         }
-        __syncthreads();
-        glimpse_tile<RTT>(kf, vtf, QT, HT, wv, lane, mb, a.M);
+        if (HEADS) {
+            const int jq = threadIdx.x >> 5, e4 = threadIdx.x & 31;
+            const Q qq = tile_query(a, b, s0, nq, tile, jq);
+            const int th = qq.t - a.tstart;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qq.qi >= 0 && qq.active && th < a.heads_T)
+                v = *reinterpret_cast<const float4*>(a.heads + (qq.r * a.heads_T + th) * RE + 4 * e4);
+            __syncthreads();            // the previous tile's readers of HT are done
+            float* hp = HT + jq * TS + e4;
+            hp[0] = v.x; hp[TG] = v.y; hp[2 * TG] = v.z; hp[3 * TG] = v.w;
+        } else {
+            __syncthreads();
+            glimpse_tile<RTT>(kf, vtf, QT, HT, wv, lane, mb, a.M);
+        }
         __syncthreads();
         f32x4 z = z4();
         float mx = -INFINITY;
@@ -319,7 +332,8 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
 template <int RTT>
 static int launch_fwd_t(const ReevalArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_reeval_fwd<RTT>, dim3((unsigned)(a.B * a.nchunk)), dim3(512), 0, st, a);
+    if (a.heads) hipLaunchKernelGGL((k_reeval_fwd<RTT, true>), dim3((unsigned)(a.B * a.nchunk)), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_reeval_fwd<RTT, false>), dim3((unsigned)(a.B * a.nchunk)), dim3(512), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 

@@ -446,6 +446,8 @@ class ReevalPlan:
         s.clip, s.temp = self.clip, self.temp
         s.logp, s.lse = _ptr(self.logp), _ptr(self.lse)
         s.entropy = _ptr(self.entropy)
+        if self.heads is not None:
+            s.heads, s.heads_T = _ptr(self.heads), self.heads.shape[1]
         return s
 
     def forward(self):
@@ -476,8 +478,6 @@ class ReevalPlan:
         E4 = self.E * 4
         base = dbuf.data_ptr()
         s.glogp, s.dheads = _ptr(glogp), _ptr(dheads)
-        if self.heads is not None:
-            s.heads, s.heads_T = _ptr(self.heads), self.heads.shape[1]
         s.dK, s.dV, s.dLp, s.dPa = (C.c_void_p(base + i * E4) for i in range(4))
         s.dPb = C.c_void_p(base + 4 * E4) if self.has_pb else None
         s.ldg = dbuf.shape[2]

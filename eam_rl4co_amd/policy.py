@@ -1020,7 +1020,7 @@ class AttentionModelPolicy(nn.Module):
         slots = {n: cache.slots[n] for n in ("K", "V", "Lp", "Pa") + (("Pb",) if "Pb" in cache.slots else ())}
         plan = ops.ReevalPlan(cache.buf, "Pb" in cache.slots, cache.gctx, cvec, meta["idxA"], meta["idxB"], meta["sc"],
                               meta["maskbits"], acts, S, meta["tstart"], float(p["tanh_clipping"]), float(p["temperature"]),
-                              slots=slots, E=E, want_entropy=True)
+                              slots=slots, E=E, want_entropy=True, rollout_heads=p.get("final_heads"))
         plan.forward()
         return plan.entropy.sum(1)
 

@@ -284,7 +284,7 @@ typedef struct eamrl_reeval {
                                                              * lse == NULL (no forward pass run), logp = the ROLLOUT's per-step
                                                              * log-probs of `actions`, from which the normaliser is recovered */
     const float* glogp; float* dheads;                      /* backward: dL/dlogp [R][T]; scratch [R][T][E], R * T < 2^31 */
-    const float* heads; int heads_T;                        /* backward, optional: the rollout's glimpse outputs [R][heads_T][E]
+    const float* heads; int heads_T;                        /* forward and backward, optional: the rollout's glimpse outputs [R][heads_T][E]
                                                              * (eamrl_state.heads_out) of exactly these actions, decode step
                                                              * t - tstart of row r at (r * heads_T + t - tstart) * E; NULL: recomputed */
     float* entropy;                                         /* forward, optional: [R][T] entropy of each step's distribution

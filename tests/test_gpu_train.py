@@ -354,12 +354,14 @@ def test_backward_with_the_rollouts_heads_equals_recomputation(cfg, env_name, N,
     for recompute in ("0", "1"):
         monkeypatch.setenv("EAMRL_REEVAL_RECOMPUTE_HEADS", recompute)
         pol.zero_grad()
-        out = pol(td.clone(), env, phase="train", decode_type="multistart_sampling", num_starts=ns, noise=noise)
+        out = pol(td.clone(), env, phase="train", decode_type="multistart_sampling", num_starts=ns, noise=noise,
+                  return_entropy=True)          # (the entropy pass reads the rollout's heads too)
         w = torch.randn(out["log_likelihood"].shape, generator=torch.Generator().manual_seed(1)).to(DEV)
         (out["log_likelihood"] * w).sum().backward()
-        res.append((out["actions"], {k: p.grad.clone() for k, p in pol.named_parameters() if p.grad is not None}))
-    assert seen == [True, False]
+        res.append((out["actions"], {k: p.grad.clone() for k, p in pol.named_parameters() if p.grad is not None}, out["entropy"]))
+    assert seen == [True, True, False, False]       # entropy plan, gradient plan
     assert torch.equal(res[0][0], res[1][0])
+    np.testing.assert_allclose(res[0][2].cpu().numpy(), res[1][2].cpu().numpy(), rtol=2e-5, atol=1e-5)
     gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in res[1][1].values())))
     for k, ref in res[1][1].items():
         rel = float((res[0][1][k].double() - ref.double()).norm()) / max(float(ref.double().norm()), 1e-2 * gnorm)
