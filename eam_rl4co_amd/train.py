@@ -371,8 +371,14 @@ def _graph_key(policy, td):
     running statistics of batch norm are read only then; in train mode every native rollout updates them in place)."""
     ins = tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in sorted(td.items(), key=lambda kv: kv[0])
                 if torch.is_tensor(v))
+    # (walking the module tree costs 0.3 ms per call and a step asks several times: the lists of Parameter / buffer objects
+    # are kept -- .to(), load_state_dict and optimizer steps keep the objects; the key is only ever compared within one step)
+    lists = policy.__dict__.get("_key_tensors")
+    if lists is None:
+        lists = (list(policy.parameters()), list(policy.buffers()))
+        policy.__dict__["_key_tensors"] = lists
     ver = ptr = 0
-    for p_ in list(policy.parameters()) + ([] if policy.training else list(policy.buffers())):
+    for p_ in lists[0] + ([] if policy.training else lists[1]):
         ver += p_._version
         ptr += p_.data_ptr()
     return ins, ver, ptr, policy.training, torch.is_grad_enabled()
