@@ -1130,11 +1130,15 @@ def _rollout_outputs(R, t_max, dev):
     return actions, logps, flags
 
 
+HEADS_CAPTURE_MAX_BYTES = 48 << 30      # larger rollouts let the backward recompute the glimpse instead (5 - 11 GB at the POMO sizes)
+
+
 def _capture_heads(st, cache, cs, R, t_max, want_heads):
     """Training: a [R, t_max, E] buffer for the steps' glimpse outputs where the kernel chosen for this shape writes it
     (eamrl_state.heads_out; st.heads afterwards, None otherwise)."""
     st.heads = st.heads_out = None
-    if want_heads and _lib.load().eamrl_rollout_rng_native(ENVS[st.env_name], C.byref(cs), R):
+    if (want_heads and R * int(t_max) * cache.E * 4 <= HEADS_CAPTURE_MAX_BYTES
+            and _lib.load().eamrl_rollout_rng_native(ENVS[st.env_name], C.byref(cs), R)):
         st.heads = st.heads_out = torch.empty(R, int(t_max), cache.E, dtype=torch.float32, device=st.mask.device)
 
 
