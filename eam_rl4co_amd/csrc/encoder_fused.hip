@@ -72,6 +72,19 @@ __device__ unsigned long long g_enc_stamps[24];
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// One ds_read_b64.  The A fragments of two k-steps are 8 bytes at an 8-byte-aligned address; read as plain float2 pairs the
+// compiler fuses neighbouring ones into ds_read2_b64, which the LDS services in 16-lane groups on 32 banks (8 array cycles,
+// and with the (SA, GA) layout 2-way conflicts on top: 16 cycles per pair -- the 46 % conflict cycles of profiles/r02g_pmc_lds_*),
+// while two ds_read_b64 take 2 + 2 cycles on 64 banks, conflict-free (MI355X_MICROARCH.md, LDS table).  A volatile access is
+// not merged.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 lds_read_b64(const float* p)
+{
+    typedef const volatile __attribute__((address_space(3))) f32x2v* lds_ptr;      // (address-space inference skips volatile accesses)
+    const f32x2v v = *(lds_ptr)(p);
+    return make_float2(v.x, v.y);
+}
+
 // First group of B fragments of a pass: issued early (before the previous phase's epilogue / barrier) so that the L2 latency
 // of a pass's first weights is not paid behind the barrier.
 template <int CT>
@@ -100,8 +113,8 @@ __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[RTW][CT], const float* ar
 #pragma unroll
     for (int rt = 0; rt < RTW; ++rt)
         if (rt < nrt) {
-            an0[rt] = *reinterpret_cast<const float2*>(arow + rt * 16 * S);
-            an1[rt] = *reinterpret_cast<const float2*>(arow + rt * 16 * S + 2);
+            an0[rt] = lds_read_b64(arow + rt * 16 * S);
+            an1[rt] = lds_read_b64(arow + rt * 16 * S + 2);
         }
     for (int u = 0; u < NU; ++u) {
         float4 b[CT];
@@ -116,8 +129,8 @@ __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[RTW][CT], const float* ar
 #pragma unroll
             for (int rt = 0; rt < RTW; ++rt)
                 if (rt < nrt) {
-                    an0[rt] = *reinterpret_cast<const float2*>(arow + rt * 16 * S + 4 * (u + 1));
-                    an1[rt] = *reinterpret_cast<const float2*>(arow + rt * 16 * S + 4 * (u + 1) + 2);
+                    an0[rt] = lds_read_b64(arow + rt * 16 * S + 4 * (u + 1));
+                    an1[rt] = lds_read_b64(arow + rt * 16 * S + 4 * (u + 1) + 2);
                 }
         }
 #pragma unroll

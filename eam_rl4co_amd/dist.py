@@ -120,6 +120,50 @@ class FlatGradBuffer:
 
 
 @torch.no_grad()
+def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> int:
+    """Every rank takes rank `src`'s parameters and buffers -- what DistributedDataParallel does at construction
+    (and, for buffers, before each forward; rl4co/utils/trainer.py:72-89).  One flat fp32 buffer for the floating-point
+    tensors (parameters, BatchNorm running statistics), one int64 buffer for integer buffers (`num_batches_tracked`).
+    Returns the number of elements sent; a no-op outside a process group."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    tensors = [p.data for p in module.parameters()] + [b for b in module.buffers()]
+    sent = 0
+    for is_float in (True, False):
+        group = [t for t in tensors if t.is_floating_point() == is_float]
+        if not group:
+            continue
+        flat = torch.cat([t.reshape(-1).to(torch.float32 if is_float else torch.int64) for t in group])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in group:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        sent += flat.numel()
+    return sent
+
+
+@torch.no_grad()
+def allreduce_buffers(module: torch.nn.Module) -> int:
+    """Mean of the floating-point buffers over the ranks (BatchNorm running statistics under `policy.train()`: each rank
+    updates them from its own shard; DDP would instead overwrite them with rank 0's -- the mean keeps every shard's
+    statistics and leaves all ranks identical, which is what the bit-identical-replica guarantee needs)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    bufs = [b for b in module.buffers() if b.is_floating_point()]
+    if not bufs:
+        return 0
+    flat = torch.cat([b.reshape(-1).float() for b in bufs])
+    dist.all_reduce(flat)
+    flat /= dist.get_world_size()
+    off = 0
+    for b in bufs:
+        b.copy_(flat[off:off + b.numel()].view_as(b))
+        off += b.numel()
+    return flat.numel()
+
+
+@torch.no_grad()
 def allreduce_gradients(module: torch.nn.Module, average: bool = True):
     """Sum (mean) gradients across ranks with one flat all-reduce; returns the number of elements reduced.
     With a `FlatGradBuffer` attached to the module (`module._flat_grads`) this is the buffer's zero-copy all-reduce;
@@ -163,3 +207,21 @@ def allreduce_scalars(values: dict, average: bool = True) -> dict:
     if average:
         t /= dist.get_world_size()
     return {k: float(v) for k, v in zip(keys, t)}
+
+
+DEFAULT_METRICS = {"train": ("loss", "reward"), "val": ("reward",), "test": ("reward",)}
+
+
+@torch.no_grad()
+def sync_metrics(metric_dict: dict, phase: str, metrics: dict | None = None, dataloader_name: str = "") -> dict:
+    """What `RL4COLitModule.log_metrics` hands to Lightning with `sync_dist=True` (rl4co/models/rl/common/base.py:111-119,
+    216-241): of a step's outputs only the phase's metric names (default train: loss, reward; val / test: reward), each
+    reduced to its mean, keyed `"{phase}/{name}"` (+ `"/{dataloader}"`), then averaged over the ranks -- ONE all-reduce of
+    a few scalars per call.  Returns {key: float}."""
+    wanted = (metrics or DEFAULT_METRICS).get(phase, ())
+    suffix = f"/{dataloader_name}" if dataloader_name else ""
+    local = {}
+    for k, v in metric_dict.items():
+        if k in wanted:
+            local[f"{phase}/{k}{suffix}"] = float(v.float().mean()) if isinstance(v, torch.Tensor) else float(v)
+    return allreduce_scalars(local, average=True)

@@ -788,13 +788,18 @@ class PolicyGradientStep:
                                                                          # utils/trainer.py:55,72-89; configs/experiment/routing/pomo.yaml
 
     Each rank owns its own instances (all starts of an instance on one GPU); the gradient buffer is the only thing
-    exchanged (dist.FlatGradBuffer: p.grad are views, no copy kernels around the collective).  Every rank ends the step
-    with bit-identical parameters: the reduced buffer is identical on all ranks and the update is deterministic."""
+    exchanged (dist.FlatGradBuffer: p.grad are views, no copy kernels around the collective).  At construction every rank
+    takes rank 0's parameters and buffers (as DDP does), so the ranks may have been seeded differently; from then on every
+    rank ends a step with bit-identical parameters: the reduced buffer is identical on all ranks and the update is
+    deterministic.  With batch normalisation in train() mode the running statistics, which each rank updates from its own
+    shard, are averaged over the ranks after the step (`sync_buffers`; DDP broadcasts rank 0's instead)."""
 
     def __init__(self, policy, env, num_starts: int = 0, baseline: str = None, lr: float = 1e-4, weight_decay: float = 1e-6,
                  max_grad_norm: float = 1.0, optimizer=None):
-        from .dist import FlatGradBuffer
+        from .dist import FlatGradBuffer, broadcast_module_state
 
+        broadcast_module_state(policy, src=0)        # before the optimizer reads the parameters
+        self.sync_buffers = any(b.is_floating_point() for b in policy.buffers())
         self.policy, self.env, self.S = policy, env, int(num_starts)
         self.baseline = baseline or ("shared" if self.S > 1 else "mean")
         self.max_grad_norm = max_grad_norm
@@ -811,4 +816,8 @@ class PolicyGradientStep:
         self.grads.allreduce(average=True)
         out["grad_norm"] = self.grads.clip_(self.max_grad_norm) if self.max_grad_norm else None
         self.optimizer.step()
+        if self.sync_buffers and self.policy.training:
+            from .dist import allreduce_buffers
+
+            allreduce_buffers(self.policy)
         return out

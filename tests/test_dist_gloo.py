@@ -121,6 +121,76 @@ def test_flat_grad_buffer_two_ranks_end_with_identical_parameters():
     assert sorted(out.get(timeout=5) for _ in range(2)) == [0, 1]
 
 
+def _init_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import dist as ed
+    from eam_rl4co_amd.train import PolicyGradientStep
+
+    ed.init_distributed("gloo")
+    torch.manual_seed(1000 + rank)                         # DIFFERENT initial weights per rank
+    pol = ea.AttentionModelPolicy(env_name="tsp", num_encoder_layers=1)        # batch norm: running statistics are buffers
+    with torch.no_grad():
+        for b in pol.buffers():
+            if b.is_floating_point():
+                b.add_(float(rank))
+    before = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).clone()
+    step = PolicyGradientStep(pol, env=None, num_starts=0)  # construction broadcasts rank 0's parameters and buffers
+
+    def gathered(t):
+        both = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(both, t)
+        return both
+
+    flat = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+    both = gathered(flat)
+    assert torch.equal(both[0], both[1]), "ranks start from different parameters"
+    assert torch.equal(flat, before) == (rank == 0)        # rank 0 kept its own, rank 1 took rank 0's
+    bufs = torch.cat([b.detach().reshape(-1).float() for b in pol.buffers()])
+    bb = gathered(bufs)
+    assert torch.equal(bb[0], bb[1])
+    # the collective half of a step (the rollout half needs the GPU): per-rank gradients -> all-reduce -> clip -> Adam
+    step.grads.zero_()
+    g = torch.Generator().manual_seed(rank)
+    sum((p * torch.randn(p.shape, generator=g)).sum() for p in pol.parameters()).backward()
+    step.grads.allreduce(average=True)
+    step.grads.clip_(1.0)
+    step.optimizer.step()
+    with torch.no_grad():                                   # each rank's shard moved the running statistics differently
+        for b in pol.buffers():
+            if b.is_floating_point():
+                b.add_(0.25 * (rank + 1))
+    ed.allreduce_buffers(pol)
+    both = gathered(torch.cat([p.detach().reshape(-1) for p in pol.parameters()]))
+    assert torch.equal(both[0], both[1]), "ranks hold different parameters after one step"
+    bb = gathered(torch.cat([b.detach().reshape(-1).float() for b in pol.buffers()]))
+    assert torch.equal(bb[0], bb[1])
+    # metric reduction with the reference's keys (log_metrics(..., sync_dist=True), rl/common/base.py:216-241)
+    out_dict = {"loss": torch.tensor(float(rank)), "reward": torch.full((5,), -10.0 * (rank + 1)), "actions": torch.zeros(5, 3),
+                "log_likelihood": torch.ones(5)}
+    m = ed.sync_metrics(out_dict, "train")
+    assert sorted(m) == ["train/loss", "train/reward"] and abs(m["train/loss"] - 0.5) < 1e-12 and abs(m["train/reward"] + 15) < 1e-12
+    v = ed.sync_metrics(out_dict, "val", dataloader_name="tsp100")
+    assert list(v) == ["val/reward/tsp100"] and abs(v["val/reward/tsp100"] + 15) < 1e-12
+    dist.barrier()
+    dist.destroy_process_group()
+    out.put(rank)
+
+
+def test_policy_gradient_step_broadcasts_rank0_state_and_syncs_metrics():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_init_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    assert sorted(out.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
 def test_bench_gpus_flag_launches_the_ranks_itself():
     """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE): the parent spawns two ranks before touching any GPU;
     rank 0 prints ONE JSON line with n_gpus == 2.  The selftest workload runs the collective half of the training step
