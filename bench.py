@@ -73,6 +73,35 @@ def algorithmic_flops_per_query_step(M, E=128):
     return 6 * M * E + 4 * E * E + 2 * E * E
 
 
+def executed_flops_per_query_step(M, E=128):
+    """What the decode kernels execute per query-step: 6*M*E.  The 6*E*E of SURVEY 8(d) (context and output projections) are
+    folded into the Pa / Pb / Lp cache slots and are executed -- and counted -- once per node in the encoder
+    launch's cache term, so pricing the decode loop with them would count them twice."""
+    return 6 * M * E
+
+
+def measured_counters(workload, family):
+    """MFMA-pipe busy fraction and achieved clock of a kernel family from the committed PMC pass (profiles/r0N*_mfma_counters.json,
+    tools/collect_mfma_counters.sh + tools/summarize_counters.py): SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), and
+    GRBM_GUI_ACTIVE / 8 XCDs / duration.  Counters cannot be collected inside the timed run; None when no pass is committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_mfma_counters.json")), reverse=True):
+        try:
+            with open(path) as f:
+                e = json.load(f).get(workload, {}).get(family)
+        except (OSError, ValueError):
+            continue
+        if e:
+            c = e["counters_per_launch"]
+            out = {"source": os.path.relpath(path, ROOT), "kernel_ms_profiled": e["mean_duration_ms"], "clock_ghz": e.get("clock_ghz"),
+                   "valu_insts_per_launch": c.get("SQ_INSTS_VALU")}
+            if c.get("SQ_BUSY_CU_CYCLES") and c.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+                out["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"]), 4)
+                out["mfma_executed_tflop"] = round(c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512 / 1e12, 4)   # incl. padded rows
+            return out
+    return None
+
+
 def algorithmic_bytes_per_decode_step(env, M, E=128, S=1):
     """SURVEY.md 8(d), step-at-a-time API: 12*M*E (K,V,L) + 4*E*g (context rows) + 2*M (mask r/w) + c; multistart (per
     instance-step, S queries sharing K/V/L): 12*M*E + S*(8*E + 2*M + 28)."""
@@ -116,9 +145,10 @@ def build_policy(env_name, device, pomo=False):
     from _util import golden_weights
 
     pol = ea.AttentionModelPolicy(env_name=env_name, **(POMO_KW if pomo else {})).eval()
-    torch.manual_seed(0)
     sd = pol.state_dict()
-    for k, v in golden_weights(("pomo_" if pomo else "am_") + env_name).items():   # closed-form weights (untrained)
+    # closed-form weights (untrained, the goldens' streams) instead of SURVEY 8d's torch.manual_seed(0) default init: every rank
+    # then holds the same policy whatever its seed, and TSP timing does not depend on the weights (CVRP: T is reported)
+    for k, v in golden_weights(("pomo_" if pomo else "am_") + env_name).items():
         sd[k].copy_(torch.from_numpy(v))
     return pol.to(device)
 
@@ -356,7 +386,10 @@ def main():
     orig = {n: getattr(ops, n) for n in ("rollout", "linear", "matmul_right", "mha_encoder", "encoder_fused")}
 
     def fused_flops(a, r, k):   # per instance and layer: qkv + QK^T + PV + out_proj + FFN (algorithmic, unpadded)
-        Bq, Mq, Eq = a[0].shape
+        if a[0] is not None:
+            Bq, Mq, Eq = a[0].shape
+        else:       # init embedding computed inside the kernel: shapes from the feature tensor and its weight
+            (Bq, Mq, _), Eq = k["init"]["feat"].shape, k["init"]["W"].shape[0]
         per = 2.0 * Mq * Eq * 3 * Eq + 4.0 * Mq * Mq * Eq + 2.0 * Mq * Eq * Eq + 4.0 * Mq * Eq * a[3]
         tot = per * Bq * len(a[1])
         if k.get("cache") is not None:      # + the decoder cache projections done from LDS: (nproj + 1) x [M, E] x [E, E]
@@ -443,7 +476,7 @@ def main():
         traffic = measured_traffic(args.workload.replace("_train", ""), batch)
         if M <= 128:
             rb = resident_bytes_per_rollout(env_name, M, T, S=S, sampling="sampling" in decode_type) * batch
-            flops = algorithmic_flops_per_query_step(M) * batch * S * T
+            flops = executed_flops_per_query_step(M) * batch * S * T
             tf = flops / (kern * 1e-3) / 1e12
             roofline_decode = {
                 "kernel": ("k_rollout_ms_mfma (decode loop of all starts of an instance on fp32 MFMA, K/V/Lp as register fragments)"
@@ -455,8 +488,12 @@ def main():
                 "issue_bound": {"bound": "mfma" if S > 1 and env_name in ("tsp", "cvrp") and M <= 112 else "fp32 valu issue",
                                 "achieved": round(tf, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(tf / F32_PEAK_TFLOPS, 4),
-                                "note": "the kernel is instruction-issue / latency bound, not HBM bound (DESIGN.md 4): useful "
-                                        "flops 6*M*E + 6*E*E per row-step against the fp32 peak"},
+                                "note": "the kernel is instruction-issue / latency bound, not HBM bound (DESIGN.md 4): executed "
+                                        "flops 6*M*E per query-step against the fp32 peak (the 6*E*E context / output "
+                                        "projections of SURVEY 8d are folded into the cache and counted in the encoder launch)",
+                                "counters": measured_counters(args.workload.replace("_train", ""),
+                                                              "k_rollout_ms_mfma" if S > 1 and env_name in ("tsp", "cvrp") and M <= 112
+                                                              else "k_rollout_resident")},
                 "step_api_view": step_api}
         else:
             ach = (traffic or step_api_bytes) / (kern * 1e-3) / 1e9
@@ -484,7 +521,8 @@ def main():
                         "frac": round(enc_tf / F32_PEAK_TFLOPS, 4),
                         "traffic": measured_traffic(args.workload.replace("_train", ""), batch, "_encoder_fused"),
                         "kernel_ms": round(fam_ms["encoder_fused"], 4), "launches_per_step": ft.launches("encoder_fused", passes),
-                        "algorithmic_flops_per_launch": int(ft.flops.get("encoder_fused", 0.0) / passes)}
+                        "algorithmic_flops_per_launch": int(ft.flops.get("encoder_fused", 0.0) / passes),
+                        "counters": measured_counters(args.workload.replace("_train", ""), "k_encoder_fused")}
         dominant = max(fam_ms, key=lambda f: fam_ms[f])
         roofline = dict(roofline_enc if dominant == "encoder_fused" else roofline_gemm if dominant == "gemm" else
                         roofline_decode["issue_bound"] | {"kernel": roofline_decode["kernel"], "kernel_ms": round(kern, 4)}
@@ -506,12 +544,16 @@ def main():
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
-            "data": f"synthetic (uniform instances, {NBATCH} different batches in rotation)",
+            "data": f"synthetic (uniform instances, {NBATCH} different batches in rotation; closed-form untrained weights)",
             "config": cfg, "roofline": roofline, "roofline_decode": roofline_decode, "roofline_gemm": roofline_gemm,
             "roofline_attention": roofline_att, "roofline_encoder_fused": roofline_enc,
         }
         if strong is not None:
             line["strong_scaling"] = strong
+        # inputs of DESIGN.md 5's strong-scaling projection: this rank's share and how its step splits into the one-shot
+        # encoder and the sequential decode loop (the first real multi-GPU run can be compared with the per-share table)
+        line["per_gpu_share"] = {"batch_per_gpu": batch, "encoder_ms": round(fam_ms["encoder_fused"] + fam_ms["gemm"] + fam_ms["attention"], 4),
+                                 "decode_ms": round(fam_ms["decode"], 4), "rollout_ms_eager": round(rollout_only_ms, 4)}
         if identical is not None:
             line["params_identical"] = identical
         if not args.no_cpu_baseline and world == 1:      # a reported baseline of the 1-GPU run only (the other ranks would wait)

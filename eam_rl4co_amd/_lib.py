@@ -35,6 +35,12 @@ class EncoderCache(C.Structure):
     _fields_ = [("Wc", _vp), ("WoutT", _vp), ("out", _vp), ("ld", _i64), ("nproj", C.c_int32), ("Wg", _vp), ("gctx", _vp)]
 
 
+class EncoderInit(C.Structure):
+    """struct eamrl_encoder_init"""
+    _fields_ = [("feat", _vp), ("F", C.c_int32), ("W", _vp), ("b", _vp), ("depot", _vp), ("depot_ld", _i64), ("Wd", _vp),
+                ("bd", _vp), ("init_out", _vp)]
+
+
 class Reeval(C.Structure):
     """struct eamrl_reeval"""
     _fields_ = [("K", _vp), ("V", _vp), ("Lp", _vp), ("Pa", _vp), ("Pb", _vp), ("ld", _i64),
@@ -85,6 +91,7 @@ PROTOTYPES = {
     "eamrl_pack_linear_weight": [_vp, _vp, _i32, _i32, _vp],
     "eamrl_encoder_fused_supported": [_i32, _i32, _i32, _i32, _i32],
     "eamrl_encoder_fused": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
+    "eamrl_encoder_fused_init": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "eamrl_reeval_supported": [_i32, _i32, _i32],
     "eamrl_reeval_forward": [_vp, _vp],
     "eamrl_reeval_backward": [_vp, _vp],

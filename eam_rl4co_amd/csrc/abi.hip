@@ -298,30 +298,52 @@ __attribute__((visibility("default"))) int eamrl_encoder_fused_supported(int M, 
     return encoder_fused_supports(M, E, H, ff_hidden, nlayers) ? 1 : 0;
 }
 
+static int check_encoder_fused(int64_t B, int M, int E, int H, int ff_hidden, int nlayers, int norm,
+                               const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache, const char* what)
+{
+    if (cache) {
+        REQUIRE(cache->Wc && cache->WoutT && cache->out && cache->nproj >= 3 && cache->nproj <= 5, what);
+        REQUIRE(cache->ld >= (int64_t)(cache->nproj + 1) * E && cache->ld % 4 == 0 && ((uintptr_t)cache->out % 16 == 0) &&
+                    ((uintptr_t)cache->Wc % 16 == 0) && ((uintptr_t)cache->WoutT % 16 == 0), what);
+    }
+    REQUIRE(layers && B >= 0, what);
+    REQUIRE(encoder_fused_supports(M, E, H, ff_hidden, nlayers), what);
+    REQUIRE(norm == EAMRL_NORM_BATCH_EVAL || norm == EAMRL_NORM_INSTANCE, what);
+    for (int l = 0; l < nlayers; ++l) {
+        const eamrl_encoder_layer& s = layers[l];
+        REQUIRE(s.Wqkv && s.bqkv && s.Wo && s.bo && s.W1 && s.b1 && s.W2 && s.b2 && s.n1_gamma && s.n1_beta && s.n2_gamma &&
+                    s.n2_beta, what);
+        REQUIRE(((uintptr_t)s.Wqkv % 16 == 0) && ((uintptr_t)s.Wo % 16 == 0) && ((uintptr_t)s.W1 % 16 == 0) &&
+                    ((uintptr_t)s.W2 % 16 == 0), what);
+        if (norm == EAMRL_NORM_BATCH_EVAL) REQUIRE(s.n1_mean && s.n1_var && s.n2_mean && s.n2_var, what);
+    }
+    return 0;
+}
+
 __attribute__((visibility("default"))) int eamrl_encoder_fused(const float* h_in, float* h_out, int64_t B, int M, int E, int H,
                                                               int ff_hidden, int nlayers, int norm, float eps,
                                                               const eamrl_encoder_layer* layers,
                                                               const eamrl_encoder_cache* cache, void* stream)
 {
-    if (cache) {
-        REQUIRE(cache->Wc && cache->WoutT && cache->out && cache->nproj >= 3 && cache->nproj <= 5, "eamrl_encoder_fused");
-        REQUIRE(cache->ld >= (int64_t)(cache->nproj + 1) * E && cache->ld % 4 == 0 && ((uintptr_t)cache->out % 16 == 0) &&
-                    ((uintptr_t)cache->Wc % 16 == 0) && ((uintptr_t)cache->WoutT % 16 == 0), "eamrl_encoder_fused");
-    }
-    REQUIRE(h_in && h_out && layers && B >= 0, "eamrl_encoder_fused");
-    REQUIRE(encoder_fused_supports(M, E, H, ff_hidden, nlayers), "eamrl_encoder_fused");
-    REQUIRE(norm == EAMRL_NORM_BATCH_EVAL || norm == EAMRL_NORM_INSTANCE, "eamrl_encoder_fused");
+    if (int rc = check_encoder_fused(B, M, E, H, ff_hidden, nlayers, norm, layers, cache, "eamrl_encoder_fused")) return rc;
+    REQUIRE(h_in && h_out, "eamrl_encoder_fused");
     REQUIRE(((uintptr_t)h_in % 16 == 0) && ((uintptr_t)h_out % 16 == 0), "eamrl_encoder_fused");
-    for (int l = 0; l < nlayers; ++l) {
-        const eamrl_encoder_layer& s = layers[l];
-        REQUIRE(s.Wqkv && s.bqkv && s.Wo && s.bo && s.W1 && s.b1 && s.W2 && s.b2 && s.n1_gamma && s.n1_beta && s.n2_gamma &&
-                    s.n2_beta, "eamrl_encoder_fused");
-        REQUIRE(((uintptr_t)s.Wqkv % 16 == 0) && ((uintptr_t)s.Wo % 16 == 0) && ((uintptr_t)s.W1 % 16 == 0) &&
-                    ((uintptr_t)s.W2 % 16 == 0), "eamrl_encoder_fused");
-        if (norm == EAMRL_NORM_BATCH_EVAL) REQUIRE(s.n1_mean && s.n1_var && s.n2_mean && s.n2_var, "eamrl_encoder_fused");
-    }
-    return launched(launch_encoder_fused(h_in, h_out, B, M, nlayers, norm, eps, layers, cache, (hipStream_t)stream),
+    return launched(launch_encoder_fused(h_in, h_out, B, M, nlayers, norm, eps, layers, cache, nullptr, (hipStream_t)stream),
                     "eamrl_encoder_fused");
+}
+
+__attribute__((visibility("default"))) int eamrl_encoder_fused_init(const eamrl_encoder_init* init, float* h_out, int64_t B, int M,
+                                                                   int E, int H, int ff_hidden, int nlayers, int norm, float eps,
+                                                                   const eamrl_encoder_layer* layers,
+                                                                   const eamrl_encoder_cache* cache, void* stream)
+{
+    const char* what = "eamrl_encoder_fused_init";
+    if (int rc = check_encoder_fused(B, M, E, H, ff_hidden, nlayers, norm, layers, cache, what)) return rc;
+    REQUIRE(init && init->feat && init->W && init->F >= 1 && init->F <= 8, what);
+    REQUIRE(!init->depot || (init->Wd && init->depot_ld >= 2), what);
+    REQUIRE(h_out || cache, what);          // something must leave the kernel
+    REQUIRE((!h_out || (uintptr_t)h_out % 16 == 0) && (!init->init_out || (uintptr_t)init->init_out % 16 == 0), what);
+    return launched(launch_encoder_fused(nullptr, h_out, B, M, nlayers, norm, eps, layers, cache, init, (hipStream_t)stream), what);
 }
 
 static int check_reeval(const eamrl_reeval* p, const char* what, bool bwd)

@@ -60,6 +60,9 @@ struct FusedArgs {
     const float* Wc; const float* WoT; float* cache; int64_t ld; int nproj;
     // optional graph context: gctx[inst] = mean_n(h) Wg^T (embeddings.mean(1) -> project_fixed_context, no bias)
     const float* Wg; float* gctx;
+    // optional init embedding (h_in == nullptr): h[n] = Linear(feat[n]) computed straight into LDS (eamrl_encoder_init)
+    const float* feat; int F; const float* Wi; const float* bi; const float* depot; int64_t depot_ld; const float* Wd; const float* bd;
+    float* init_out;
     FusedLayer L[MAX_FUSED_LAYERS];
 };
 
@@ -229,15 +232,71 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
     unsigned long long st_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_readcyclecounter();
 #endif
 
-    // ---- load h (row-major in HBM) into the A layout; rows >= M are zero ------------------------------------------
-    {
+    // ---- h into the A layout; rows >= M are zero ---------------------------------------------------------------------
+    if (a.h_in) {
+        // from HBM (row-major): all of a thread's loads are issued before the first LDS store (a load-store loop pays the HBM
+        // latency once per trip: 7 trips = 27 k of the kernel's 900 k cycles, profiles/r03b_stamps_encoder_fused.txt)
+        constexpr int NLD = (ROWS * (FE / 4) + 511) / 512;
         const float* src = a.h_in + inst * (int64_t)M * FE;
-        for (int idx = tid; idx < ROWS * (FE / 4); idx += blockDim.x) {
+        float4 v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + u * 512;
             const int row = idx / (FE / 4), q4 = idx % (FE / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < M) v = *reinterpret_cast<const float4*>(src + (int64_t)row * FE + 4 * q4);
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < M) v[u] = *reinterpret_cast<const float4*>(src + (int64_t)row * FE + 4 * q4);
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + u * 512;
+            const int row = idx / (FE / 4), q4 = idx % (FE / 4);
+            if (row < ROWS) {
+                float* p = HB + row * SA + q4;
+                p[0] = v[u].x; p[GA] = v[u].y; p[2 * GA] = v[u].z; p[3 * GA] = v[u].w;
+            }
+        }
+    } else {
+        // init embedding computed in place (nn/env_embeddings/init.py: Linear(F -> E) of the node features; depot envs: row 0
+        // is Linear(2 -> E) of the depot coordinates): each output is chain_k(x[k], W[c][k], F, bias[c]), the order of
+        // eamrl_linear.  Thread = (row, four adjacent columns); the weights of its columns stay in registers over the rows.
+        const int q4 = tid % (FE / 4), r0 = tid / (FE / 4);          // 32 column groups x 16 row phases
+        const int F = a.F;
+        float w[4][8], wd[4][2], bb[4], bdv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bb[c] = a.bi ? a.bi[4 * q4 + c] : 0.0f;
+            bdv[c] = (a.depot && a.bd) ? a.bd[4 * q4 + c] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[c][k] = (k < F) ? a.Wi[(4 * q4 + c) * F + k] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) wd[c][k] = a.depot ? a.Wd[(4 * q4 + c) * 2 + k] : 0.0f;
+        }
+        const float* fsrc = a.feat + inst * (int64_t)M * F;
+        float* iout = a.init_out ? a.init_out + inst * (int64_t)M * FE : nullptr;
+        for (int row = r0; row < ROWS; row += 16) {
+            float y[4] = {0.f, 0.f, 0.f, 0.f};
+            if (row < M) {
+                if (a.depot && row == 0) {
+                    const float x0 = a.depot[inst * a.depot_ld], x1 = a.depot[inst * a.depot_ld + 1];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) y[c] = fma_(x1, wd[c][1], fma_(x0, wd[c][0], bdv[c]));
+                } else {
+                    float x[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) x[k] = (k < F) ? fsrc[(int64_t)row * F + k] : 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float acc = bb[c];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (k < F) acc = fma_(x[k], w[c][k], acc);
+                        y[c] = acc;
+                    }
+                }
+                if (iout) *reinterpret_cast<float4*>(iout + (int64_t)row * FE + 4 * q4) = make_float4(y[0], y[1], y[2], y[3]);
+            }
             float* p = HB + row * SA + q4;
-            p[0] = v.x; p[GA] = v.y; p[2 * GA] = v.z; p[3 * GA] = v.w;
+            p[0] = y[0]; p[GA] = y[1]; p[2 * GA] = y[2]; p[3 * GA] = y[3];
         }
     }
     __syncthreads();
@@ -482,8 +541,8 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
         }
         ESTAMP(12);
     }
-    // ---- store h (row-major, float4 per thread) ------------------------------------------------------------------------------
-    {
+    // ---- store h (row-major, float4 per thread); skipped when the caller keeps only the decoder cache -----------------------
+    if (a.h_out) {
         float* dst = a.h_out + inst * (int64_t)M * FE;
         for (int idx = tid; idx < M * (FE / 4); idx += blockDim.x) {
             const int row = idx / (FE / 4), q4 = idx % (FE / 4);
@@ -613,11 +672,18 @@ bool encoder_fused_supports(int M, int E, int H, int FFdim, int nlayers)
 }
 
 int launch_encoder_fused(const float* h_in, float* h_out, int64_t B, int M, int nlayers, int norm, float eps,
-                         const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache, hipStream_t st)
+                         const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache, const eamrl_encoder_init* init,
+                         hipStream_t st)
 {
     if (B <= 0) return 0;
     FusedArgs a;
     a.h_in = h_in; a.h_out = h_out; a.M = M; a.nlayers = nlayers; a.norm = norm; a.eps = eps;
+    a.feat = nullptr; a.F = 0; a.Wi = a.bi = a.depot = a.Wd = a.bd = nullptr; a.depot_ld = 0; a.init_out = nullptr;
+    if (init) {
+        a.h_in = nullptr;
+        a.feat = init->feat; a.F = init->F; a.Wi = init->W; a.bi = init->b; a.depot = init->depot; a.depot_ld = init->depot_ld;
+        a.Wd = init->Wd; a.bd = init->bd; a.init_out = init->init_out;
+    }
     a.Wc = nullptr; a.WoT = nullptr; a.cache = nullptr; a.ld = 0; a.nproj = 0; a.Wg = nullptr; a.gctx = nullptr;
     if (cache) {
         a.Wc = cache->Wc; a.WoT = cache->WoutT; a.cache = cache->out; a.ld = cache->ld; a.nproj = cache->nproj;

@@ -40,7 +40,8 @@ int launch_pointer_attention(const float* q, const float* K, const float* V, con
                              int E, int H, int mask_inner, hipStream_t st);
 bool encoder_fused_supports(int M, int E, int H, int FFdim, int nlayers);
 int launch_encoder_fused(const float* h_in, float* h_out, int64_t B, int M, int nlayers, int norm, float eps,
-                         const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache, hipStream_t st);
+                         const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache, const eamrl_encoder_init* init,
+                         hipStream_t st);
 int launch_pack_mfma_b(const float* W, float* Wp, int N, int K, hipStream_t st);
 // Linear weight gradient (train_gemm.hip)
 bool linear_wgrad_supports(int out_dim, int in_dim);

@@ -7,14 +7,17 @@
 // 512 rows are in flight on the chip and a 1024-row batch takes two waves of workgroups.  Per step nothing
 // but the selected action and its log-prob (12 B) goes to HBM, and the Exp(1) noise row when sampling.
 //
-// Thread layouts (tid in [0,256), lane = tid & 63, wave w = tid >> 6).  Each lane owns the node pair
-// (lane, lane + 64), so every reduction over nodes is one in-wave DPP butterfly and a step needs 4 barriers:
-//   scores   : wave w, heads 2w and 2w+1 : K[n][32w .. 32w+31] of both nodes in registers -> per-head max and
-//              softmax weights inside the wave
-//   glimpse  : thread (column e = tid & 127, g = tid >> 7) keeps V[n][e] for the nodes of chunks 2g and 2g+1
-//   logits   : wave w, column chunk w     : Lp[n][32w .. 32w+31] of both nodes; the 32 glimpse values of the
-//              chunk are finished by lanes 0-31 of the same wave and re-read through a wave-private LDS row
-//   finish   : wavefront 0: clip, mask, log-softmax, selection, env transition, next context query
+// Thread layouts (tid in [0,256), lane = tid & 63, wave w = tid >> 6).  A step is two phases and two barriers (round 3; it was
+// four stages and four barriers: the glimpse of a head needs only that head's weights and value columns, so a wavefront that
+// owns two heads can carry them from the scores to the logit partials of its own 32 columns without meeting the others):
+//   wave w, heads 2w and 2w+1, columns 32w .. 32w+31, no workgroup barrier inside:
+//     scores   : lane owns the node pair (lane, lane + 64): K[n][32w .. 32w+31] of both nodes in registers -> per-head max
+//                and softmax weights by in-wave DPP butterflies; the weights go to two wave-private LDS rows
+//     glimpse  : lane (j = lane & 31, half = lane >> 5) keeps V[n][32w + j] for the nodes of chunks 2 half and 2 half + 1;
+//                the two halves' chunk sums meet through v_permlane32_swap
+//     logits   : Lp[n][32w .. 32w+31] of the lane's node pair against the wave's own 32 glimpse values (re-read through a
+//                wave-private LDS row) -> the column-chunk partial of both nodes
+//   finish   : wavefront 0: partial sums, clip, mask, log-softmax, selection, env transition, next context query
 // The arithmetic follows the canonical order, so tours, log-probs and rewards are bit-identical
 // to k_rollout_stream, k_decode_step and the CPU oracle.
 //
@@ -49,14 +52,11 @@ struct ResLds {
     float q[RE];
     float headsw[RE];                           // 4 wave-private rows of 32 glimpse values
     float w[RH * WROW];
-    float partA[EAMRL_NCHUNK * RE];
-    float partZ[EAMRL_NCHUNK * RH];
     float cpart[RNP * 4];
     float dem[RNP];                             // CVRP: demand; SDVRP: remaining demand (demand_with_depot)
     float lp_out[TM];                           // selected log-probs of the episode, written out once
     int16_t act_out[TM];                        // selected actions of the episode
     float dynv[3 * SDF];                        // SDVRP: dynamic-embedding vectors wk | wv | lw
-    float partR[RH];                            // SDVRP: R_h = lane-tree sum of w * rem
     float xy[2 * XYF];                          // OP, CVRPTW: node coordinates
     float twv[3 * TWF];                         // CVRPTW: window start | window end | service time per node
     int done;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
     constexpr int WROW = L::WROW;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ve = tid & 127, vg = tid >> 7;   // glimpse layout: column, chunk pair
+    const int ve = 32 * wv + (lane & 31), vg = lane >> 5;   // glimpse layout: column (one of the wave's 32), chunk pair
     const int M = a.M;
     const int64_t bi = blockIdx.x % a.B;
     const int64_t ld = a.ld;
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
 
         // ---- S1: scores, per-head max and softmax weights of heads 2w, 2w+1 for both nodes (all inside the wave) ----
         // Branch-free and written so that the two heads' chains, butterflies and exponentials interleave.
+        float Rh[2] = {0.0f, 0.0f};         // SDVRP: R_h = lane tree of w * rem, wavefront-uniform
         {
             float s0[2] = {0.0f, 0.0f}, s1[2] = {0.0f, 0.0f}, qw[2] = {0.0f, 0.0f};
 #pragma unroll
@@ -279,22 +280,23 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                 const float w0 = f0 ? e2.x : 0.0f, w1 = f1 ? e2.y : 0.0f;
                 wrow[pos0] = w0;                                         // absent nodes write 0 into the row's spare slot
                 wrow[pos1] = w1;
-                if (SD) {       // R_h = lane tree of w * rem over the two 64-blocks (the second is all zeros when M <= 64)
-                    const float R = wave_tree_sum(w0 * l.dem[n0]) + wave_tree_sum(w1 * l.dem[n1]);
-                    if (lane == 0) l.partR[2 * wv + hh] = R;
-                }
+                if (SD)         // R_h = lane tree of w * rem over the two 64-blocks (the second is all zeros when M <= 64)
+                    Rh[hh] = wave_tree_sum(w0 * l.dem[n0]) + wave_tree_sum(w1 * l.dem[n1]);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();        // the rows are this wavefront's own: LDS executes its accesses in order
         STAMP(0);
 
-        // ---- S2: glimpse partials, column ve, chunks 2vg and 2vg+1 ----------------------------------------------------
+        // ---- S2: glimpse of the wave's 32 columns: lane (column ve, half vg) sums chunks 2vg and 2vg+1, the halves meet
+        //      through v_permlane32_swap, every lane ends with heads[ve] ------------------------------------------------
+        float head_e;
         {
-            const int h = ve >> 4;
+            const int h = ve >> 4;              // = 2 wv + ((lane & 31) >> 4)
+            float ag[2], zg[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const float* wp = l.w + h * WROW + (2 * vg + c) * CP;
-                float ag = 0.0f;
+                float acc = 0.0f;
                 // Z_g in the canonical order: four partial sums by position in the chunk (slot i mod 4: the components of the float4,
                 // four independent add chains), combined as (P0 + P1) + (P2 + P3)
                 // (as two packed adds per float4: the row's spare slots up to CP hold w = 0, so whole float4 can be added)
@@ -305,29 +307,31 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                     const float4 ww = *reinterpret_cast<const float4*>(wp + i);
                     z01 = z01 + (f32x2){ww.x, ww.y};
                     z23 = z23 + (f32x2){ww.z, ww.w};
-                    ag = fma_(ww.x, vreg[c][i], ag);
-                    if (i + 1 < CR) ag = fma_(ww.y, vreg[c][i + 1], ag);
-                    if (i + 2 < CR) ag = fma_(ww.z, vreg[c][i + 2], ag);
-                    if (i + 3 < CR) ag = fma_(ww.w, vreg[c][i + 3], ag);
+                    acc = fma_(ww.x, vreg[c][i], acc);
+                    if (i + 1 < CR) acc = fma_(ww.y, vreg[c][i + 1], acc);
+                    if (i + 2 < CR) acc = fma_(ww.z, vreg[c][i + 2], acc);
+                    if (i + 3 < CR) acc = fma_(ww.w, vreg[c][i + 3], acc);
                 }
-                l.partA[(2 * vg + c) * RE + ve] = ag;
-                if ((ve & 15) == 0) l.partZ[(2 * vg + c) * RH + h] = (z01.x + z01.y) + (z23.x + z23.y);
+                ag[c] = acc;
+                zg[c] = (z01.x + z01.y) + (z23.x + z23.y);
             }
+            // chunks 0, 1 live in lanes 0-31, chunks 2, 3 in lanes 32-63 of the same column: one swap per value leaves both in
+            // every lane ([0] = the low half's, [1] = the high half's); then the canonical ((A0 + A1) + A2) + A3 over the chunks
+            const auto a02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ag[0]), __float_as_uint(ag[0]), false, false);
+            const auto a13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ag[1]), __float_as_uint(ag[1]), false, false);
+            const auto z02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(zg[0]), __float_as_uint(zg[0]), false, false);
+            const auto z13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(zg[1]), __float_as_uint(zg[1]), false, false);
+            float A = ((__uint_as_float(a02[0]) + __uint_as_float(a13[0])) + __uint_as_float(a02[1])) + __uint_as_float(a13[1]);
+            const float Z = ((__uint_as_float(z02[0]) + __uint_as_float(z13[0])) + __uint_as_float(z02[1])) + __uint_as_float(z13[1]);
+            if (SD) A = fma_((lane & 16) ? Rh[1] : Rh[0], l.dynv[RE + ve], A);
+            head_e = A / Z;
         }
-        __syncthreads();
         STAMP(1);
 
-        // ---- S4: lanes 0-31 finish the 32 glimpse values of column chunk w; then the logit partials of both nodes ----
+        // ---- S4: the wave's 32 glimpse values, re-read as a wave-private LDS row; then the logit partials of both nodes ----
         {
             float* hw = l.headsw + wv * 32;
-            if (lane < 32) {
-                const int e = wv * 32 + lane, h = e >> 4;
-                float A = l.partA[e], Z = l.partZ[h];
-#pragma unroll
-                for (int g = 1; g < EAMRL_NCHUNK; ++g) { A = A + l.partA[g * RE + e]; Z = Z + l.partZ[g * RH + h]; }
-                if (SD) A = fma_(l.partR[h], l.dynv[RE + e], A);
-                hw[lane] = A / Z;
-            }
+            if (lane < 32) hw[lane] = head_e;
             __builtin_amdgcn_wave_barrier();        // same wavefront: LDS executes its accesses in order
             float c0 = 0.0f, c1 = 0.0f, hl = 0.0f;
 #pragma unroll

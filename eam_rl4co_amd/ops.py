@@ -4,6 +4,8 @@ every computation below happens in libeamrl_hip.so."""
 from __future__ import annotations
 
 import ctypes as C
+import logging
+import os
 
 import torch
 
@@ -259,14 +261,27 @@ def encoder_fused_supported(M, E, H, ff_hidden, nlayers) -> bool:
     return bool(_lib.load().eamrl_encoder_fused_supported(int(M), int(E), int(H), int(ff_hidden), int(nlayers)))
 
 
-def encoder_fused(h, layers, num_heads, ff_hidden, norm, eps, cache=None):
+def encoder_fused(h, layers, num_heads, ff_hidden, norm, eps, cache=None, init=None, store_hidden=True):
     """All encoder layers of every instance in one launch.  h [B, M, E]; layers: list of dicts with the 16 fields of
     struct eamrl_encoder_layer (packed weights, biases, norm parameters; running stats may be None for instance norm).
     cache = (Wc_packed, WoutT_packed, out [B, M, ld], nproj[, Wg [E, E], gctx [B, E]]): also fill the slot-major decoder
-    cache and, with the last two, the graph context (struct eamrl_encoder_cache)."""
+    cache and, with the last two, the graph context (struct eamrl_encoder_cache).
+    init (instead of h; struct eamrl_encoder_init) = dict(feat [B, M, F], W [E, F], b, depot [B, >= 2] or None, Wd, bd,
+    want_init): the init embedding is computed inside the kernel; returns (hidden or None, init embeddings or None) then.
+    store_hidden=False (with init and cache): the node embeddings never leave LDS."""
     lib = _lib.load()
-    _chk(h, "h", torch.float32)
-    B, M, E = h.shape
+    if init is not None:
+        feat = init["feat"]
+        _chk(feat, "node features", torch.float32)
+        B, M, F = feat.shape
+        W = init["W"]
+        E = W.shape[0]
+        _chk(W, "init_embed.weight", torch.float32, (E, F))
+        dev = feat.device
+    else:
+        _chk(h, "h", torch.float32)
+        B, M, E = h.shape
+        dev = h.device
     arr = (_lib.EncoderLayer * len(layers))()
     for i, d in enumerate(layers):
         for name, _ in _lib.EncoderLayer._fields_:
@@ -276,7 +291,7 @@ def encoder_fused(h, layers, num_heads, ff_hidden, norm, eps, cache=None):
                 if t.dtype != torch.float32 or not t.is_contiguous():
                     raise TypeError(f"encoder_fused: {name} must be contiguous fp32")
             setattr(arr[i], name, _ptr(t))
-    out = torch.empty_like(h)
+    out = torch.empty(B, M, E, dtype=torch.float32, device=dev) if (store_hidden or cache is None) else None
     cstruct = None
     if cache is not None:
         Wc, WoT, buf, nproj = cache[:4]
@@ -295,6 +310,24 @@ def encoder_fused(h, layers, num_heads, ff_hidden, norm, eps, cache=None):
                 raise ValueError("encoder_fused: Wg must be 16-byte aligned")
             cs.Wg, cs.gctx = _ptr(Wg), _ptr(gctx)
         cstruct = C.byref(cs)
+    if init is not None:
+        ist = _lib.EncoderInit()
+        b, depot, Wd, bd = init.get("b"), init.get("depot"), init.get("Wd"), init.get("bd")
+        for name, t in (("init_embed.bias", b), ("depot", depot), ("init_embed_depot.weight", Wd), ("init_embed_depot.bias", bd)):
+            if t is not None:
+                _need_gpu(t, name)
+                if t.dtype != torch.float32:
+                    raise TypeError(f"encoder_fused: {name} must be fp32")
+        if depot is not None and (depot.dim() != 2 or depot.stride(1) != 1 or depot.shape[0] != B or Wd is None or not Wd.is_contiguous()):
+            raise ValueError("encoder_fused: depot must be [B, >= 2] with unit inner stride, Wd [E, 2] contiguous")
+        init_out = torch.empty(B, M, E, dtype=torch.float32, device=dev) if init.get("want_init") else None
+        ist.feat, ist.F, ist.W, ist.b = _ptr(feat), int(F), _ptr(W), _ptr(b)
+        ist.depot, ist.depot_ld = _ptr(depot), (depot.stride(0) if depot is not None else 0)
+        ist.Wd, ist.bd, ist.init_out = _ptr(Wd), _ptr(bd), _ptr(init_out)
+        _lib.check(lib.eamrl_encoder_fused_init(C.byref(ist), _ptr(out), B, M, E, int(num_heads), int(ff_hidden), len(layers),
+                                                int(norm), float(eps), C.cast(arr, C.c_void_p), cstruct, _stream(feat)),
+                   "eamrl_encoder_fused_init")
+        return out, init_out
     _lib.check(lib.eamrl_encoder_fused(_ptr(h), _ptr(out), B, M, E, int(num_heads), int(ff_hidden), len(layers), int(norm),
                                        float(eps), C.cast(arr, C.c_void_p), cstruct, _stream(h)), "eamrl_encoder_fused")
     return out
@@ -944,11 +977,11 @@ class DecodeCache:
     (zoo/am/decoder.py:206-235); P_* and Lp are the weight folds described in DESIGN.md.
     """
 
-    def __init__(self, env_name, buf, cvec, gctx, embeddings, num_heads, dyn=None):
+    def __init__(self, env_name, buf, cvec, gctx, embeddings, num_heads, dyn=None, embed_dim=None):
         self.env_name, self.buf, self.cvec, self.gctx = env_name, buf, cvec, gctx
         self.dyn = dyn          # sdvrp: [3, E] dynamic-embedding vectors (key, value, folded logit key)
-        self.node_embeddings = embeddings
-        self.E = embeddings.shape[-1]
+        self.node_embeddings = embeddings      # None when the fused encoder kept them in LDS (nobody asked for them)
+        self.E = embeddings.shape[-1] if embeddings is not None else int(embed_dim)
         self.H = num_heads
         self.slots = slot_map(env_name)
         self.planes = buf.dim() == 4
@@ -1130,16 +1163,37 @@ def _rollout_outputs(R, t_max, dev):
     return actions, logps, flags
 
 
-HEADS_CAPTURE_MAX_BYTES = 48 << 30      # larger rollouts let the backward recompute the glimpse instead (5 - 11 GB at the POMO sizes)
+HEADS_CAPTURE_MAX_BYTES = int(os.environ.get("EAMRL_HEADS_CAPTURE_MAX_BYTES", 48 << 30))   # 5 - 11 GB at the POMO sizes
+_heads_skip_logged = False
 
 
 def _capture_heads(st, cache, cs, R, t_max, want_heads):
     """Training: a [R, t_max, E] buffer for the steps' glimpse outputs where the kernel chosen for this shape writes it
-    (eamrl_state.heads_out; st.heads afterwards, None otherwise)."""
+    (eamrl_state.heads_out; st.heads afterwards, None otherwise).  The backward allocates a second buffer of the same size
+    (dheads), so the capture is taken only while twice its size fits into half of the free device memory and under
+    EAMRL_HEADS_CAPTURE_MAX_BYTES; otherwise -- and if the allocation fails -- the backward recomputes the glimpse (logged
+    once: it is a slower path, not an error)."""
+    global _heads_skip_logged
     st.heads = st.heads_out = None
-    if (want_heads and R * int(t_max) * cache.E * 4 <= HEADS_CAPTURE_MAX_BYTES
-            and _lib.load().eamrl_rollout_rng_native(ENVS[st.env_name], C.byref(cs), R)):
-        st.heads = st.heads_out = torch.empty(R, int(t_max), cache.E, dtype=torch.float32, device=st.mask.device)
+    if not want_heads or not _lib.load().eamrl_rollout_rng_native(ENVS[st.env_name], C.byref(cs), R):
+        return
+    need = R * int(t_max) * cache.E * 4
+    free = torch.cuda.mem_get_info(st.mask.device)[0] + torch.cuda.memory_reserved(st.mask.device) - torch.cuda.memory_allocated(st.mask.device)
+    reason = None
+    if need > HEADS_CAPTURE_MAX_BYTES:
+        reason = f"{need / 2**30:.1f} GiB > EAMRL_HEADS_CAPTURE_MAX_BYTES"
+    elif 2 * need > free // 2:
+        reason = f"2 x {need / 2**30:.1f} GiB would take more than half of the {free / 2**30:.1f} GiB free"
+    else:
+        try:
+            st.heads = st.heads_out = torch.empty(R, int(t_max), cache.E, dtype=torch.float32, device=st.mask.device)
+        except torch.cuda.OutOfMemoryError:
+            reason = f"allocation of {need / 2**30:.1f} GiB failed"
+    if reason and not _heads_skip_logged:
+        _heads_skip_logged = True
+        logging.getLogger(__name__).warning(
+            "rollout: glimpse outputs of the decode steps are not kept for the backward (%s); the re-evaluation recomputes "
+            "them (logits backward 18 instead of 11 ms at 1024 x 100 x 100)", reason)
 
 
 def rollout(st: RolloutState, cache: DecodeCache, mode="greedy", noise=None, given=None, clip=10.0, temp=1.0,

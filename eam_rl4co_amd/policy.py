@@ -51,6 +51,23 @@ class TSPInitEmbedding(nn.Module):
     def forward(self, td):
         return ops.linear(td["locs"].contiguous(), self.init_embed.weight, self.init_embed.bias)
 
+    def fused_spec(self, td):
+        """struct eamrl_encoder_init: the fused encoder kernel computes this Linear itself (ops.encoder_fused(init=...))."""
+        return dict(feat=td["locs"].contiguous(), W=self.init_embed.weight.detach(),
+                    b=None if self.init_embed.bias is None else self.init_embed.bias.detach())
+
+
+def _depot_fused_spec(mod, locs, feat):
+    """struct eamrl_encoder_init of a depot env: customer features zero-padded to one row per node (row 0 unused), the depot
+    row from the coordinates (`_depot_and_customers` inside the fused kernel)."""
+    if feat.shape[-1] > 8 or mod.init_embed_depot.weight.shape[1] != 2:
+        return None
+    locs = locs.contiguous()
+    bias = lambda lin: None if lin.bias is None else lin.bias.detach()
+    return dict(feat=torch.nn.functional.pad(feat, (0, 0, 1, 0)).contiguous(), W=mod.init_embed.weight.detach().contiguous(),
+                b=bias(mod.init_embed), depot=locs[:, 0, :], Wd=mod.init_embed_depot.weight.detach().contiguous(),
+                bd=bias(mod.init_embed_depot))
+
 
 def _depot_and_customers(mod, locs, feat):
     """[B, M, E] init embeddings of a depot env: row 0 = init_embed_depot(depot), rows 1.. = init_embed(customer features).
@@ -79,6 +96,10 @@ class VRPInitEmbedding(nn.Module):
         feat = torch.cat((locs[:, 1:, :], td["demand"][..., None]), -1)   # [B, N, 3] input assembly (plumbing)
         return _depot_and_customers(self, locs, feat)
 
+    def fused_spec(self, td):
+        locs = td["locs"]
+        return _depot_fused_spec(self, locs, torch.cat((locs[:, 1:, :], td["demand"][..., None]), -1))
+
 
 class PCTSPInitEmbedding(nn.Module):
     """x, y, expected prize, penalty per customer; depot embedded separately (nn/env_embeddings/init.py:227-257)."""
@@ -92,6 +113,11 @@ class PCTSPInitEmbedding(nn.Module):
         locs = td["locs"]
         feat = torch.cat((locs[:, 1:, :], td["expected_prize"][..., None], td["penalty"][..., 1:, None]), -1)
         return _depot_and_customers(self, locs, feat)
+
+    def fused_spec(self, td):
+        locs = td["locs"]
+        return _depot_fused_spec(self, locs, torch.cat((locs[:, 1:, :], td["expected_prize"][..., None],
+                                                        td["penalty"][..., 1:, None]), -1))
 
 
 class VRPTWInitEmbedding(nn.Module):
@@ -110,6 +136,12 @@ class VRPTWInitEmbedding(nn.Module):
         cust = ops.linear(feat, self.init_embed.weight, self.init_embed.bias)
         return torch.cat((depot, cust), 1)
 
+    def fused_spec(self, td):
+        locs = td["locs"]
+        return _depot_fused_spec(self, locs, torch.cat((locs[:, 1:, :], td["demand"][..., None],
+                                                        td["time_windows"][..., 1:, :].to(torch.float32),
+                                                        td["durations"][..., 1:, None]), -1))
+
 
 class OPInitEmbedding(nn.Module):
     """x, y, prize per customer; depot embedded separately (nn/env_embeddings/init.py:260-286)."""
@@ -123,6 +155,10 @@ class OPInitEmbedding(nn.Module):
         locs = td["locs"]
         feat = torch.cat((locs[:, 1:, :], td["prize"][..., 1:, None]), -1)
         return _depot_and_customers(self, locs, feat)
+
+    def fused_spec(self, td):
+        locs = td["locs"]
+        return _depot_fused_spec(self, locs, torch.cat((locs[:, 1:, :], td["prize"][..., 1:, None]), -1))
 
 
 class _Holder(nn.Module):
@@ -212,18 +248,23 @@ class GraphAttentionNetwork(nn.Module):
         self.layers = nn.Sequential(*(MultiHeadAttentionLayer(embed_dim, num_heads, feedforward_hidden, normalization)
                                       for _ in range(num_layers)))
 
-    def forward(self, x, mask=None, cache_spec=None):
+    def forward(self, x, mask=None, cache_spec=None, init=None, store_hidden=True, fused=None):
         """cache_spec (optional, from AttentionModelDecoder._fused_cache_spec): the fused kernel also fills the decoder cache
-        from the embeddings it still holds in LDS and sets cache_spec["filled"]."""
+        from the embeddings it still holds in LDS and sets cache_spec["filled"].  init (instead of x; an init embedding's
+        `fused_spec`, only with `fused` = this network's `_fused_layers`): the kernel computes the init embedding too and the
+        call returns (embeddings or None when store_hidden is False, init embeddings or None)."""
         assert mask is None, "Mask not yet supported!"
-        fused = self._fused_layers(x)
+        if fused is None:
+            assert init is None, "init= needs the fused kernel (check _fused_layers first)"
+            fused = self._fused_layers(x)
         if fused is not None:       # all layers of an instance in one workgroup, activations resident in LDS
             layers, H, ff, norm, eps = fused
             cache = None
             if cache_spec is not None:
                 cache = (cache_spec["Wc"], cache_spec["WoT"], cache_spec["buf"], cache_spec["nproj"], cache_spec.get("Wg"),
                          cache_spec.get("gctx"))
-            out = ops.encoder_fused(x.contiguous(), layers, H, ff, norm, eps, cache=cache)
+            out = ops.encoder_fused(None if init is not None else x.contiguous(), layers, H, ff, norm, eps, cache=cache,
+                                    init=init, store_hidden=store_hidden)
             if cache_spec is not None:
                 cache_spec["filled"] = True
             return out
@@ -231,7 +272,7 @@ class GraphAttentionNetwork(nn.Module):
             x = layer(x)
         return x
 
-    def _fused_layers(self, x):
+    def _fused_layers(self, x, shape=None):
         """Arguments of `ops.encoder_fused` when the fused kernel covers this network (eval-mode batch norm or instance
         norm, E = 128, 8 heads, one hidden layer of 512, graphs up to 112 nodes), else None.  The packed weights live in
         persistent buffers refreshed in place when a parameter changes (a captured HIP graph keeps reading them)."""
@@ -242,7 +283,11 @@ class GraphAttentionNetwork(nn.Module):
         if len(ffn0.lins) != 2:
             return None
         E, H, ff = mha0.embed_dim, mha0.num_heads, ffn0.lins[0].out_features
-        if x.dim() != 3 or x.shape[-1] != E or not ops.encoder_fused_supported(x.shape[1], E, H, ff, len(self.layers)):
+        if shape is None:       # shape = (M, E) of the embeddings when they are not materialised (fused init embedding)
+            if x.dim() != 3:
+                return None
+            shape = (x.shape[1], x.shape[-1])
+        if shape[1] != E or not ops.encoder_fused_supported(shape[0], E, H, ff, len(self.layers)):
             return None
         n0 = first[1].normalizer
         if isinstance(n0, nn.BatchNorm1d):
@@ -293,7 +338,19 @@ class AttentionModelEncoder(nn.Module):
         self.net = GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden) \
             if net is None else net
 
-    def forward(self, td, mask=None, cache_spec=None):
+    def forward(self, td, mask=None, cache_spec=None, want_hidden=True, want_init=True):
+        """-> (embeddings, init embeddings).  With a `cache_spec` the whole encoder can be ONE launch that starts from the
+        node features (`init_embedding.fused_spec`) and ends in the decoder cache; want_hidden / want_init = False then
+        return None for tensors the caller does not need (they never leave the workgroup's LDS)."""
+        spec_fn = getattr(self.init_embedding, "fused_spec", None)
+        if (cache_spec is not None and spec_fn is not None and mask is None and isinstance(self.net, GraphAttentionNetwork)
+                and os.environ.get("EAMRL_FUSED_INIT", "1") != "0"):
+            M, E = td["locs"].shape[1], self.net.layers[0][0].module.embed_dim if len(self.net.layers) else 0
+            fused = self.net._fused_layers(None, (M, E)) if E else None
+            init = spec_fn(td) if fused is not None else None
+            if init is not None:
+                init["want_init"] = want_init
+                return self.net(None, None, cache_spec=cache_spec, init=init, store_hidden=want_hidden, fused=fused)
         init_h = self.init_embedding(td)
         h = self.net(init_h, mask, cache_spec=cache_spec) if cache_spec is not None else self.net(init_h, mask)
         return h, init_h
@@ -391,11 +448,15 @@ class AttentionModelDecoder(nn.Module):
         """K | V | L (+ folded context / logit projections) in one slot-major buffer (ops.DecodeCache).  prefilled: a
         `_fused_cache_spec` whose buffer the fused encoder kernel has already filled (only the graph context is left)."""
         E = self.embed_dim
-        emb = embeddings.contiguous()
-        B, M, _ = emb.shape
         slots = ops.slot_map(self.env_name)
         Wa, Wb, cvec = self._weight_constants()
         Wkvl = self.project_node_embeddings.weight
+        if embeddings is None:      # the fused encoder kept them in LDS: everything derived from them is already in `prefilled`
+            assert prefilled is not None and prefilled.get("filled") and (not self.use_graph_context or prefilled.get("gctx") is not None)
+            emb = None
+        else:
+            emb = embeddings.contiguous()
+            B, M, _ = emb.shape
         if prefilled is not None and prefilled.get("filled"):
             buf = prefilled["buf"]
         elif M > 128 and os.environ.get("EAMRL_CACHE_PLANES", "1") != "0":     # streaming-kernel territory: one dense
@@ -427,7 +488,7 @@ class AttentionModelDecoder(nn.Module):
             w = self.dynamic_embedding.projection.weight.detach().reshape(3, E)
             lw = ops.matmul_right(w[2:3].contiguous(), self.pointer.project_out.weight.contiguous())
             dyn = torch.cat((w[0:2], lw), 0).contiguous()
-        return ops.DecodeCache(self.env_name, buf, cvec.contiguous(), gctx, emb, self.num_heads, dyn=dyn)
+        return ops.DecodeCache(self.env_name, buf, cvec.contiguous(), gctx, emb, self.num_heads, dyn=dyn, embed_dim=E)
 
     def _weight_constants(self):
         """Tensors that depend on the weights only, recomputed when a parameter changes (optimizer step, load):
@@ -821,7 +882,13 @@ class AttentionModelPolicy(nn.Module):
             if init_embeds is None and return_init_embeds:
                 init_embeds = self.encoder.init_embedding(td)
         else:
-            hidden, init_embeds = self.encoder(td, cache_spec=spec) if spec is not None else self.encoder(td)
+            if spec is not None and isinstance(self.encoder, AttentionModelEncoder):
+                # the embeddings leave the kernel only when someone will read them (return_hidden, a second call sharing them)
+                need_emb = (return_hidden or ekey is not None
+                            or (self.decoder.use_graph_context and spec.get("gctx") is None))
+                hidden, init_embeds = self.encoder(td, cache_spec=spec, want_hidden=need_emb, want_init=return_init_embeds)
+            else:
+                hidden, init_embeds = self.encoder(td, cache_spec=spec) if spec is not None else self.encoder(td)
             if ekey is not None and spec.get("filled"):
                 shared["native"] = (ekey, hidden, init_embeds, spec)
         cache = self.decoder._precompute_cache(hidden, num_starts=S, prefilled=spec)
@@ -859,6 +926,10 @@ class AttentionModelPolicy(nn.Module):
                     seed_dev = torch.empty(1, dtype=torch.int64, device=st.mask.device).random_()
                 else:
                     seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                    # data-parallel replicas are usually seeded alike (and the noise is a pure function of (seed, row, step,
+                    # node)): mix the rank in so that the ranks explore with independent noise fields
+                    if torch.distributed.is_available() and torch.distributed.is_initialized():
+                        seed ^= (torch.distributed.get_rank() * 0x9E3779B97F4A7C15) & (2 ** 62 - 1)
             elif noise is None:
                 noise = torch.empty(st.R, t_max, M, dtype=torch.float32, device=st.mask.device).exponential_(1)
             else:

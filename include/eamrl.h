@@ -231,6 +231,24 @@ typedef struct eamrl_encoder_cache {
     float* gctx;
 } eamrl_encoder_cache;
 
+/* Optional head of eamrl_encoder_fused_init: the init embedding  [nn/env_embeddings/init.py:55-68 (TSP), 115-138 (VRP),
+ * 141-157 (VRPTW), 227-286 (PCTSP, OP); zoo/am/encoder.py:86-87] computed straight into the workgroup's LDS instead of being
+ * written to and read back from HBM.  Row n of instance b is Linear(F -> E) of feat[b][n][0..F-1] (W [E][F] row-major, b [E] or
+ * NULL), each output the k-ordered fma chain of eamrl_linear; with depot != NULL row 0 is instead Linear(2 -> E) of the depot
+ * coordinates depot[b * depot_ld + 0..1] (Wd [E][2], bd) and feat's row 0 is not read.  init_out (may be NULL): [B][M][E],
+ * also receives the init embeddings (return_init_embeds). */
+typedef struct eamrl_encoder_init {
+    const float* feat;      /* [B][M][F] */
+    int F;                  /* 1 .. 8 */
+    const float* W;         /* [E][F] init_embed.weight */
+    const float* b;         /* [E] init_embed.bias or NULL */
+    const float* depot;     /* NULL (TSP) or the depot coordinates, instance stride depot_ld floats */
+    int64_t depot_ld;
+    const float* Wd;        /* [E][2] init_embed_depot.weight */
+    const float* bd;        /* [E] or NULL */
+    float* init_out;        /* NULL or [B][M][E] */
+} eamrl_encoder_init;
+
 /* Wp = W [out_dim][in_dim] (torch.nn.Linear.weight) re-ordered for the fused encoder: block (ct, u) of 256 floats holds,
  * for lane l = 16 g + j of a wavefront, the float4 { W[16 ct + j][16 u + 4 q + g] : q = 0..3 } -- the B operand of four
  * consecutive v_mfma_f32_16x16x4_f32 k-steps.  out_dim, in_dim multiples of 16.  Redo after every weight update. */
@@ -247,6 +265,14 @@ int eamrl_encoder_fused_supported(int M, int E, int H, int ff_hidden, int nlayer
 int eamrl_encoder_fused(const float* h_in, float* h_out, int64_t B, int M, int E, int H, int ff_hidden, int nlayers, int norm,
                         float eps, const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache /* may be NULL */,
                         void* stream);
+
+/* AttentionModelEncoder.forward in one launch  [zoo/am/encoder.py:70-91]: init embedding (eamrl_encoder_init) -> all layers ->
+ * (optionally) the decoder cache.  h_out may be NULL when only the cache is wanted (the node embeddings then never leave
+ * LDS: 2 x B*M*E*4 bytes of HBM traffic and the init-embedding launch less than eamrl_linear + eamrl_encoder_fused).
+ * Same values as those two calls. */
+int eamrl_encoder_fused_init(const eamrl_encoder_init* init, float* h_out /* may be NULL */, int64_t B, int M, int E, int H,
+                             int ff_hidden, int nlayers, int norm, float eps, const eamrl_encoder_layer* layers,
+                             const eamrl_encoder_cache* cache /* may be NULL */, void* stream);
 
 /* out[b][e] = (sum_n emb[b][n][e]) / M   (embeddings.mean(1), zoo/am/decoder.py:225-227) */
 int eamrl_mean_nodes(const float* emb, float* out, int64_t B, int M, int E, void* stream);

@@ -105,3 +105,47 @@ def test_fused_cache_is_bit_identical(monkeypatch, cfg, env_name, N, B):
     out_u = pol(td.clone(), env, phase="test", decode_type="greedy")
     assert_bits_equal(out_f["actions"], out_u["actions"], "actions")
     assert_bits_equal(out_f["log_likelihood"], out_u["log_likelihood"], "ll")
+
+
+@pytest.mark.parametrize("cfg,env_name,N,B", [("am_tsp", "tsp", 20, 5), ("am_tsp", "tsp", 100, 6), ("am_tsp", "tsp", 112, 2),
+                                              ("am_cvrp", "cvrp", 20, 4), ("am_cvrp", "cvrp", 100, 3), ("pomo_tsp", "tsp", 50, 3),
+                                              ("am_sdvrp", "sdvrp", 33, 2), ("am_pctsp", "pctsp", 30, 3), ("am_op", "op", 64, 2),
+                                              ("am_cvrptw", "cvrptw", 20, 3)])
+def test_fused_init_embedding_and_skipped_hidden_store(monkeypatch, cfg, env_name, N, B):
+    """eamrl_encoder_fused_init: the init embedding computed inside the fused kernel (features -> LDS) gives the same init
+    embeddings, node embeddings, decoder cache and graph context, bit for bit, as the init-embedding launch + the fused kernel
+    on its output; and a rollout whose embeddings never leave LDS (want_hidden=False) the same tours and log-likelihoods."""
+    import eam_rl4co_amd as ea
+
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=N + 3)
+    torch.manual_seed(N * 11 + B)
+    td = env.reset(batch_size=[B]).to(DEV)
+    pol = make_policy(cfg)
+    M = td["locs"].shape[1]
+    with torch.no_grad():
+        spec_a = pol.decoder._fused_cache_spec(B, M, DEV)
+        h_a, init_a = pol.encoder(td, cache_spec=spec_a)                               # fused init, everything stored
+        spec_n = pol.decoder._fused_cache_spec(B, M, DEV)
+        h_n, init_n = pol.encoder(td, cache_spec=spec_n, want_hidden=False, want_init=False)
+        monkeypatch.setenv("EAMRL_FUSED_INIT", "0")
+        spec_b = pol.decoder._fused_cache_spec(B, M, DEV)
+        h_b, init_b = pol.encoder(td, cache_spec=spec_b)                               # init-embedding launch + fused kernel
+    assert spec_a["filled"] and spec_b["filled"] and spec_n["filled"]
+    assert h_n is None and init_n is None
+    assert_bits_equal(init_a, init_b, "init embeddings")
+    assert_bits_equal(h_a, h_b, "embeddings")
+    assert_bits_equal(spec_a["buf"], spec_b["buf"], "decoder cache")
+    assert_bits_equal(spec_n["buf"], spec_b["buf"], "decoder cache (embeddings kept in LDS)")
+    if spec_b.get("gctx") is not None:
+        assert_bits_equal(spec_a["gctx"], spec_b["gctx"], "graph context")
+        assert_bits_equal(spec_n["gctx"], spec_b["gctx"], "graph context (embeddings kept in LDS)")
+    out_old = pol(td.clone(), env, phase="test", decode_type="greedy", return_hidden=True, return_init_embeds=True)
+    monkeypatch.delenv("EAMRL_FUSED_INIT")
+    out_new = pol(td.clone(), env, phase="test", decode_type="greedy")                 # default: nothing but the cache leaves
+    out_hid = pol(td.clone(), env, phase="test", decode_type="greedy", return_hidden=True, return_init_embeds=True)
+    for o in (out_new, out_hid):
+        assert_bits_equal(o["actions"], out_old["actions"], "actions")
+        assert_bits_equal(o["log_likelihood"], out_old["log_likelihood"], "ll")
+        assert_bits_equal(o["reward"], out_old["reward"], "reward")
+    assert_bits_equal(out_hid["init_embeds"], out_old["init_embeds"], "returned init embeddings")
+    assert_bits_equal(out_hid["hidden"].node_embeddings, out_old["hidden"].node_embeddings, "returned embeddings")
