@@ -322,7 +322,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
 
     SSTAMP(3);      // D5 (logit keys)
     // ---- D6 combine, /sqrt(E), tanh clip, mask, /temperature ------------------------------------------------------
-    const float sqrtE = __builtin_sqrtf((float)E);
+    const float inv_sqrtE = 1.0f / __builtin_sqrtf((float)E);      // one rounded constant (canonical: logit = u * inv_sqrtE)
     float tmax = -INFINITY;
     bool nan_seen = false;
     for (int n = tid; n < M; n += BLOCK) {
@@ -330,7 +330,7 @@ __device__ void decode_row(const DecArgs& a, const RowLds& l, int64_t r, const R
         float u = pl[0];
 #pragma unroll
         for (int c = 1; c < EAMRL_NCHUNK; ++c) u = u + pl[c];
-        float logit = u / sqrtE;
+        float logit = u * inv_sqrtE;
         const bool feas = l.msk[n] != 0;
         if (feas && logit != logit) nan_seen = true;
         if (logits_row) logits_row[n] = feas ? logit : -INFINITY;

@@ -196,6 +196,21 @@ __device__ __forceinline__ float d_logf(float x)
     return fma_(0.693359375f, fe, r);
 }
 
+// 1 / x for a normal positive x: three Newton iterations r <- r + r (1 - x r) from the integer seed 0x7EF311C7 - bits(x) (5 %
+// off).  Integer subtraction and fma only, so every host evaluates the same bits; 6e-8 relative (0.5 ulp).  Stands where an
+// IEEE division would sit on a serial path: v_div_scale / v_rcp / v_div_fmas / v_div_fixup are ~11 dependent, unpackable
+// instructions around VCC, this is 1 + 6 (round 3: the decode loop's finishing wavefront had four divisions per step).
+__device__ __forceinline__ float d_rcpf(float x)
+{
+    float r = __uint_as_float(0x7EF311C7u - __float_as_uint(x));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float t = fma_(-x, r, 1.0f);
+        r = fma_(r, t, r);
+    }
+    return r;
+}
+
 // tanh: small-|x| polynomial and exp-based branch both evaluated, result selected (no exec-mask branches)
 __device__ __forceinline__ float d_tanhf(float x)
 {
@@ -209,7 +224,7 @@ __device__ __forceinline__ float d_tanhf(float x)
     const float t_small = fma_(p * z, a, a);
     const float ac = a > 9.0f ? 9.0f : a;           // keeps exp finite; |x| > 9 is forced to 1 below
     const float e = d_expf(ac + ac);
-    const float t_big = 1.0f - 2.0f / (e + 1.0f);
+    const float t_big = fma_(-2.0f, d_rcpf(e + 1.0f), 1.0f);            // 1 - 2 / (e^2a + 1)
     const float t = (a < 0.625f) ? t_small : ((a > 9.0f) ? 1.0f : t_big);
     return __builtin_copysignf(t, x);
 }
@@ -231,7 +246,16 @@ __device__ __forceinline__ f32x2 d_tanhf2(f32x2 x)
     ac.x = a.x > 9.0f ? 9.0f : a.x;
     ac.y = a.y > 9.0f ? 9.0f : a.y;
     const f32x2 e = d_expf2(ac + ac);
-    const f32x2 t_big = splat2(1.0f) - splat2(2.0f) / (e + splat2(1.0f));
+    const f32x2 x1 = e + splat2(1.0f);
+    f32x2 r;                                                            // d_rcpf on both halves
+    r.x = __uint_as_float(0x7EF311C7u - __float_as_uint(x1.x));
+    r.y = __uint_as_float(0x7EF311C7u - __float_as_uint(x1.y));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const f32x2 t = pk_fma(-x1, r, splat2(1.0f));
+        r = pk_fma(r, t, r);
+    }
+    const f32x2 t_big = pk_fma(splat2(-2.0f), r, splat2(1.0f));
     f32x2 t;
     t.x = (a.x < 0.625f) ? t_small.x : ((a.x > 9.0f) ? 1.0f : t_big.x);
     t.y = (a.y < 0.625f) ? t_small.y : ((a.y > 9.0f) ? 1.0f : t_big.y);

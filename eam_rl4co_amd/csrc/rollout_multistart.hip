@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
     const int part = (int)(blockIdx.x - b * nsplit);
     const int64_t ld = a.ld;
     const int C = CC > 0 ? CC : (M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
-    const float sqrtE = __builtin_sqrtf((float)ME);
+    const float inv_sqrtE = 1.0f / __builtin_sqrtf((float)ME);     // one rounded constant (canonical: logit = u * inv_sqrtE)
     const uint64_t seed = a.seed ^ ((a.use_rng && a.seed_dev) ? *a.seed_dev : 0ull);
     const int b1 = C, b2 = 2 * C, b3 = 3 * C;      // node chunk boundaries
     uint64_t cgbits = 0;                            // chunk id (2 bits) of this lane's node 4 t + G, t = 0 .. 4 RTT - 1
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 f32x2 v01, v23;
                 {
                     const f32x4 u = ((c[0] + c[1]) + c[2]) + c[3];
-                    const f32x2 l01 = (f32x2){u[0], u[1]} / splat2(sqrtE), l23 = (f32x2){u[2], u[3]} / splat2(sqrtE);
+                    const f32x2 l01 = (f32x2){u[0], u[1]} * splat2(inv_sqrtE), l23 = (f32x2){u[2], u[3]} * splat2(inv_sqrtE);
                     const uint32_t w = (nbase >> 5) == 0 ? mb.x : (nbase >> 5) == 1 ? mb.y : (nbase >> 5) == 2 ? mb.z : mb.w;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) fe[r] = (w >> ((nbase & 31) + r)) & 1u;

@@ -101,7 +101,9 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
     const bool in0 = n0 < M, in1 = n1 < M;
 
     // ---- one-time loads: K, Lp column slices of both nodes, V columns (chunked), context rows -> LDS ------------
-    float kreg[2][32], lreg[2][32], vreg[2][CR];
+    // operands as PAIRS (v_pk_fma_f32: two chains per instruction): k2[i] / l2[i] = (node n0, node n1) of column 32w + i,
+    // v2[i] = (chunk 2vg, chunk 2vg + 1) at chunk slot i
+    f32x2 k2[32], l2[32], v2[CR];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int nn = k ? n1 : n0;
@@ -112,8 +114,8 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         for (int i = 0; i < 32; i += 4) {
             const float4 kk = valid ? *reinterpret_cast<const float4*>(kp + i) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 ll = valid ? *reinterpret_cast<const float4*>(lp + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-            kreg[k][i] = kk.x; kreg[k][i + 1] = kk.y; kreg[k][i + 2] = kk.z; kreg[k][i + 3] = kk.w;
-            lreg[k][i] = ll.x; lreg[k][i + 1] = ll.y; lreg[k][i + 2] = ll.z; lreg[k][i + 3] = ll.w;
+            k2[i][k] = kk.x; k2[i + 1][k] = kk.y; k2[i + 2][k] = kk.z; k2[i + 3][k] = kk.w;
+            l2[i][k] = ll.x; l2[i + 1][k] = ll.y; l2[i + 2][k] = ll.z; l2[i + 3][k] = ll.w;
         }
     }
     {
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
 #pragma unroll
             for (int i = 0; i < CR; ++i) {
                 const int nn = nb + i;
-                vreg[c][i] = (i < C && nn < M) ? vp[(int64_t)nn * ld] : 0.0f;
+                v2[i][c] = (i < C && nn < M) ? vp[(int64_t)nn * ld] : 0.0f;
             }
         }
         const float* Pc = (ENV == EAMRL_ENV_TSP ? a.Pb : a.Pa) + bi * M * ld;
@@ -151,10 +153,12 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         if (SD)
             for (int i = tid; i < 3 * RE; i += RB) l.dynv[i] = a.dyn[i];
     }
-    // slots of the two nodes in a w row; absent nodes (n >= M) point at the row's never-read spare slot 4*CP
-    const int pos0 = in0 ? (n0 / C) * CP + (n0 - (n0 / C) * C) : 4 * CP;
-    const int pos1 = in1 ? (n1 / C) * CP + (n1 - (n1 / C) * C) : 4 * CP;
-    const float sqrtE = __builtin_sqrtf((float)RE);
+    // slots of the two nodes in a w row: chunk c, slot i -> ((c >> 1) * CP + i) * 2 + (c & 1), i.e. the two chunks a glimpse
+    // lane sums side by side (one float4 = slots i, i + 1 of both); absent nodes (n >= M) point at the row's never-read spare slot
+    const int ch0 = n0 / C, ch1 = n1 / C;
+    const int pos0 = in0 ? ((ch0 >> 1) * CP + (n0 - ch0 * C)) * 2 + (ch0 & 1) : 4 * CP;
+    const int pos1 = in1 ? ((ch1 >> 1) * CP + (n1 - ch1 * C)) * 2 + (ch1 & 1) : 4 * CP;
+    const float inv_sqrtE = 1.0f / __builtin_sqrtf((float)RE);     // one rounded constant (canonical: logit = u * inv_sqrtE)
 
     for (int s = MS ? (int)(blockIdx.x / a.B) : 0; s < (MS ? S : 1); s += (MS ? G : 1)) {
     const int64_t r = MS ? (int64_t)s * a.B + bi : (int64_t)blockIdx.x;
@@ -242,7 +246,8 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         // Branch-free and written so that the two heads' chains, butterflies and exponentials interleave.
         float Rh[2] = {0.0f, 0.0f};         // SDVRP: R_h = lane tree of w * rem, wavefront-uniform
         {
-            float s0[2] = {0.0f, 0.0f}, s1[2] = {0.0f, 0.0f}, qw[2] = {0.0f, 0.0f};
+            f32x2 s2[2] = {splat2(0.0f), splat2(0.0f)};     // (node n0, node n1) per head
+            float qw[2] = {0.0f, 0.0f};
 #pragma unroll
             for (int d = 0; d < RD; d += 4) {
 #pragma unroll
@@ -253,22 +258,21 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                         qw[hh] = fma_(qq.x, dk.x, qw[hh]); qw[hh] = fma_(qq.y, dk.y, qw[hh]);
                         qw[hh] = fma_(qq.z, dk.z, qw[hh]); qw[hh] = fma_(qq.w, dk.w, qw[hh]);
                     }
-                    s0[hh] = fma_(qq.x, kreg[0][hh * RD + d], s0[hh]);     s1[hh] = fma_(qq.x, kreg[1][hh * RD + d], s1[hh]);
-                    s0[hh] = fma_(qq.y, kreg[0][hh * RD + d + 1], s0[hh]); s1[hh] = fma_(qq.y, kreg[1][hh * RD + d + 1], s1[hh]);
-                    s0[hh] = fma_(qq.z, kreg[0][hh * RD + d + 2], s0[hh]); s1[hh] = fma_(qq.z, kreg[1][hh * RD + d + 2], s1[hh]);
-                    s0[hh] = fma_(qq.w, kreg[0][hh * RD + d + 3], s0[hh]); s1[hh] = fma_(qq.w, kreg[1][hh * RD + d + 3], s1[hh]);
+                    s2[hh] = pk_fma(splat2(qq.x), k2[hh * RD + d], s2[hh]);
+                    s2[hh] = pk_fma(splat2(qq.y), k2[hh * RD + d + 1], s2[hh]);
+                    s2[hh] = pk_fma(splat2(qq.z), k2[hh * RD + d + 2], s2[hh]);
+                    s2[hh] = pk_fma(splat2(qq.w), k2[hh * RD + d + 3], s2[hh]);
                 }
             }
             f32x2 sc[2];
             float m[2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                if (SD) {       // remaining demand of the lane's nodes (slots >= M hold 0); re-read where needed: no live range
-                    s0[hh] = fma_(l.dem[n0], qw[hh], s0[hh]);
-                    s1[hh] = fma_(l.dem[n1], qw[hh], s1[hh]);
-                }
-                sc[hh].x = f0 ? s0[hh] * 0.25f : -INFINITY;              // 1/sqrt(16)
-                sc[hh].y = f1 ? s1[hh] * 0.25f : -INFINITY;
+                if (SD)         // remaining demand of the lane's nodes (slots >= M hold 0); re-read where needed: no live range
+                    s2[hh] = pk_fma((f32x2){l.dem[n0], l.dem[n1]}, splat2(qw[hh]), s2[hh]);
+                const f32x2 sq = s2[hh] * splat2(0.25f);                 // 1/sqrt(16)
+                sc[hh].x = f0 ? sq.x : -INFINITY;
+                sc[hh].y = f1 ? sq.y : -INFINITY;
                 m[hh] = vmax_raw(sc[hh].x, sc[hh].y);
             }
             m[0] = wave_max(m[0]);
@@ -292,29 +296,25 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         float head_e;
         {
             const int h = ve >> 4;              // = 2 wv + ((lane & 31) >> 4)
-            float ag[2], zg[2];
+            // both chunks of the lane at once: one float4 of the (pair-interleaved) weight row = slots i, i + 1 of chunk 2vg (.x, .z)
+            // and chunk 2vg + 1 (.y, .w).  Z_g in the canonical order: four partial sums by slot class (i mod 4), combined as
+            // (P0 + P1) + (P2 + P3); padded slots hold w = 0, so whole float4 can be added.
+            static_assert(CR <= CP && CP % 2 == 0, "a chunk's CR slots must lie inside its padded row");
+            const float* wp = l.w + h * WROW + vg * (2 * CP);
+            f32x2 acc2 = splat2(0.0f), zc[4] = {splat2(0.0f), splat2(0.0f), splat2(0.0f), splat2(0.0f)};
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const float* wp = l.w + h * WROW + (2 * vg + c) * CP;
-                float acc = 0.0f;
-                // Z_g in the canonical order: four partial sums by position in the chunk (slot i mod 4: the components of the float4,
-                // four independent add chains), combined as (P0 + P1) + (P2 + P3)
-                // (as two packed adds per float4: the row's spare slots up to CP hold w = 0, so whole float4 can be added)
-                static_assert(((CR + 3) & ~3) <= CP, "the last float4 of a chunk row must lie inside its padded row");
-                f32x2 z01 = splat2(0.0f), z23 = splat2(0.0f);
-#pragma unroll
-                for (int i = 0; i < CR; i += 4) {          // slots >= C hold w = 0 (and are skipped beyond CR)
-                    const float4 ww = *reinterpret_cast<const float4*>(wp + i);
-                    z01 = z01 + (f32x2){ww.x, ww.y};
-                    z23 = z23 + (f32x2){ww.z, ww.w};
-                    acc = fma_(ww.x, vreg[c][i], acc);
-                    if (i + 1 < CR) acc = fma_(ww.y, vreg[c][i + 1], acc);
-                    if (i + 2 < CR) acc = fma_(ww.z, vreg[c][i + 2], acc);
-                    if (i + 3 < CR) acc = fma_(ww.w, vreg[c][i + 3], acc);
+            for (int i = 0; i < CR; i += 2) {          // slots >= C hold w = 0 (and are skipped beyond CR)
+                const float4 ww = *reinterpret_cast<const float4*>(wp + 2 * i);
+                const f32x2 wa = (f32x2){ww.x, ww.y}, wb = (f32x2){ww.z, ww.w};
+                zc[i & 3] = zc[i & 3] + wa;
+                acc2 = pk_fma(wa, v2[i], acc2);
+                if (i + 1 < CR) {
+                    zc[(i + 1) & 3] = zc[(i + 1) & 3] + wb;
+                    acc2 = pk_fma(wb, v2[i + 1], acc2);
                 }
-                ag[c] = acc;
-                zg[c] = (z01.x + z01.y) + (z23.x + z23.y);
             }
+            const f32x2 zz = (zc[0] + zc[1]) + (zc[2] + zc[3]);
+            const float ag[2] = {acc2.x, acc2.y}, zg[2] = {zz.x, zz.y};
             // chunks 0, 1 live in lanes 0-31, chunks 2, 3 in lanes 32-63 of the same column: one swap per value leaves both in
             // every lane ([0] = the low half's, [1] = the high half's); then the canonical ((A0 + A1) + A2) + A3 over the chunks
             const auto a02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ag[0]), __float_as_uint(ag[0]), false, false);
@@ -333,7 +333,8 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             float* hw = l.headsw + wv * 32;
             if (lane < 32) hw[lane] = head_e;
             __builtin_amdgcn_wave_barrier();        // same wavefront: LDS executes its accesses in order
-            float c0 = 0.0f, c1 = 0.0f, hl = 0.0f;
+            f32x2 c2 = splat2(0.0f);            // (node n0, node n1)
+            float hl = 0.0f;
 #pragma unroll
             for (int e = 0; e < 32; e += 4) {
                 const float4 h4 = *reinterpret_cast<const float4*>(hw + e);
@@ -342,14 +343,13 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                     hl = fma_(h4.x, dl.x, hl); hl = fma_(h4.y, dl.y, hl);
                     hl = fma_(h4.z, dl.z, hl); hl = fma_(h4.w, dl.w, hl);
                 }
-                c0 = fma_(h4.x, lreg[0][e], c0);     c1 = fma_(h4.x, lreg[1][e], c1);
-                c0 = fma_(h4.y, lreg[0][e + 1], c0); c1 = fma_(h4.y, lreg[1][e + 1], c1);
-                c0 = fma_(h4.z, lreg[0][e + 2], c0); c1 = fma_(h4.z, lreg[1][e + 2], c1);
-                c0 = fma_(h4.w, lreg[0][e + 3], c0); c1 = fma_(h4.w, lreg[1][e + 3], c1);
+                c2 = pk_fma(splat2(h4.x), l2[e], c2);
+                c2 = pk_fma(splat2(h4.y), l2[e + 1], c2);
+                c2 = pk_fma(splat2(h4.z), l2[e + 2], c2);
+                c2 = pk_fma(splat2(h4.w), l2[e + 3], c2);
             }
-            if (SD) { c0 = fma_(l.dem[n0], hl, c0); c1 = fma_(l.dem[n1], hl, c1); }
-            l.cpart[n0 * 4 + wv] = c0;
-            l.cpart[n1 * 4 + wv] = c1;
+            if (SD) c2 = pk_fma((f32x2){l.dem[n0], l.dem[n1]}, splat2(hl), c2);
+            *reinterpret_cast<float2*>(l.cpart + wv * (2 * 64) + 2 * lane) = make_float2(c2.x, c2.y);   // [chunk][lane][node of the pair]
         }
         __syncthreads();
         STAMP(2);
@@ -363,12 +363,16 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             bool fe[2];
             fe[0] = f0;                          // the mask changes only at the end of this section
             fe[1] = f1;
-            const float4 cpa = *reinterpret_cast<const float4*>(l.cpart + n0 * 4);
-            const float4 cpb = *reinterpret_cast<const float4*>(l.cpart + n1 * 4);
-            f32x2 u2 = (f32x2){cpa.x, cpb.x} + (f32x2){cpa.y, cpb.y};
-            u2 = u2 + (f32x2){cpa.z, cpb.z};
-            u2 = u2 + (f32x2){cpa.w, cpb.w};
-            const f32x2 logit2 = u2 / splat2(sqrtE);
+            // the four column-chunk partials of the lane's node pair arrive as pairs (one 8-byte read each, no repacking)
+            const float2 cp0 = *reinterpret_cast<const float2*>(l.cpart + 2 * lane);
+            const float2 cp1 = *reinterpret_cast<const float2*>(l.cpart + 128 + 2 * lane);
+            const float2 cp2 = *reinterpret_cast<const float2*>(l.cpart + 256 + 2 * lane);
+            const float2 cp3 = *reinterpret_cast<const float2*>(l.cpart + 384 + 2 * lane);
+            const unsigned long long fb0 = __ballot(f0), fb1 = __ballot(f1);      // feasibility bits (the mask row, in SGPRs)
+            f32x2 u2 = (f32x2){cp0.x, cp0.y} + (f32x2){cp1.x, cp1.y};
+            u2 = u2 + (f32x2){cp2.x, cp2.y};
+            u2 = u2 + (f32x2){cp3.x, cp3.y};
+            const f32x2 logit2 = u2 * splat2(inv_sqrtE);
             const bool nan_seen = (fe[0] && logit2.x != logit2.x) || (fe[1] && logit2.y != logit2.y);
             f32x2 v2 = (a.clip > 0.0f) ? d_tanhf2(logit2) * splat2(a.clip) : logit2;
             v2.x = fe[0] ? v2.x : -INFINITY;
@@ -409,7 +413,9 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             sel = __builtin_amdgcn_readfirstlane(sel);
             if (__ballot(nan_seen) != 0ull) st_flags |= EAMRL_ST_NAN_LOGITS;
             if (sel < 0 || sel >= M) { st_flags |= EAMRL_ST_INFEASIBLE; sel = 0; }
-            else if (!l.msk[sel]) st_flags |= EAMRL_ST_INFEASIBLE;
+            // l.msk[sel], from the ballots instead of an LDS round trip on the serial path
+            const bool sel_ok = (((sel < 64) ? (fb0 >> sel) : (fb1 >> (sel - 64))) & 1ull) != 0ull;
+            if (!sel_ok) st_flags |= EAMRL_ST_INFEASIBLE;
             const float lp_sel = __int_as_float(
                 (sel < 64) ? __builtin_amdgcn_readlane(__float_as_int(lpv[0]), sel)
                            : __builtin_amdgcn_readlane(__float_as_int(lpv[1]), sel - 64));
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
                 }
                 cur = sel;
                 istep += 1;
-                count -= (l.msk[sel] != 0);
+                count -= sel_ok ? 1 : 0;
                 done = (count == 0);
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) { l.msk[sel] = 0; l.done = done; }
@@ -640,8 +646,8 @@ int launch_env(const DecArgs& a, hipStream_t st)
     if (a.t_max > res_tmax(ENV)) return EAMRL_E_ARG;
     if (C <= 8) return launch_cp<ENV, 8, 8>(a, st);
     if (C <= 16) return launch_cp<ENV, 16, 16>(a, st);
-    if (C <= 25) return launch_cp<ENV, 28, 25>(a, st);      // M <= 100
-    if (C <= 26) return launch_cp<ENV, 28, 26>(a, st);      // M <= 104 (CVRP-100: M = 101)
+    if (C <= 26) return launch_cp<ENV, 28, 26>(a, st);      // M <= 104 (TSP-100; CVRP-100: M = 101).  (An odd CR leaves the
+                                                            // pair-register array of the values unaligned: the 25-slot variant spilled.)
     if (C <= 28) return launch_cp<ENV, 28, 28>(a, st);
     return launch_cp<ENV, 32, 32>(a, st);
 }

@@ -114,6 +114,17 @@ static float d_logf(float x)
     return fmaf(0.693359375f, fe, r);
 }
 
+/* 1 / x, x normal and positive: three Newton steps from an integer seed (integer subtraction + fma only; dmath.hpp d_rcpf). */
+static float d_rcpf(float x)
+{
+    float r = bits2f(0x7EF311C7u - f2bits(x));
+    for (int i = 0; i < 3; ++i) {
+        float t = fmaf(-x, r, 1.0f);
+        r = fmaf(r, t, r);
+    }
+    return r;
+}
+
 static float d_tanhf(float x)
 {
     float a = fabsf(x);
@@ -130,7 +141,7 @@ static float d_tanhf(float x)
         t = 1.0f;
     } else {
         float e = d_expf(a + a);
-        t = 1.0f - 2.0f / (e + 1.0f);
+        t = fmaf(-2.0f, d_rcpf(e + 1.0f), 1.0f);
     }
     return copysignf(t, x);
 }
@@ -746,7 +757,7 @@ static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, in
     }
     /* D5-D6 logits, clip, mask, temperature */
     const int EC = E / ORC_NCHUNK;
-    const float sqrtE = sqrtf((float)E);
+    const float inv_sqrtE = 1.0f / sqrtf((float)E);      /* one rounded constant; logit = u * inv_sqrtE (round 3: was u / sqrt(E)) */
     float mx = -INFINITY;
     int nan_seen = 0;
     float hl[ORC_NCHUNK];
@@ -762,7 +773,7 @@ static int decode_row(const orc_dec_t* c, long r, int64_t first, int64_t cur, in
             if (dl) cg = fmaf(rem[n], hl[g], cg);
             u = (g == 0) ? cg : u + cg;
         }
-        float logit = u / sqrtE;
+        float logit = u * inv_sqrtE;
         if (logit != logit) nan_seen = 1;
         if (out_logits) out_logits[n] = logit;
         float v = (c->clip > 0.0f) ? d_tanhf(logit) * c->clip : logit;
