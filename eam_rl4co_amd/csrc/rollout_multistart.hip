@@ -13,9 +13,12 @@
 //            P_r the sequential sum of the weights at the chunk's positions r (mod 4) -- a lane holds exactly one such class; a k-step that straddles a chunk boundary is issued for both chunks with
 //            the other chunk's weights zeroed (fma(0, v, acc) == acc);  heads = (((A0+A1)+A2)+A3) / (((Z0+Z1)+Z2)+Z3)
 //   logits   four column chunks of 32: one accumulator per chunk (8 k-steps each), u = ((c0+c1)+c2)+c3
-//   finish   u / sqrt(E), 10 tanh, mask, / temperature, log-softmax with the lane tree (keys of a tile sit 4 per lane in
-//            natural order: the tree's levels are two in-lane adds, two cross-lane adds, then the tile sums pairwise),
-//            greedy = first node equal to the maximum, sampling = first node with the largest p / noise
+//   finish   (round 3) the logit tiles are transposed through LDS so that a HALF-WAVEFRONT owns all keys of one query (lane =
+//            four consecutive keys): u * (1 / sqrt(E)), 10 tanh, mask, / temperature, log-softmax with the lane tree (two
+//            in-lane adds, four DPP levels = a 64-key block per 16 lanes, the two blocks added), greedy = first node equal to the
+//            maximum, sampling = first node with the largest p / noise, and the env transition of that start -- all reductions
+//            inside the half-wavefront, no barrier between them (it was four cross-wave reductions with a barrier each, on seven
+//            of the eight wavefronts)
 // Noise: the caller's [R][t_max][M] tensor, or computed in place from (seed, row, step, node) (exp1_noise4, dmath.hpp).
 //
 // Reference loop replaced: rl4co/models/common/constructive/base.py:236-250 with the multistart layout of
@@ -80,6 +83,37 @@ __device__ __forceinline__ int group_min(int v)
     return min((int)b[0], (int)b[1]);
 }
 
+// Reductions over the 32 lanes of a half-wavefront (both halves at once): the four DPP levels inside a 16-lane row, then the two
+// rows of the half through v_permlane16_swap (result 0 = the even row's value, 1 = the odd row's, in both rows).
+__device__ __forceinline__ float half_max(float v)
+{
+    EAMRL_MAX_DPP(v, "quad_perm:[1,0,3,2]");
+    EAMRL_MAX_DPP(v, "quad_perm:[2,3,0,1]");
+    EAMRL_MAX_DPP(v, "row_half_mirror");
+    EAMRL_MAX_DPP(v, "row_mirror");
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmax_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// the lane tree over keys laid out four per lane: levels 4 .. 32 inside a row (one 64-key block per 16 lanes), then block 0 + block 1
+__device__ __forceinline__ float half_tree_sum(float v)
+{
+    v = v + dpp_f<DPP_XOR1>(v);
+    v = v + dpp_f<DPP_XOR2>(v);
+    v = v + dpp_f<DPP_HALF_MIRROR>(v);
+    v = v + dpp_f<DPP_MIRROR>(v);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ int half_min(int v)
+{
+    v = min(v, dpp_i<DPP_XOR1>(v));
+    v = min(v, dpp_i<DPP_XOR2>(v));
+    v = min(v, dpp_i<DPP_HALF_MIRROR>(v));
+    v = min(v, dpp_i<DPP_MIRROR>(v));
+    auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return min((int)r[0], (int)r[1]);
+}
+
 // CC: the node-chunk length ceil(M / 4) as a compile-time value (0: run time).  With it every "does k-step t touch chunk g"
 // decision folds away; left to run time the ~100 uniform conditions are hoisted out of the loops into SGPRs that spill
 // (measured: 256 VGPRs + scratch vs 167 VGPRs), so the common sizes get their own instantiation.
@@ -91,9 +125,9 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
     constexpr bool CV = ENV == EAMRL_ENV_CVRP;
     __shared__ __attribute__((aligned(16))) float QT[16 * TS];
     __shared__ __attribute__((aligned(16))) float HT[16 * TS];
-    __shared__ float RED[8][16], RED2[8][16], LPS[16];
-    __shared__ int REDI[8][16];
-    __shared__ float REDLP[8][16], LP0[16];
+    constexpr int US = 16 * RTT + 4;                                // row stride of UT (16-byte aligned rows)
+    __shared__ __attribute__((aligned(16))) float UT[16 * US];      // raw logit sums u[query][key] of the tile (transposed tiles)
+    __shared__ float LPSEL[16];                                     // log-prob of each query's pick
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[SMAX][4];
     __shared__ int s_cur[SMAX], s_first[SMAX], s_istep[SMAX], s_cnt[SMAX], s_done[SMAX];
     __shared__ __attribute__((aligned(16))) uint32_t s_vis[CV ? SMAX : 1][4];       // CVRP: visited nodes (depot = bit 0)
@@ -138,7 +172,8 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
         const int n = 4 * t + G;
         vtf[t] = n < M ? a.V[(b * M + n) * ld + 16 * wv + j] : 0.0f;
     }
-    float* lpf = LPF + wv * 32 * 64 + lane;       // lpf[64 * t]
+    float* lpf = LPF + wv * 32 * 64 + lane;       // lpf[64 * t]  (kept in LDS: with the ~165 VGPRs of the compile-time-chunk
+                                                  // variants they would fit in registers, measured 1 % slower -- r03j)
     if (wv < RTT) {
         const int n = 16 * wv + j;
 #pragma unroll
@@ -228,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
             uint4 mb = make_uint4(0, 0, 0, 0);
             if (live) mb = *reinterpret_cast<const uint4*>(&s_bits[sq][0]);
             MSTAMP(0);
-            if (!have_q) __syncthreads();
+            __syncthreads();        // QT is published (stored above, or during the previous tile's finish phase)
             MSTAMP(1);
             // ---- glimpse of head wv ------------------------------------------------------------------------------------------
             {
@@ -258,8 +293,10 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 // softmax weights; a masked node has s = -inf and d_expf2_nonpos gives it exactly 0 (as the canonical select does)
 #pragma unroll
                 for (int kt = 0; kt < RTT; ++kt) {
-                    const f32x2 e01 = d_expf2_nonpos((f32x2){s[kt][0] - m, s[kt][1] - m});
-                    const f32x2 e23 = d_expf2_nonpos((f32x2){s[kt][2] - m, s[kt][3] - m});
+                    // (compile-time chunk length: keys from 4 CC on do not exist -- their weight is the 0 a masked key gets)
+                    const bool pad01 = CC > 0 && 16 * kt >= 4 * CC, pad23 = CC > 0 && 16 * kt + 8 >= 4 * CC;
+                    const f32x2 e01 = pad01 ? splat2(0.0f) : d_expf2_nonpos((f32x2){s[kt][0] - m, s[kt][1] - m});
+                    const f32x2 e23 = pad23 ? splat2(0.0f) : d_expf2_nonpos((f32x2){s[kt][2] - m, s[kt][3] - m});
                     s[kt] = (f32x4){e01.x, e01.y, e23.x, e23.y};
                 }
                 MSTAMP(3);
@@ -267,8 +304,36 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 // progress (A_g against V^T, Z_g against a row of ones), `tot` the finished ones as ((A0 + A1) + A2) + A3.
                 // K-step t holds nodes 4 t .. 4 t + 3 (this lane: 4 t + G); where it straddles a chunk boundary it is issued
                 // once per chunk with the other chunk's weights zeroed.
-                f32x4 cur_o = z4(), tot_o = z4();
-                float cur_z = 0.0f, tot_z = 0.0f;        // Z_g: this lane's nodes are one residue class mod 4 -> P_gG, then the lane groups
+                f32x4 tot_o = z4();
+                float tot_z = 0.0f;
+                if (CC > 0) {
+                    // compile-time chunk length: chunk g is the nodes [g CC, (g + 1) CC) -- slots beyond M carry zero weights and
+                    // zero values --, so which k-steps touch it, and which of them straddle a boundary, is known per (g, t4) and
+                    // everything but the accumulations folds away (round 3: with the chunk in progress as a loop-carried variable
+                    // the unrolled code kept ~70 branches and a group sum per possible boundary position).
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nlo = g * CC, nhi = (g + 1) * CC;
+                        f32x4 co = z4();
+                        float cz = 0.0f;        // Z_g: this lane's nodes are one residue class mod 4 -> P_gG, then the lane groups
+#pragma unroll
+                        for (int t4 = 0; t4 < 4 * RTT; ++t4) {
+                            if (4 * t4 + 3 >= nlo && 4 * t4 < nhi) {                        // the k-step holds nodes of the chunk
+                                const float w = s[t4 >> 2][t4 & 3];
+                                const bool whole = 4 * t4 >= nlo && 4 * t4 + 3 < nhi;       // ... and only such nodes
+                                const int n = 4 * t4 + G;
+                                const float wg = whole ? w : ((n >= nlo && n < nhi) ? w : 0.0f);
+                                co = mf(vtf[t4], wg, co);
+                                cz = cz + wg;
+                            }
+                        }
+                        const float zg = (nlo & 1) ? group_sum_odd(cz, lane) : group_sum(cz);
+                        tot_o = g == 0 ? co : tot_o + co;
+                        tot_z = g == 0 ? zg : tot_z + zg;
+                    }
+                } else {
+                f32x4 cur_o = z4();
+                float cur_z = 0.0f;        // Z_g: this lane's nodes are one residue class mod 4 -> P_gG, then the lane groups
                 int curc = 0;
                 bool first = true;
 #pragma unroll
@@ -302,6 +367,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                     tot_o = first ? cur_o : tot_o + cur_o;
                     tot_z = first ? zg : tot_z + zg;
                 }
+                }
                 // lane (query j, G), register r -> head column e = 4 G + r -> A layout (g = r, t = 4 wv + G)
                 float* hp = HT + j * TS + 4 * wv + G;
                 float hv[4];
@@ -321,12 +387,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
             MSTAMP(5);
             float4 q_next = make_float4(0.f, 0.f, 0.f, 0.f);
             if (pre) q_next = q_load(qt + 1 == qt1 ? qt0 : qt + 1);
-            // ---- logits of key tile wv, finish ----------------------------------------------------------------------------
-            float x[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            bool fe[4] = {false, false, false, false};
-            float nz[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-            const int nbase = 16 * wv + 4 * G;                       // this lane's keys: nbase + r
-            bool nan_seen = false;
+            // ---- logits of key tile wv: u[query][key] = ((c0 + c1) + c2) + c3, transposed into UT ---------------------------------
             if (wv < RTT) {
                 const float* hp = HT + j * TS + G * TG;
                 f32x4 c[4];
@@ -343,26 +404,44 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                         c[g] = mf(lpf[64 * (8 * g + 4 * u + 3)], hi.y, c[g]);
                     }
                 }
-                MSTAMP(6);
-                if (a.mode == EAMRL_SAMPLE && live) {
-                    const int64_t r = (int64_t)sq * a.B + b;
+                const f32x4 u = ((c[0] + c[1]) + c[2]) + c[3];          // lane (query j, G): keys 16 wv + 4 G + (0..3)
+                *reinterpret_cast<float4*>(UT + j * US + 16 * wv + 4 * G) = make_float4(u[0], u[1], u[2], u[3]);
+            }
+            MSTAMP(6);
+            __syncthreads();
+            MSTAMP(9);
+            // ---- finish: half-wavefront hw2 = query 2 wv + (lane >> 5) of the tile; lane l32 holds the keys 4 l32 .. 4 l32 + 3 --------
+            {
+                const int l32 = lane & 31;
+                const int jq2 = 2 * wv + (lane >> 5), s2 = 16 * qt + jq2;
+                const bool live2 = s2 < S && !s_done[s2];
+                const int nb4 = 4 * l32;                                 // this lane's keys: nb4 + r
+                const bool inq = l32 < 4 * RTT;                          // UT holds 16 RTT keys per query
+                const int64_t r2 = (int64_t)s2 * a.B + b;
+                uint4 mb2 = make_uint4(0, 0, 0, 0);
+                if (live2) mb2 = *reinterpret_cast<const uint4*>(&s_bits[s2][0]);
+                float4 u4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inq) u4 = *reinterpret_cast<const float4*>(UT + jq2 * US + nb4);
+                float nz[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+                if (a.mode == EAMRL_SAMPLE && live2 && inq) {
                     if (a.use_rng) {
-                        exp1_noise4(seed, r, t, nbase >> 2, nz);
+                        exp1_noise4(seed, r2, t, l32, nz);
                     } else {
-                        const float* np_ = a.noise + (r * a.t_max + t) * (int64_t)M;
+                        const float* np_ = a.noise + (r2 * a.t_max + t) * (int64_t)M;
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr)
-                            if (nbase + rr < M) nz[rr] = np_[nbase + rr];
+                            if (nb4 + rr < M) nz[rr] = np_[nb4 + rr];
                     }
                 }
                 MSTAMP(7);
+                bool fe[4];
                 f32x2 v01, v23;
+                bool nan_seen;
                 {
-                    const f32x4 u = ((c[0] + c[1]) + c[2]) + c[3];
-                    const f32x2 l01 = (f32x2){u[0], u[1]} * splat2(inv_sqrtE), l23 = (f32x2){u[2], u[3]} * splat2(inv_sqrtE);
-                    const uint32_t w = (nbase >> 5) == 0 ? mb.x : (nbase >> 5) == 1 ? mb.y : (nbase >> 5) == 2 ? mb.z : mb.w;
+                    const f32x2 l01 = (f32x2){u4.x, u4.y} * splat2(inv_sqrtE), l23 = (f32x2){u4.z, u4.w} * splat2(inv_sqrtE);
+                    const uint32_t w = (nb4 >> 5) == 0 ? mb2.x : (nb4 >> 5) == 1 ? mb2.y : (nb4 >> 5) == 2 ? mb2.z : mb2.w;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) fe[r] = (w >> ((nbase & 31) + r)) & 1u;
+                    for (int r = 0; r < 4; ++r) fe[r] = inq && ((w >> ((nb4 & 31) + r)) & 1u);
                     nan_seen = (fe[0] && l01.x != l01.x) || (fe[1] && l01.y != l01.y) || (fe[2] && l23.x != l23.x) ||
                                (fe[3] && l23.y != l23.y);
                     v01 = (a.clip > 0.0f) ? d_tanhf2(l01) * splat2(a.clip) : l01;
@@ -375,104 +454,54 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                         v23 = v23 / splat2(a.temp);
                     }
                 }
-                x[0] = v01.x; x[1] = v01.y; x[2] = v23.x; x[3] = v23.y;
-                const float mx = group_max(vmax_raw(vmax_raw(x[0], x[1]), vmax_raw(x[2], x[3])));
-                if (G == 0) RED[wv][j] = mx;
-            }
-            MSTAMP(8);
-            __syncthreads();
-            MSTAMP(9);
-            float mq = -INFINITY;
-#pragma unroll
-            for (int w = 0; w < RTT; ++w) mq = vmax_raw(mq, RED[w][j]);
-            float d[4] = {0.f, 0.f, 0.f, 0.f};                       // x - max
-            if (wv < RTT) {
-                const f32x2 d01 = (f32x2){x[0], x[1]} - splat2(mq), d23 = (f32x2){x[2], x[3]} - splat2(mq);
-                const f32x2 e01 = d_expf2_nonpos(d01), e23 = d_expf2_nonpos(d23);
-                d[0] = d01.x; d[1] = d01.y; d[2] = d23.x; d[3] = d23.y;
-                const float e0 = fe[0] ? e01.x : 0.0f, e1 = fe[1] ? e01.y : 0.0f, e2 = fe[2] ? e23.x : 0.0f, e3 = fe[3] ? e23.y : 0.0f;
-                const float ts = group_sum((e0 + e1) + (e2 + e3));      // lane tree levels 1, 2 (in lane), 4, 8 (lane groups)
-                if (G == 0) RED2[wv][j] = ts;
-            }
-            MSTAMP(10);
-            __syncthreads();
-            MSTAMP(11);
-            float lse, lp[4];
-            {
-                float T[8];
-#pragma unroll
-                for (int w = 0; w < 8; ++w) T[w] = w < RTT ? RED2[w][j] : 0.0f;
-                const float Zl = ((T[0] + T[1]) + (T[2] + T[3])) + ((T[4] + T[5]) + (T[6] + T[7]));   // levels 16, 32; 64-blocks ascending
-                lse = d_logf(Zl);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) lp[r] = fe[r] ? d[r] - lse : -INFINITY;
-            }
-            // ---- selection -------------------------------------------------------------------------------------------------
-            float key[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            float top = 0.0f - lse;                                   // greedy: the maximum log-prob is (mx - mx) - lse
-            if (a.mode == EAMRL_SAMPLE) {
-                if (wv < RTT) {
+                const float mq = half_max(vmax_raw(vmax_raw(v01.x, v01.y), vmax_raw(v23.x, v23.y)));
+                MSTAMP(8);
+                const f32x2 d01 = v01 - splat2(mq), d23 = v23 - splat2(mq);
+                float lse, lp[4];
+                {
+                    const f32x2 e01 = d_expf2_nonpos(d01), e23 = d_expf2_nonpos(d23);
+                    const float e0 = fe[0] ? e01.x : 0.0f, e1 = fe[1] ? e01.y : 0.0f, e2 = fe[2] ? e23.x : 0.0f, e3 = fe[3] ? e23.y : 0.0f;
+                    const float Zl = half_tree_sum((e0 + e1) + (e2 + e3));     // levels 1, 2 in lane; 4 .. 32 in the row; block 0 + block 1
+                    lse = d_logf(Zl);
+                    lp[0] = fe[0] ? d01.x - lse : -INFINITY; lp[1] = fe[1] ? d01.y - lse : -INFINITY;
+                    lp[2] = fe[2] ? d23.x - lse : -INFINITY; lp[3] = fe[3] ? d23.y - lse : -INFINITY;
+                }
+                MSTAMP(10);
+                // ---- selection: greedy = first node whose log-prob equals the maximum (mx - mx) - lse; sampling = first node with
+                //      the largest p / noise --------------------------------------------------------------------------------------
+                int cand = 1 << 20;
+                if (a.mode == EAMRL_SAMPLE) {
                     const f32x2 k01 = d_expf2_nonpos((f32x2){lp[0], lp[1]}) / (f32x2){nz[0], nz[1]};
                     const f32x2 k23 = d_expf2_nonpos((f32x2){lp[2], lp[3]}) / (f32x2){nz[2], nz[3]};
-                    key[0] = nbase + 0 < M ? k01.x : -INFINITY; key[1] = nbase + 1 < M ? k01.y : -INFINITY;
-                    key[2] = nbase + 2 < M ? k23.x : -INFINITY; key[3] = nbase + 3 < M ? k23.y : -INFINITY;
-                    const float km = group_max(vmax_raw(vmax_raw(key[0], key[1]), vmax_raw(key[2], key[3])));
-                    if (G == 0) RED[wv][j] = km;                      // (RED was last read before the previous barrier)
+                    float key[4];
+                    key[0] = (inq && nb4 + 0 < M) ? k01.x : -INFINITY; key[1] = (inq && nb4 + 1 < M) ? k01.y : -INFINITY;
+                    key[2] = (inq && nb4 + 2 < M) ? k23.x : -INFINITY; key[3] = (inq && nb4 + 3 < M) ? k23.y : -INFINITY;
+                    const float top = half_max(vmax_raw(vmax_raw(key[0], key[1]), vmax_raw(key[2], key[3])));
+#pragma unroll
+                    for (int r = 3; r >= 0; --r)
+                        if (key[r] == top) cand = nb4 + r;
+                } else {
+                    const float top = 0.0f - lse;
+#pragma unroll
+                    for (int r = 3; r >= 0; --r)
+                        if (inq && nb4 + r < M && lp[r] == top) cand = nb4 + r;
                 }
-                __syncthreads();
-                top = -INFINITY;
-#pragma unroll
-                for (int w = 0; w < RTT; ++w) top = vmax_raw(top, RED[w][j]);
-            }
-            if (wv < RTT) {
-                int cand = 1 << 20;
-#pragma unroll
-                for (int r = 3; r >= 0; --r) {
-                    const bool hit = (a.mode == EAMRL_SAMPLE) ? (key[r] == top) : (nbase + r < M && lp[r] == top);
-                    if (hit) cand = nbase + r;
+                int sel = half_min(cand);
+                if (a.mode == EAMRL_EVALUATE && live2) sel = (t < a.t_given) ? (int)a.given[r2 * a.t_given + t] : 0;
+                uint32_t fl = 0;
+                if (live2) {
+                    if (nan_seen) fl |= EAMRL_ST_NAN_LOGITS;
+                    if (sel < 0 || sel >= M) { fl |= EAMRL_ST_INFEASIBLE; sel = 0; }
                 }
-                cand = group_min(cand);
-                if (G == 0) REDI[wv][j] = cand;
-                if (cand >= nbase && cand < nbase + 4) REDLP[wv][j] = lp[cand - nbase];     // the log-prob of this tile's candidate
-                if (wv == 0 && G == 0) LP0[j] = lp[0];
-            }
-            if (pre) q_store(q_next);           // QT is free since the glimpse barrier; the barrier below publishes it
-            have_q = pre;
-            MSTAMP(12);
-            __syncthreads();
-            MSTAMP(13);
-            int sel = 1 << 20;
-#pragma unroll
-            for (int w = 0; w < RTT; ++w) sel = min(sel, REDI[w][j]);
-            const int picked = sel;             // the wave whose candidate this is holds its log-prob in REDLP
-            if (a.mode == EAMRL_EVALUATE && live)
-                sel = (t < a.t_given) ? (int)a.given[((int64_t)sq * a.B + b) * a.t_given + t] : 0;
-            uint32_t fl = 0;
-            if (live) {
-                if (nan_seen) fl |= EAMRL_ST_NAN_LOGITS;
-                if (sel < 0 || sel >= M) { fl |= EAMRL_ST_INFEASIBLE; sel = 0; }
-            }
-            if (fl) atomicOr(&s_flags, fl);
-            if (a.mode == EAMRL_EVALUATE) {     // the given node's log-prob lives in whichever wave owns that key tile
-                if (live && wv < RTT && sel >= nbase && sel < nbase + 4) LPS[j] = lp[sel - nbase];
-                __syncthreads();
-            }
-            // ---- env transition (TSPEnv._step, tsp/env.py:62-88) of the tile's 16 starts: lanes (j, G = 0) of wave 0 -------------
-            if (!CV && tid < 16) {
-                const int s = 16 * qt + tid;
-                if (s < S && !s_done[s]) {
-                    const int sl = sel;
-                    float lpv;
-                    if (a.mode == EAMRL_EVALUATE) lpv = LPS[tid];
-                    else {
-                        lpv = LP0[tid];         // (sel was replaced by node 0 after an infeasible pick)
-#pragma unroll
-                        for (int w = 0; w < RTT; ++w)
-                            if (sl == picked && REDI[w][tid] == picked) lpv = REDLP[w][tid];
-                    }
-                    const int64_t r = (int64_t)s * a.B + b;
-                    a.action[r * a.t_max + t] = sl;
-                    a.logp[r * a.t_max + t] = lpv;
+                if (fl) atomicOr(&s_flags, fl);
+                if (live2 && inq && sel >= nb4 && sel < nb4 + 4) LPSEL[jq2] = lp[sel - nb4];      // the lane that holds the pick
+                __builtin_amdgcn_wave_barrier();        // LPSEL is read by lanes of the same wavefront: LDS keeps its accesses in order
+                MSTAMP(12);
+                // ---- env transition (TSPEnv._step, tsp/env.py:62-88): lane 0 of the half-wavefront ---------------------------------
+                if (!CV && l32 == 0 && live2) {
+                    const int s = s2, sl = sel;
+                    a.action[r2 * a.t_max + t] = sl;
+                    a.logp[r2 * a.t_max + t] = LPSEL[jq2];
                     const uint32_t bit = 1u << (sl & 31);
                     const uint32_t wd = s_bits[s][sl >> 5];
                     if (!(wd & bit)) atomicOr(&s_flags, EAMRL_ST_INFEASIBLE);
@@ -483,29 +512,12 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                     s_cnt[s] -= (wd & bit) != 0;
                     s_done[s] = s_cnt[s] == 0;
                 }
-            }
-            // ---- CVRP: CVRPEnv._step + get_action_mask (cvrp/env.py:68-100,132-144).  Half-wavefront hw owns start 16 qt + hw: every
-            // lane knows the pick, lane l tests nodes l, l + 32, l + 64, l + 96, the ballots are the new mask words ---------------
-            if (CV) {
-                const int hw = tid >> 5, l32 = tid & 31;
-                const int s = 16 * qt + hw;
-                if (s < S && !s_done[s]) {
-                    int sl = 1 << 20;
-#pragma unroll
-                    for (int w = 0; w < RTT; ++w) sl = min(sl, REDI[w][hw]);
-                    const int pk = sl;
-                    const int64_t r = (int64_t)s * a.B + b;
-                    if (a.mode == EAMRL_EVALUATE) sl = (t < a.t_given) ? (int)a.given[r * a.t_given + t] : 0;
-                    if (sl < 0 || sl >= M) sl = 0;                 // (flagged above by the query's own lanes)
-                    float lpv;
-                    if (a.mode == EAMRL_EVALUATE) lpv = LPS[hw];
-                    else {
-                        lpv = LP0[hw];
-#pragma unroll
-                        for (int w = 0; w < RTT; ++w)
-                            if (sl == pk && REDI[w][hw] == pk) lpv = REDLP[w][hw];
-                    }
-                    const uint4 ob = *reinterpret_cast<const uint4*>(&s_bits[s][0]);
+                // ---- CVRP: CVRPEnv._step + get_action_mask (cvrp/env.py:68-100,132-144): every lane of the half-wavefront knows the
+                // pick, lane l tests nodes l, l + 32, l + 64, l + 96, the ballots are the new mask words ------------------------------
+                if (CV && live2) {
+                    const int s = s2, sl = sel, hw = lane >> 5;
+                    const float lpv = LPSEL[jq2];
+                    const uint4 ob = mb2;
                     uint4 vw = *reinterpret_cast<const uint4*>(&s_vis[s][0]);
                     const uint32_t bit = 1u << (sl & 31);
                     const int wi = sl >> 5;
@@ -524,13 +536,13 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                         const uint32_t vk = k == 0 ? vw.x : k == 1 ? vw.y : k == 2 ? vw.z : vw.w;
                         const bool ok = n >= 1 && n < M && !((vk >> l32) & 1u) && !((s_dem[n] + u) > lim);
                         const unsigned long long bl = __ballot(ok);
-                        nb[k] = (uint32_t)(bl >> (32 * (hw & 1)));
+                        nb[k] = (uint32_t)(bl >> (32 * hw));
                     }
                     const bool any_free = (nb[0] | nb[1] | nb[2] | nb[3]) != 0u;
                     if (!((sl == 0) && any_free)) nb[0] |= 1u;          // the depot: closed only while at it with customers left
                     if (l32 == 0) {
-                        a.action[r * a.t_max + t] = sl;
-                        a.logp[r * a.t_max + t] = lpv;
+                        a.action[r2 * a.t_max + t] = sl;
+                        a.logp[r2 * a.t_max + t] = lpv;
                         if (!(oword & bit)) atomicOr(&s_flags, EAMRL_ST_INFEASIBLE);
                         *reinterpret_cast<uint4*>(&s_bits[s][0]) = make_uint4(nb[0], nb[1], nb[2], nb[3]);
                         *reinterpret_cast<uint4*>(&s_vis[s][0]) = vw;
@@ -542,8 +554,10 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                     }
                 }
             }
-            // (ordered against its readers by the barriers of the next tile: REDI / REDLP are rewritten only after three of them,
-            //  and the state of these 16 starts is next read one round later, or behind the tile-start barrier when nqt == 1)
+            if (pre) q_store(q_next);           // QT is free since the glimpse barrier; the next tile's first barrier publishes it
+            have_q = pre;
+            // (UT / LPSEL are rewritten by the next tile only behind its glimpse barrier, which every wavefront reaches after this
+            //  finish phase; the state of these 16 starts is next read one round later, or behind the tile-start barrier)
             MSTAMP(14);
         }
         ++t;
