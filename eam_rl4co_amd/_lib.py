@@ -82,6 +82,10 @@ PROTOTYPES = {
     "eamrl_matmul_right": [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "eamrl_linear_wgrad_scratch": [_i64, _i32, _i32],
     "eamrl_linear_wgrad": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
+    "eamrl_small_linear_wgrad_scratch": [_i64, _i32],
+    "eamrl_small_linear_wgrad": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
+    "eamrl_batchnorm_backward_scratch": [_i64, _i32],
+    "eamrl_batchnorm_backward": [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "eamrl_mha_encoder": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "eamrl_mha_encoder_backward_supported": [_i32, _i32, _i32],
     "eamrl_mha_encoder_backward": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
@@ -121,7 +125,8 @@ PROTOTYPES = {
                            _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eamrl_ea_tsp_run": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp],
 }
-_RESTYPES = {"eamrl_last_error": C.c_char_p, "eamrl_linear_wgrad_scratch": C.c_int64}
+_RESTYPES = {"eamrl_last_error": C.c_char_p, "eamrl_linear_wgrad_scratch": C.c_int64,
+             "eamrl_small_linear_wgrad_scratch": C.c_int64, "eamrl_batchnorm_backward_scratch": C.c_int64}
 
 _lib = None
 

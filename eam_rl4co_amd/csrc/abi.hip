@@ -298,6 +298,42 @@ __attribute__((visibility("default"))) int eamrl_encoder_fused_supported(int M, 
     return encoder_fused_supports(M, E, H, ff_hidden, nlayers) ? 1 : 0;
 }
 
+__attribute__((visibility("default"))) int64_t eamrl_small_linear_wgrad_scratch(int64_t rows, int out_dim)
+{
+    if (rows < 0 || out_dim <= 0) return -1;
+    return small_linear_wgrad_scratch(rows, out_dim);
+}
+
+__attribute__((visibility("default"))) int eamrl_small_linear_wgrad(const float* dy, int64_t ldy, const float* x, int64_t ldx,
+                                                                   int64_t rows, int out_dim, int in_dim, float* dW, float* db,
+                                                                   float* scratch, int64_t scratch_floats, void* stream)
+{
+    REQUIRE(dy && x && dW && scratch, "eamrl_small_linear_wgrad");
+    REQUIRE(rows >= 0 && out_dim > 0 && in_dim >= 1 && in_dim <= 8 && ldy >= out_dim && ldx >= in_dim, "eamrl_small_linear_wgrad");
+    REQUIRE(scratch_floats >= small_linear_wgrad_scratch(rows, out_dim), "eamrl_small_linear_wgrad");
+    return launched(launch_small_linear_wgrad(dy, ldy, x, ldx, rows, out_dim, in_dim, dW, db, scratch, (hipStream_t)stream),
+                    "eamrl_small_linear_wgrad");
+}
+
+__attribute__((visibility("default"))) int64_t eamrl_batchnorm_backward_scratch(int64_t rows, int E)
+{
+    if (rows < 0 || E <= 0) return -1;
+    return batchnorm_backward_scratch(rows, E);
+}
+
+__attribute__((visibility("default"))) int eamrl_batchnorm_backward(const float* x, const float* dy, const float* save_mean,
+                                                                   const float* save_var, const float* gamma, float eps, int64_t rows,
+                                                                   int E, float* dx, float* dgamma, float* dbeta, float* scratch,
+                                                                   int64_t scratch_floats, void* stream)
+{
+    REQUIRE(x && dy && save_mean && save_var && dx && scratch, "eamrl_batchnorm_backward");
+    REQUIRE(rows >= 0 && E > 0 && E % 4 == 0, "eamrl_batchnorm_backward");
+    REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0), "eamrl_batchnorm_backward");
+    REQUIRE(scratch_floats >= batchnorm_backward_scratch(rows, E), "eamrl_batchnorm_backward");
+    return launched(launch_batchnorm_backward(x, dy, save_mean, save_var, gamma, eps, rows, E, dx, dgamma, dbeta, scratch,
+                                              (hipStream_t)stream), "eamrl_batchnorm_backward");
+}
+
 static int check_encoder_fused(int64_t B, int M, int E, int H, int ff_hidden, int nlayers, int norm,
                                const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache, const char* what)
 {

@@ -43,6 +43,13 @@ int launch_encoder_fused(const float* h_in, float* h_out, int64_t B, int M, int 
                          const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache, const eamrl_encoder_init* init,
                          hipStream_t st);
 int launch_pack_mfma_b(const float* W, float* Wp, int N, int K, hipStream_t st);
+// BatchNorm-train backward and the tiny-K Linear weight gradient (train_norm.hip)
+int64_t batchnorm_backward_scratch(int64_t rows, int E);
+int launch_batchnorm_backward(const float* x, const float* dy, const float* mean, const float* var, const float* gamma, float eps,
+                              int64_t rows, int E, float* dx, float* dgamma, float* dbeta, float* ws, hipStream_t st);
+int64_t small_linear_wgrad_scratch(int64_t rows, int out_dim);
+int launch_small_linear_wgrad(const float* dy, int64_t ldy, const float* x, int64_t ldx, int64_t rows, int out_dim, int K, float* dW,
+                              float* db, float* ws, hipStream_t st);
 // Linear weight gradient (train_gemm.hip)
 bool linear_wgrad_supports(int out_dim, int in_dim);
 int64_t linear_wgrad_scratch(int64_t rows, int out_dim, int in_dim);

@@ -147,6 +147,43 @@ def linear_wgrad(dy, x, need_bias=True):
     return dW, db
 
 
+def small_linear_wgrad(dy, x, need_bias=True):
+    """dW [out, K] = dy^T x, db [out] for a Linear with K <= 8 inputs (eamrl_small_linear_wgrad); dy [..., out], x [..., K]."""
+    lib = _lib.load()
+    dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+    for nm, t_ in (("dy", dy2), ("x", x2)):
+        _need_gpu(t_, nm)
+        if t_.dtype != torch.float32 or t_.stride(-1) != 1:
+            raise TypeError(f"small_linear_wgrad: {nm} must be fp32 with unit inner stride")
+    rows, out_dim = dy2.shape
+    K = x2.shape[1]
+    if x2.shape[0] != rows or not 1 <= K <= 8:
+        raise ValueError("small_linear_wgrad: row mismatch or more than 8 input features")
+    dW = torch.empty(out_dim, K, dtype=torch.float32, device=dy.device)
+    db = torch.empty(out_dim, dtype=torch.float32, device=dy.device) if need_bias else None
+    scratch = torch.empty(max(int(lib.eamrl_small_linear_wgrad_scratch(rows, out_dim)), 4), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.eamrl_small_linear_wgrad(_ptr(dy2), dy2.stride(0), _ptr(x2), x2.stride(0), rows, out_dim, K, _ptr(dW), _ptr(db),
+                                            _ptr(scratch), scratch.numel(), _stream(dy)), "eamrl_small_linear_wgrad")
+    return dW, db
+
+
+def batchnorm_backward(x, dy, save_mean, save_var, gamma, eps, need_affine_grads=True):
+    """Gradient of batchnorm_train_ (eamrl_batchnorm_backward): x = the normalisation's input [..., E] -> (dx, dgamma, dbeta)."""
+    lib = _lib.load()
+    _chk(x, "x", torch.float32)
+    _chk(dy, "dy", torch.float32, tuple(x.shape))
+    E = x.shape[-1]
+    rows = x.numel() // E
+    dx = torch.empty_like(x)
+    dg = torch.empty(E, dtype=torch.float32, device=x.device) if need_affine_grads else None
+    db = torch.empty(E, dtype=torch.float32, device=x.device) if need_affine_grads else None
+    scratch = torch.empty(max(int(lib.eamrl_batchnorm_backward_scratch(rows, E)), 4), dtype=torch.float32, device=x.device)
+    _lib.check(lib.eamrl_batchnorm_backward(_ptr(x), _ptr(dy), _ptr(save_mean), _ptr(save_var), _ptr(gamma), float(eps), rows, E,
+                                            _ptr(dx), _ptr(dg), _ptr(db), _ptr(scratch), scratch.numel(), _stream(x)),
+               "eamrl_batchnorm_backward")
+    return dx, dg, db
+
+
 def mha_encoder(qkv, num_heads):
     lib = _lib.load()
     _chk(qkv, "qkv", torch.float32)

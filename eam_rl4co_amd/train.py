@@ -55,6 +55,61 @@ class _InstanceNormFn(torch.autograd.Function):
         return dx, (dg if ctx.affine[0] else None), (db if ctx.affine[1] else None), None
 
 
+class _BatchNormTrainFn(torch.autograd.Function):
+    """BatchNorm1d with BATCH statistics on [rows, E] (policy.train(), nn/ops.py:45-47): forward eamrl_batchnorm_train -- the
+    kernels, and therefore the bits, of the native rollout's encoder --, backward eamrl_batchnorm_backward.  The running
+    statistics are not touched here (the rollout updated them once for this forward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        from . import ops
+
+        y = x.clone(memory_format=torch.contiguous_format)          # the kernel normalises in place; x is kept for the backward
+        _, mean, var = ops.batchnorm_train_(y, weight.detach(), bias.detach(), None, None, 0.0, eps)
+        ctx.save_for_backward(x.contiguous(), mean, var, weight)
+        ctx.eps = eps
+        ctx.affine = weight.requires_grad or bias.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+
+        x, mean, var, weight = ctx.saved_tensors
+        dx, dg, db = ops.batchnorm_backward(x, dy.contiguous(), mean, var, weight.detach(), ctx.eps, need_affine_grads=ctx.affine)
+        return dx, dg, db, None
+
+
+class _SmallLinearFn(torch.autograd.Function):
+    """The init embeddings' Linear(2 .. 8 -> E) on [rows, K] node features: forward eamrl_linear's tiny-K kernel (the rollout's
+    own init embedding), weight / bias gradient eamrl_small_linear_wgrad.  The features are inputs: no input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import ops
+
+        xc = x.contiguous()
+        ctx.save_for_backward(xc)
+        ctx.has_bias = bias is not None
+        return ops.linear(xc, weight.detach(), None if bias is None else bias.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+
+        (x,) = ctx.saved_tensors
+        dW, db = ops.small_linear_wgrad(dy.contiguous(), x, need_bias=ctx.has_bias)
+        return None, dW, db
+
+
+def _small_linear(x, weight, bias):
+    """F.linear for the init embeddings; native where the features need no gradient (they are the instance)."""
+    if (x.is_cuda and x.dtype == torch.float32 and not x.requires_grad and weight.shape[1] <= 8 and weight.is_contiguous()
+            and os.environ.get("EAMRL_TORCH_INIT_EMBED", "0") != "1"):
+        return _SmallLinearFn.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
 class _LinearFn(torch.autograd.Function):
     """torch.nn.Linear (+ ReLU) of the training graph on the package's own GEMMs: forward eamrl_linear (the rollout's kernel),
     input gradient eamrl_linear on the transposed weight, weight / bias gradient eamrl_linear_wgrad.  hipBLASLt runs these fp32 shapes
@@ -137,7 +192,10 @@ def _normalize(norm: nn.Module, x: torch.Tensor, training: bool) -> torch.Tensor
         # Batch statistics when training, as the reference (nn/ops.py:45-47) and as the native rollout that drew the
         # actions (ops.batchnorm_train_); the running statistics were updated by that rollout, not again here.
         x2 = x.reshape(-1, x.size(-1))
-        if training:
+        if training and x2.is_cuda and x2.dtype == torch.float32 and n.weight is not None and x2.size(-1) % 4 == 0 \
+                and os.environ.get("EAMRL_TORCH_BATCHNORM", "0") != "1":
+            y = _BatchNormTrainFn.apply(x2, n.weight, n.bias, float(n.eps))
+        elif training:
             y = F.batch_norm(x2, None, None, n.weight, n.bias, True, 0.0, n.eps)
         else:
             y = F.batch_norm(x2, n.running_mean, n.running_var, n.weight, n.bias, False, 0.0, n.eps)
@@ -152,10 +210,11 @@ def encode_autograd(policy, td):
     enc = policy.encoder
     ie = enc.init_embedding
     locs = td["locs"]
+    native_init = locs.is_cuda and os.environ.get("EAMRL_TORCH_INIT_EMBED", "0") != "1"
     if policy.env_name == "tsp":
-        h = F.linear(locs, ie.init_embed.weight, ie.init_embed.bias)
+        h = _small_linear(locs, ie.init_embed.weight, ie.init_embed.bias)
     else:
-        depot = F.linear(locs[:, :1], ie.init_embed_depot.weight, ie.init_embed_depot.bias)
+        depot = _small_linear(locs[:, :1], ie.init_embed_depot.weight, ie.init_embed_depot.bias)
         if policy.env_name == "pctsp":
             feat = torch.cat((locs[:, 1:], td["expected_prize"][..., None], td["penalty"][..., 1:, None]), -1)
         elif policy.env_name == "op":
@@ -165,12 +224,13 @@ def encode_autograd(policy, td):
                               td["durations"][..., 1:, None]), -1)
         else:
             feat = torch.cat((locs[:, 1:], td["demand"][..., None]), -1)
-        h = torch.cat((depot, F.linear(feat, ie.init_embed.weight, ie.init_embed.bias)), 1)
-    if locs.is_cuda:
-        # the VALUE of the rollout's own init embedding (its kernels' rounding), the gradient of the expression above:
-        # x + (y - y) is exactly x.  With that, the Linears / attention / instance norms below being the rollout's kernels,
-        # the embeddings of this graph equal the native encoder's bit for bit (instance-norm policies;
-        # test_training_graph_encoder_equals_native_encoder) and one encoder pass can serve rollout and gradient.
+        h = torch.cat((depot, _small_linear(feat, ie.init_embed.weight, ie.init_embed.bias)), 1)
+    if locs.is_cuda and not native_init:
+        # (cross-check path, EAMRL_TORCH_INIT_EMBED=1) the VALUE of the rollout's own init embedding (its kernels' rounding), the
+        # gradient of torch's expression above: x + (y - y) is exactly x.  By default `_small_linear` already IS the rollout's
+        # kernel, so -- the Linears / attention / norms below being the rollout's kernels too -- the embeddings of this graph equal
+        # the native encoder's bit for bit (test_training_graph_encoder_equals_native_encoder) and one encoder pass can serve
+        # rollout and gradient.
         with torch.no_grad():
             h_native = ie(td)
         h = h_native + (h - h.detach())
@@ -385,9 +445,11 @@ def _graph_key(policy, td):
 
 
 def graph_encoder_equals_native(policy, td) -> bool:
-    """True where `encode_autograd` reproduces the native encoder's embeddings bit for bit: instance-norm layers (their
-    training forward kernel sums in the rollout's order; batch norm goes through torch's batch_norm), every Linear, the
-    self-attention and the norms on this library's kernels (none of the EAMRL_TORCH_* switches), fp32 on the GPU."""
+    """True where `encode_autograd` reproduces the native encoder's embeddings bit for bit AND may stand in for it: instance-norm
+    layers (their training forward kernel sums in the rollout's order), every Linear, the self-attention and the norms on this
+    library's kernels (none of the EAMRL_TORCH_* switches), fp32 on the GPU.  Batch-norm policies keep two passes: their graph
+    runs on the same kernels since round 3 (`_BatchNormTrainFn`), but the rollout's pass is the one that updates the running
+    statistics."""
     if any(os.environ.get(k, "0") == "1" for k in ("EAMRL_TORCH_LINEAR", "EAMRL_TORCH_ATTENTION", "EAMRL_TORCH_INSTANCE_NORM",
                                                   "EAMRL_SEPARATE_ENCODER_PASSES")):
         return False

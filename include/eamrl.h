@@ -158,6 +158,21 @@ int64_t eamrl_linear_wgrad_scratch(int64_t rows, int out_dim, int in_dim);
 int eamrl_linear_wgrad(const float* dy, int64_t ldy, const float* x, int64_t ldx, int64_t rows, int out_dim, int in_dim,
                        float* dW, float* db, float* scratch, int64_t scratch_floats, void* stream);
 
+/* The same for the init embeddings' Linears (in_dim = 2 .. 8 node features -> E  [nn/env_embeddings/init.py:55-68,115-138]):
+ * dW [out_dim][in_dim], db [out_dim] (or NULL).  scratch: eamrl_small_linear_wgrad_scratch(rows, out_dim) floats. */
+int64_t eamrl_small_linear_wgrad_scratch(int64_t rows, int out_dim);
+int eamrl_small_linear_wgrad(const float* dy, int64_t ldy, const float* x, int64_t ldx, int64_t rows, int out_dim, int in_dim,
+                             float* dW, float* db, float* scratch, int64_t scratch_floats, void* stream);
+
+/* Gradient of eamrl_batchnorm_train (BatchNorm1d with batch statistics under loss.backward(), nn/ops.py:45-47):
+ * x, dy [rows][E] (x = the INPUT of the normalisation), save_mean / save_var as written by eamrl_batchnorm_train,
+ * gamma [E] (NULL: ones) -> dx [rows][E], dgamma [E], dbeta [E] (either may be NULL).  E a multiple of 4.
+ * scratch: eamrl_batchnorm_backward_scratch(rows, E) floats.  Chunk-order sums (gradient path, not bit-exact). */
+int64_t eamrl_batchnorm_backward_scratch(int64_t rows, int E);
+int eamrl_batchnorm_backward(const float* x, const float* dy, const float* save_mean, const float* save_var, const float* gamma,
+                             float eps, int64_t rows, int E, float* dx, float* dgamma, float* dbeta, float* scratch,
+                             int64_t scratch_floats, void* stream);
+
 /* Encoder self-attention on packed qkv [B][N][3E] ("b s (three h d)"), no mask -> out [B][N][E]
  * [nn/attention.py:112-136 MultiHeadAttention.forward]. */
 int eamrl_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H, void* stream);

@@ -561,3 +561,86 @@ def test_native_reevaluation_matches_autograd(cfg, env_name, N, B, ns, ms):
             assert rel <= 1e-4 * loose, (which, k, rel)
             scale = max(float(ref.abs().max()), 1e-2 * top)
             assert float((got - ref).abs().max()) <= 5e-4 * loose * scale, (which, k)
+
+
+@pytest.mark.parametrize("rows,E", [(37, 128), (129, 128), (5000, 128), (102400, 128), (300, 64)])
+def test_batchnorm_train_autograd_function_matches_torch(rows, E):
+    """train._BatchNormTrainFn (eamrl_batchnorm_train forward, eamrl_batchnorm_backward): value and all three gradients of
+    F.batch_norm(training=True) -- what the reference's Normalization("batch") runs under policy.train() (nn/ops.py:45-47)."""
+    import torch.nn.functional as F
+    from eam_rl4co_amd.train import _BatchNormTrainFn
+
+    g = torch.Generator(device=DEV).manual_seed(rows + E)
+    x = (torch.randn(rows, E, device=DEV, generator=g) * 1.7 + 0.3).requires_grad_()
+    w = (torch.rand(E, device=DEV, generator=g) + 0.5).requires_grad_()
+    b = torch.randn(E, device=DEV, generator=g).requires_grad_()
+    dy = torch.randn(rows, E, device=DEV, generator=g)
+    y = _BatchNormTrainFn.apply(x, w, b, 1e-5)
+    y.backward(dy)
+    got = [y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone()]
+    for t in (x, w, b):
+        t.grad = None
+    yr = F.batch_norm(x.double(), None, None, w.double(), b.double(), True, 0.0, 1e-5)
+    yr.backward(dy.double())
+    want = [yr.detach(), x.grad, w.grad, b.grad]
+    for name, a, r in zip(("y", "dx", "dgamma", "dbeta"), got, want):
+        scale = float(r.abs().max()) + 1e-12
+        assert float((a.double() - r.double()).abs().max()) <= 2e-5 * scale + 1e-6, name
+
+
+@pytest.mark.parametrize("rows,K,strided", [(1, 2, False), (100, 2, False), (513, 3, False), (102400, 2, False), (2000, 6, True),
+                                            (300, 4, False)])
+def test_init_embedding_linear_autograd_function_matches_torch(rows, K, strided):
+    """train._SmallLinearFn: the init embeddings' Linear(K -> 128) -- value = the rollout's tiny-K kernel, weight / bias gradient
+    = eamrl_small_linear_wgrad -- against torch's F.linear under autograd."""
+    import torch.nn.functional as F
+    from eam_rl4co_amd.train import _SmallLinearFn
+
+    g = torch.Generator(device=DEV).manual_seed(rows * 7 + K)
+    x = torch.rand(rows, K + (2 if strided else 0), device=DEV, generator=g)[:, :K]
+    w = (torch.randn(128, K, device=DEV, generator=g) * 0.5).requires_grad_()
+    b = torch.randn(128, device=DEV, generator=g).requires_grad_()
+    dy = torch.randn(rows, 128, device=DEV, generator=g)
+    y = _SmallLinearFn.apply(x, w, b)
+    y.backward(dy)
+    got = [y.detach(), w.grad.clone(), b.grad.clone()]
+    w.grad = b.grad = None
+    yr = F.linear(x.double(), w.double(), b.double())
+    yr.backward(dy.double())
+    for name, a, r in zip(("y", "dW", "db"), got, (yr.detach(), w.grad, b.grad)):
+        scale = float(r.abs().max()) + 1e-12
+        assert float((a.double() - r.double()).abs().max()) <= 2e-5 * scale, name
+
+
+def test_default_am_policy_trains_without_torch_norm_or_linear_kernels(monkeypatch):
+    """AttentionModelPolicy's default (batch normalisation) under policy.train(): the gradient graph's BatchNorm and init-embedding
+    Linears run on this library's kernels, and give the gradients of the torch ops they replace (EAMRL_TORCH_BATCHNORM=1 /
+    EAMRL_TORCH_INIT_EMBED=1) within 1e-3 norm-wise (two fp32 implementations of a backward through three batch norms over
+    120 rows; the gradient of a bias in front of a batch norm is a sum that cancels to rounding level).  The reference's own
+    gradients are matched to 1e-4 in test_reference_trainer_step_runs_on_the_policy_and_matches_reference_gradients."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import train
+
+    for env_name in ("tsp", "cvrp"):
+        env = ea.get_env(env_name, generator_params=dict(num_loc=20), seed=5)
+        torch.manual_seed(11)
+        td = env.reset(batch_size=[6]).to(DEV)
+        pol = make_policy("am_" + env_name).train()
+        g = torch.Generator().manual_seed(3)
+        M = td["locs"].shape[1]
+        noise = torch.empty(6, 2 * M + 1, M).exponential_(1, generator=g).to(DEV)
+        grads = []
+        for torch_ops in ("0", "1"):
+            monkeypatch.setenv("EAMRL_TORCH_BATCHNORM", torch_ops)
+            monkeypatch.setenv("EAMRL_TORCH_INIT_EMBED", torch_ops)
+            for p in pol.parameters():
+                p.grad = None
+            out = train.reinforce_loss(pol, env, td.clone(), baseline="no", noise=noise)
+            out["loss"].backward()
+            grads.append({k: (p.grad.clone() if p.grad is not None else None) for k, p in pol.named_parameters()})
+        top = max(float(g.norm()) for g in grads[1].values() if g is not None)
+        for k in grads[0]:
+            a, r = grads[0][k], grads[1][k]
+            assert (a is None) == (r is None), k
+            if a is not None:       # (biases in front of a batch norm have a gradient that is zero up to rounding: absolute floor)
+                assert float((a - r).norm()) <= 1e-3 * float(r.norm()) + 1e-5 * top, k
