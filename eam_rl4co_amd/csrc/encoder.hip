@@ -750,6 +750,9 @@ int launch_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, in
         hipLaunchKernelGGL(k_mha_encoder_x2, dim3((unsigned)(B * (H / 4))), dim3(256), lds2, st, qkv, out, N, E, H);
         return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
     }
+    // large graphs: the key-tiled fp32-MFMA kernel (encoder_attn_mfma.hip); debug key 15 keeps the VALU one for A/B runs
+    if (!g_debug[15] && !g_debug[3] && mha_encoder_mfma_supports(N, E, H) && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0)
+        return launch_mha_encoder_mfma(qkv, out, B, N, E, H, st);
     if (D == 16 && H % 4 == 0 && !g_debug[3] && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
         B * (H / 4) * ((N + 127) / 128) <= 0x7fffffffLL) {              // large graphs: keys tiled through LDS
         const unsigned nb = (unsigned)(B * (H / 4) * ((N + 127) / 128));
