@@ -82,6 +82,7 @@ PROTOTYPES = {
     "eamrl_matmul_right": [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "eamrl_linear_wgrad_scratch": [_i64, _i32, _i32],
     "eamrl_linear_wgrad": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
+    "eamrl_augment_xy": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp],
     "eamrl_small_linear_wgrad_scratch": [_i64, _i32],
     "eamrl_small_linear_wgrad": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
     "eamrl_batchnorm_backward_scratch": [_i64, _i32],

@@ -19,7 +19,7 @@ LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libeamrl_hip.so")
 
-SOURCES = ["abi.hip", "decode_step.hip", "rollout_resident.hip", "env_reward.hip", "encoder.hip", "evolution.hip", "evolution_prize.hip", "pointer.hip", "encoder_fused.hip", "reeval.hip", "rollout_multistart.hip", "train_gemm.hip", "train_norm.hip", "encoder_attn_mfma.hip"]
+SOURCES = ["abi.hip", "decode_step.hip", "rollout_resident.hip", "env_reward.hip", "encoder.hip", "evolution.hip", "evolution_prize.hip", "pointer.hip", "encoder_fused.hip", "reeval.hip", "rollout_multistart.hip", "train_gemm.hip", "train_norm.hip", "encoder_attn_mfma.hip", "augment.hip"]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -334,6 +334,14 @@ __attribute__((visibility("default"))) int eamrl_batchnorm_backward(const float*
                                               (hipStream_t)stream), "eamrl_batchnorm_backward");
 }
 
+__attribute__((visibility("default"))) int eamrl_augment_xy(const float* xy, const float* cs, const int32_t* code, float* out, int64_t R,
+                                                           int64_t B, int N, float offset, void* stream)
+{
+    REQUIRE(xy && code && out && R >= 0 && B > 0 && N > 0, "eamrl_augment_xy");
+    REQUIRE(((uintptr_t)xy % 8 == 0) && ((uintptr_t)out % 8 == 0), "eamrl_augment_xy");
+    return launched(launch_augment_xy(xy, cs, code, out, R, B, N, offset, (hipStream_t)stream), "eamrl_augment_xy");
+}
+
 static int check_encoder_fused(int64_t B, int M, int E, int H, int ff_hidden, int nlayers, int norm,
                                const eamrl_encoder_layer* layers, const eamrl_encoder_cache* cache, const char* what)
 {

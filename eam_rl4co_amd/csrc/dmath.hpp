@@ -56,9 +56,10 @@ __device__ __forceinline__ f32x2 d_expf2(f32x2 x)
     xc.x = xc.x > 88.0f ? 88.0f : xc.x;
     xc.y = xc.y > 88.0f ? 88.0f : xc.y;
     const f32x2 t = xc * splat2(1.44269504088896341f);
-    f32x2 n;
-    n.x = __builtin_rintf(t.x);
-    n.y = __builtin_rintf(t.y);
+    // n = rint(t) as (t + 1.5 * 2^23) - 1.5 * 2^23 (round to nearest even, exact for |t| < 2^22): two packed adds instead of two
+    // v_rndne + two v_cvt, and the sum's low mantissa bits ARE the integer -- (bits << 23) + 0x3F800000 == (n + 127) << 23
+    const f32x2 tm = t + splat2(12582912.0f);
+    const f32x2 n = tm - splat2(12582912.0f);
     f32x2 r = pk_fma(n, splat2(-0.693359375f), xc);
     r = pk_fma(n, splat2(2.12194440e-4f), r);
     f32x2 p = splat2(1.9875691500e-4f);
@@ -70,8 +71,8 @@ __device__ __forceinline__ f32x2 d_expf2(f32x2 x)
     const f32x2 r2 = r * r;
     const f32x2 y = pk_fma(p, r2, r) + splat2(1.0f);
     f32x2 sc;
-    sc.x = __uint_as_float((uint32_t)((int)n.x + 127) << 23);
-    sc.y = __uint_as_float((uint32_t)((int)n.y + 127) << 23);
+    sc.x = __uint_as_float((__float_as_uint(tm.x) << 23) + 0x3F800000u);
+    sc.y = __uint_as_float((__float_as_uint(tm.y) << 23) + 0x3F800000u);
     f32x2 res = y * sc;
     res.x = (x.x >= -87.0f) ? res.x : 0.0f;
     res.y = (x.y >= -87.0f) ? res.y : 0.0f;
@@ -87,9 +88,10 @@ __device__ __forceinline__ f32x2 d_expf2_nonpos(f32x2 x)
     xc.x = vmax_raw(x.x, -88.0f);                   // -inf / NaN -> -88; the result of that lane is replaced by 0 below
     xc.y = vmax_raw(x.y, -88.0f);
     const f32x2 t = xc * splat2(1.44269504088896341f);
-    f32x2 n;
-    n.x = __builtin_rintf(t.x);
-    n.y = __builtin_rintf(t.y);
+    // n = rint(t) as (t + 1.5 * 2^23) - 1.5 * 2^23 (round to nearest even, exact for |t| < 2^22): two packed adds instead of two
+    // v_rndne + two v_cvt, and the sum's low mantissa bits ARE the integer -- (bits << 23) + 0x3F800000 == (n + 127) << 23
+    const f32x2 tm = t + splat2(12582912.0f);
+    const f32x2 n = tm - splat2(12582912.0f);
     f32x2 r = pk_fma(n, splat2(-0.693359375f), xc);
     r = pk_fma(n, splat2(2.12194440e-4f), r);
     f32x2 p = splat2(1.9875691500e-4f);
@@ -101,8 +103,8 @@ __device__ __forceinline__ f32x2 d_expf2_nonpos(f32x2 x)
     const f32x2 r2 = r * r;
     const f32x2 y = pk_fma(p, r2, r) + splat2(1.0f);
     f32x2 sc;
-    sc.x = __uint_as_float((uint32_t)((int)n.x + 127) << 23);
-    sc.y = __uint_as_float((uint32_t)((int)n.y + 127) << 23);
+    sc.x = __uint_as_float((__float_as_uint(tm.x) << 23) + 0x3F800000u);
+    sc.y = __uint_as_float((__float_as_uint(tm.y) << 23) + 0x3F800000u);
     f32x2 res = y * sc;
     res.x = (x.x >= -87.0f) ? res.x : 0.0f;
     res.y = (x.y >= -87.0f) ? res.y : 0.0f;

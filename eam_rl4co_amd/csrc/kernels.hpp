@@ -38,6 +38,8 @@ int launch_batchnorm_train(float* x, int64_t rows, int E, const float* gamma, co
 int launch_pointer_attention(const float* q, const float* K, const float* V, const float* Lk, int64_t ld, const uint8_t* mask,
                              int mask_per_query, const float* Wout, const float* bout, float* logits, int64_t B, int L, int M,
                              int E, int H, int mask_inner, hipStream_t st);
+int launch_augment_xy(const float* xy, const float* cs, const int32_t* code, float* out, int64_t R, int64_t B, int N, float offset,
+                      hipStream_t st);
 bool mha_encoder_mfma_supports(int N, int E, int H);
 int launch_mha_encoder_mfma(const float* qkv, float* out, int64_t B, int N, int E, int H, hipStream_t st);
 bool encoder_fused_supports(int M, int E, int H, int FFdim, int nlayers);

@@ -147,6 +147,24 @@ def linear_wgrad(dy, x, need_bias=True):
     return dW, db
 
 
+def augment_xy(xy, code, cs=None, offset=0.5):
+    """Coordinates [B, N, 2] -> [R, N, 2] with row r = a * B + b the instance b transformed by code[r] (eamrl_augment_xy:
+    0..7 dihedral variants, 8 rotation by the angle with (cos, sin) = cs[r], 9 rotation + x <-> y)."""
+    lib = _lib.load()
+    _chk(xy, "xy", torch.float32)
+    B, N, two = xy.shape
+    if two != 2:
+        raise ValueError("augment_xy: coordinates must be [B, N, 2]")
+    _chk(code, "code", torch.int32)
+    R = code.shape[0]
+    if cs is not None:
+        _chk(cs, "cs", torch.float32, (R, 2))
+    out = torch.empty(R, N, 2, dtype=torch.float32, device=xy.device)
+    _lib.check(lib.eamrl_augment_xy(_ptr(xy), _ptr(cs), _ptr(code), _ptr(out), R, B, N, float(offset), _stream(xy)),
+               "eamrl_augment_xy")
+    return out
+
+
 def small_linear_wgrad(dy, x, need_bias=True):
     """dW [out, K] = dy^T x, db [out] for a Linear with K <= 8 inputs (eamrl_small_linear_wgrad); dy [..., out], x [..., K]."""
     lib = _lib.load()

@@ -173,6 +173,15 @@ int eamrl_batchnorm_backward(const float* x, const float* dy, const float* save_
                              float eps, int64_t rows, int E, float* dx, float* dgamma, float* dbeta, float* scratch,
                              int64_t scratch_floats, void* stream);
 
+/* Instance augmentation of coordinates for the evaluators  [data/transforms.py:16-90: dihedral_8_augmentation,
+ * symmetric_transform / symmetric_augmentation; tasks/eval.py:138-297]: out [R][N][2], row r = a * B + b is instance b of
+ * xy [B][N][2] (the "(a b)" batchify order) transformed by code[r]: 0..7 = the dihedral variant (x, y), (1-x, y), (x, 1-y),
+ * (1-x, 1-y), (y, x), (1-y, x), (y, 1-x), (1-y, 1-x); 8 = rotation about (offset, offset) by the angle whose (cos, sin) is
+ * cs[r][0..1]; 9 = that rotation followed by x <-> y.  cs may be NULL when no code is >= 8.  Separately rounded fp32
+ * products and sums (no fma), as the reference's tensor expressions evaluate them. */
+int eamrl_augment_xy(const float* xy, const float* cs, const int32_t* code, float* out, int64_t R, int64_t B, int N, float offset,
+                     void* stream);
+
 /* Encoder self-attention on packed qkv [B][N][3E] ("b s (three h d)"), no mask -> out [B][N][E]
  * [nn/attention.py:112-136 MultiHeadAttention.forward]. */
 int eamrl_mha_encoder(const float* qkv, float* out, int64_t B, int N, int E, int H, void* stream);

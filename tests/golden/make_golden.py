@@ -3,7 +3,7 @@
 
 Run only in the build container (the reference never travels to the GPU box):
 
-    python tests/golden/make_golden.py [extra | beam | filtering | sdvrp | pctsp | op | cvrptw | train | eval | inject]
+    python tests/golden/make_golden.py [extra | beam | filtering | sdvrp | pctsp | op | cvrptw | train | eval | inject | augment]
 
 (no argument: the first batch, TSP / CVRP / POMO; `extra`: larger graphs and decoding options; `beam`: beam search;
 `filtering`: top-k / top-p; `sdvrp`, `pctsp` (incl. SPCTSP), `op`, `cvrptw`: the sibling envs and their state_dict
@@ -513,6 +513,44 @@ def eval_batch():
                   data_seed=503, num_starts=20, num_augment=4)
 
 
+def augment_fixture():
+    """Twelfth batch (python make_golden.py augment): the reference's StateAugmentation itself (data/transforms.py:106-153) with
+    first_aug_identity=False -- the option whose save / restore indexes `[list(td.size()), 0]` -- and with the
+    default, on one TSP batch; the drawn angles are recorded."""
+    import math
+
+    import rl4co.data.transforms as ref_tf
+    from rl4co.data.transforms import StateAugmentation
+
+    env = TSPEnv(generator_params=gen_params("tsp", 20), seed=601)
+    torch.manual_seed(601)
+    td = env.reset(batch_size=[5])
+    fx = {"torch_version": np.array(torch.__version__), "locs": np_(td["locs"])}
+    for tag, kw in (("noident", dict(num_augment=4, first_aug_identity=False)), ("default", dict(num_augment=4)),
+                    ("dihedral8", dict(num_augment=8, augment_fn="dihedral8"))):
+        phis = []
+        orig = ref_tf.symmetric_augmentation
+
+        def rec(xy, num_augment=8, first_augment=False):
+            state = torch.get_rng_state()
+            phis.append(torch.rand(xy.shape[0]) * 4 * math.pi)
+            torch.set_rng_state(state)
+            return orig(xy, num_augment, first_augment)
+
+        ref_tf.symmetric_augmentation = rec
+        try:
+            torch.manual_seed(77)
+            out = StateAugmentation(**kw)(td.clone())
+        finally:
+            ref_tf.symmetric_augmentation = orig
+        fx[f"{tag}_locs"] = np_(out["locs"])
+        if phis:
+            fx[f"{tag}_phi"] = np_(phis[0])
+    path = os.path.join(HERE, "state_augmentation.npz")
+    np.savez_compressed(path, **fx)
+    print(f"state_augmentation -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def inject():
     """Eleventh batch (python make_golden.py inject): the reference's PointerAttention module (nn/attention.py:224-328) on
     recorded inputs -- what a `pointer=` replacement must reproduce."""
@@ -557,6 +595,8 @@ if __name__ == "__main__":
         eval_batch()
     elif len(sys.argv) > 1 and sys.argv[1] == "inject":
         inject()
+    elif len(sys.argv) > 1 and sys.argv[1] == "augment":
+        augment_fixture()
     elif len(sys.argv) > 1 and sys.argv[1] == "cvrptw":
         cvrptw()
     elif len(sys.argv) > 1 and sys.argv[1] == "op":

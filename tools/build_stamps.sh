@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_stamps
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -DEAMRL_STAMPS"
-for f in abi decode_step rollout_resident env_reward encoder evolution evolution_prize pointer encoder_fused reeval rollout_multistart train_gemm train_norm encoder_attn_mfma; do
+for f in abi decode_step rollout_resident env_reward encoder evolution evolution_prize pointer encoder_fused reeval rollout_multistart train_gemm train_norm encoder_attn_mfma augment; do
   /opt/rocm/bin/hipcc $FLAGS -c eam_rl4co_amd/csrc/$f.hip -o tools/_stamps/$f.o &
 done
 wait
