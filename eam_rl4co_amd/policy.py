@@ -781,19 +781,20 @@ class AttentionModelPolicy(nn.Module):
     def _attach_grad(self, out: dict, p: dict) -> dict:
         from .train import evaluate_log_likelihood
 
-        if p["S"] > 0 and p["select_best"]:
-            raise NotImplementedError("select_best=True under autograd: the reference's trainers select the best start "
-                                      "only outside training (reinforce.py:64)")
-        if p["top_k"] or p["top_p"]:
-            raise NotImplementedError("top-k / top-p filtering is not part of the differentiable re-evaluation")
+        # select_best (decoding.py:419-427): `final_actions` are then the B best rows, re-evaluated as single rows whose first
+        # column is the forced start node; top-k / top-p: the filtered entries are a fixed mask of the PyTorch re-evaluation
+        best = p["S"] > 0 and p["select_best"]
+        filtering = bool(p["top_k"]) or 0.0 < float(p["top_p"] or 0.0) < 1.0
         # the rollout's own per-step log-probs let the re-evaluation skip its forward pass (train.evaluate_log_likelihood)
         fl = p.get("final_logp")
-        if fl is not None and (fl.shape != p["final_actions"].shape or os.environ.get("EAMRL_REEVAL_FORWARD", "0") == "1"):
+        if fl is not None and (fl.shape != p["final_actions"].shape or os.environ.get("EAMRL_REEVAL_FORWARD", "0") == "1"
+                               or filtering or best):
             fl = None
         fh = p.get("final_heads") if fl is not None else None       # (heads are only used together with the rollout's log-probs)
-        re = evaluate_log_likelihood(self, p["td"], p["env"], p["final_actions"], num_starts=p["S"],
+        re = evaluate_log_likelihood(self, p["td"], p["env"], p["final_actions"], num_starts=0 if best else p["S"],
                                      multistart=bool(p["pre"]), temperature=p["temperature"],
-                                     tanh_clipping=p["tanh_clipping"], rollout_logp=fl, rollout_heads=fh)
+                                     tanh_clipping=p["tanh_clipping"], rollout_logp=fl, rollout_heads=fh,
+                                     top_k=int(p["top_k"] or 0), top_p=float(p["top_p"] or 0.0))
         td_mask = p["td"].get("mask", None) if hasattr(p["td"], "get") else None
         if td_mask is not None:
             re = re.masked_fill(~td_mask, 0)

@@ -496,7 +496,27 @@ def decoder_tensors(policy, td):
     return t
 
 
-def _logp_rows(env_name, t, static, act, nrep, multistart, H, temperature, clip):
+def _filter_logits_(logits, act, top_k: int, top_p: float):
+    """process_logits' top-k / top-p filtering (utils/decoding.py:111-137,170-176) as a fixed, non-differentiated choice of the
+    entries that stay: top-k keeps an entry iff fewer than k are strictly larger, top-p sorts ascending and drops the entries
+    whose cumulative probability stays <= 1 - top_p (DESIGN.md 2).  The chosen action always stays (it did in the rollout;
+    a last-bit difference between torch's sums and the rollout kernel's at the threshold must not turn its log-prob into -inf)."""
+    with torch.no_grad():
+        drop = torch.zeros_like(logits, dtype=torch.bool)
+        if top_k > 0:
+            k = min(int(top_k), logits.shape[-1])
+            kth = torch.topk(logits, k, dim=-1).values[..., -1:]
+            drop |= logits < kth
+        if 0.0 < top_p < 1.0:
+            x = logits.masked_fill(drop, float("-inf"))
+            srt, idx = torch.sort(x, dim=-1, descending=False, stable=True)
+            cum = torch.softmax(srt, dim=-1).cumsum(-1)
+            drop |= torch.zeros_like(drop).scatter_(-1, idx, cum <= (1.0 - top_p))
+        drop.scatter_(-1, act[..., None], False)
+    return logits.masked_fill(drop, float("-inf"))
+
+
+def _logp_rows(env_name, t, static, act, nrep, multistart, H, temperature, clip, top_k=0, top_p=0.0):
     """Per-step log-probabilities [Rc, T] of the rows `act` (nrep whole start groups of the B instances, (s b) order).
     `t`: decoder_tensors; `static`: the instance tensors the masks are rebuilt from."""
     emb, K, V, L = t["emb"], t["K"], t["V"], t["L"]
@@ -556,6 +576,8 @@ def _logp_rows(env_name, t, static, act, nrep, multistart, H, temperature, clip)
     if clip > 0:
         logits = torch.tanh(logits) * clip
     logits = logits.masked_fill(~mask, float("-inf")) / temperature
+    if top_k > 0 or 0.0 < top_p < 1.0:
+        logits = _filter_logits_(logits, act, top_k, top_p)
     logp = F.log_softmax(logits, dim=-1).gather(-1, act[..., None]).squeeze(-1)
     if multistart:   # the start node is not a decision (decoding.py:318-324)
         logp = torch.cat((torch.zeros_like(logp[:, :1]), logp[:, 1:]), 1)
@@ -712,7 +734,7 @@ def _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip, r
 
 def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, temperature=None, tanh_clipping=None,
                             chunk_rows: int = 4096, multistart=None, checkpoint=None, native=None, rollout_logp=None,
-                            rollout_heads=None):
+                            rollout_heads=None, top_k: int = 0, top_p: float = 0.0):
     """Differentiable per-step log-probabilities of `actions` [R, T] (R = B or S*B rows in (s b) order).  native
     (default: where supported -- TSP / CVRP / PCTSP / OP / CVRPTW, graphs up to 112 nodes): forward and backward of the
     decode steps run in the HIP re-evaluation kernels; otherwise (and as the cross-check) PyTorch autograd ops.  multistart
@@ -720,7 +742,9 @@ def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, tempe
     the multi-sample layout (every column a decision).  checkpoint (default: by size): keep no activations in the
     forward and recompute chunk by chunk in the backward.  rollout_logp [R, T] (native path only): the per-step log-probs
     the rollout kernel produced for exactly these actions with this policy -- the HIP forward pass is then skipped (the
-    returned values are these; the backward recovers each step's normaliser from them).  Returns logp [R, T]."""
+    returned values are these; the backward recovers each step's normaliser from them).  top_k / top_p: the rollout filtered
+    its logits (process_logits, decoding.py:170-176): the same entries are dropped here, as a fixed mask, before the
+    log-softmax (PyTorch path).  Returns logp [R, T]."""
     temperature = policy.temperature if temperature is None else temperature
     clip = policy.tanh_clipping if tanh_clipping is None else tanh_clipping
     H = policy.decoder.num_heads
@@ -732,9 +756,12 @@ def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, tempe
     if multistart is None:
         multistart = S > 1
     env_name = policy.env_name
+    filtering = top_k > 0 or 0.0 < top_p < 1.0
     if native is None:
-        native = native_reeval_supported(policy, M)
+        native = native_reeval_supported(policy, M) and not filtering
     if native:
+        if filtering:
+            raise ValueError("evaluate_log_likelihood: the native re-evaluation kernels do not filter (top_k / top_p)")
         return _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip, rollout_logp, rollout_heads)
     static = {k: td[k] for k in _STATE_KEYS[env_name]}
     # rows are processed in chunks of whole start-groups so that memory stays bounded ([rows, H, T, M] scores)
@@ -745,7 +772,7 @@ def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, tempe
     def chunk(c, *tensors):
         s0, s1 = bounds[c]
         return _logp_rows(env_name, dict(zip(names, tensors)), static, actions[s0 * B:s1 * B], s1 - s0, multistart, H,
-                          temperature, clip)
+                          temperature, clip, top_k, top_p)
 
     if checkpoint is None:      # ~6 live [rows, H, T, M] fp32 tensors per chunk if the graph is kept
         checkpoint = len(bounds) > 1 and 24.0 * R * H * T * M > 8e9
