@@ -2,7 +2,7 @@
 + AttentionModel decode) behind the RL4CO interfaces of Tarseus/eam-rl4co.  See DESIGN.md."""
 from .envs import (CVRPEnv, CVRPGenerator, CVRPTWEnv, CVRPTWGenerator, OPEnv, OPGenerator, PCTSPEnv, PCTSPGenerator, RL4COEnvBase, SDVRPEnv, SPCTSPEnv,  # noqa: F401
                    TSPEnv, TSPGenerator, get_env)  # noqa: F401
-from .policy import (AttentionModelDecoder, AttentionModelEncoder, AttentionModelPolicy, GraphedRollout,  # noqa: F401
+from .policy import (AttentionModelDecoder, AttentionModelEncoder, AttentionModelPolicy, GraphedRollout, SymNCOPolicy,  # noqa: F401
                      load_reference_checkpoint, random_policy, rollout)
 from .attention import PointerAttention, scaled_dot_product_attention  # noqa: F401
 from .evolution import EA, EACvrpDraws, EAPrizeDraws, EADraws, evolution_worker, generate_batch_population  # noqa: F401

@@ -1255,6 +1255,47 @@ def random_policy(td):
     return td
 
 
+class SymNCOPolicy(AttentionModelPolicy):
+    """AttentionModelPolicy + the projection head of SymNCO (rl4co/models/zoo/symnco/policy.py:13-96): `forward` also returns
+    `proj_embeddings = projection_head(init_embeds)`, which the invariance loss of SymNCO / SymEAM compares across the
+    augmented copies of an instance (zoo/symnco/losses.py:31-39, zoo/earl/model.py:471-712).  The head is torchrl's
+    `MLP(E, E, depth 1, E, ReLU)` = Linear, ReLU, Linear with state_dict keys `projection_head.{0,2}.{weight,bias}`.
+
+    Under autograd (phase "train") the init embeddings handed to the head are the differentiable ones (the tiny-K Linear of
+    the training graph, train._small_linear -- same values as the rollout's, bit for bit), so the invariance loss reaches
+    the init-embedding weights as it does in the reference."""
+
+    def __init__(self, embed_dim: int = 128, env_name: str = "tsp", num_encoder_layers: int = 3, num_heads: int = 8,
+                 normalization: str = "batch", projection_head: nn.Module = None, use_projection_head: bool = True, **kwargs):
+        super().__init__(env_name=env_name, embed_dim=embed_dim, num_encoder_layers=num_encoder_layers, num_heads=num_heads,
+                         normalization=normalization, **kwargs)
+        self.use_projection_head = use_projection_head
+        if use_projection_head:
+            self.projection_head = projection_head if projection_head is not None else nn.Sequential(
+                nn.Linear(embed_dim, embed_dim), nn.ReLU(), nn.Linear(embed_dim, embed_dim))
+
+    def forward(self, td, env=None, phase: str = "train", return_actions: bool = True, return_init_embeds: bool = True, **kwargs):
+        assert not (self.use_projection_head and not return_init_embeds), \
+            "If `use_projection_head` is True, then we must `return_init_embeds`"
+        out = super().forward(td, env, phase, return_actions=return_actions, return_init_embeds=return_init_embeds, **kwargs)
+        if self.use_projection_head:
+            init = out["init_embeds"]
+            if torch.is_grad_enabled() and phase == "train" and not torch.is_inference_mode_enabled():
+                from .train import init_embedding_autograd
+
+                init = init_embedding_autograd(self, td)
+                out = dict(out)
+                out["init_embeds"] = init
+            head = self.projection_head
+            if isinstance(head, nn.Sequential) and len(head) == 3 and isinstance(head[0], nn.Linear) and isinstance(head[2], nn.Linear):
+                from .train import _linear
+
+                out["proj_embeddings"] = _linear(_linear(init, head[0].weight, head[0].bias, relu=True), head[2].weight, head[2].bias)
+            else:
+                out["proj_embeddings"] = head(init)
+        return out
+
+
 class GraphedRollout:
     """`policy(td, env, **kwargs)` for a fixed batch shape, captured once into a HIP graph and replayed.
 

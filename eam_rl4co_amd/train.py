@@ -206,7 +206,8 @@ def _normalize(norm: nn.Module, x: torch.Tensor, training: bool) -> torch.Tensor
     return F.instance_norm(x.permute(0, 2, 1), weight=n.weight, bias=n.bias, eps=n.eps).permute(0, 2, 1)
 
 
-def encode_autograd(policy, td):
+def init_embedding_autograd(policy, td):
+    """The init embedding of the training graph [B, M, E] (differentiable w.r.t. the init-embedding weights)."""
     enc = policy.encoder
     ie = enc.init_embedding
     locs = td["locs"]
@@ -234,6 +235,12 @@ def encode_autograd(policy, td):
         with torch.no_grad():
             h_native = ie(td)
         h = h_native + (h - h.detach())
+    return h
+
+
+def encode_autograd(policy, td):
+    enc = policy.encoder
+    h = init_embedding_autograd(policy, td)
     training = policy.training
     for layer in enc.net.layers:
         mha, ffn = layer[0].module, layer[2].module
@@ -865,6 +872,69 @@ def _eam_loss(policy, env, td, ea, S, improve, draws, generator, return_entropy=
     r_all, ll_all = torch.cat(rs, 0), torch.cat(lls, 0)              # [B or 2B, S]
     adv = r_all - r_all.mean(1, keepdim=True)
     res["loss"] = -(adv * ll_all).mean()
+    return res
+
+
+def problem_symmetricity_loss(reward, log_likelihood, dim=1):
+    """zoo/symnco/losses.py:5-15: REINFORCE with the mean over `dim` as baseline (0 when that axis has fewer than 2 entries)."""
+    if reward.shape[dim] < 2:
+        return 0
+    return (-(reward - reward.mean(dim=dim, keepdim=True)) * log_likelihood).mean()
+
+
+def solution_symmetricity_loss(reward, log_likelihood, dim=-1):
+    """zoo/symnco/losses.py:18-28: the same over the last axis."""
+    return problem_symmetricity_loss(reward, log_likelihood, dim)
+
+
+def invariance_loss(proj_embed, num_augment):
+    """zoo/symnco/losses.py:31-39: mean cosine similarity between the projected embeddings of an instance's first copy and its
+    other copies -- with the reference's own grouping "(b a) ... -> b a ..." of the rows."""
+    pe = proj_embed.reshape(proj_embed.shape[0] // num_augment, num_augment, *proj_embed.shape[1:])
+    sim = sum(F.cosine_similarity(pe[:, 0], pe[:, i], dim=-1) for i in range(1, num_augment))
+    return sim.mean()
+
+
+def symeam_loss(policy, env, td, ea, num_augment: int = 4, num_starts: int = 0, alpha: float = 0.2, beta: float = 1.0,
+                improve: bool = True, augment=None, draws=None, generator=None):
+    """The training branch of `SymEAM.shared_step`, the fork's second trainer (rl4co/models/zoo/earl/model.py:535-660), on a
+    `SymNCOPolicy`: symmetric augmentation of the batch (num_augment copies) -> sampled rollout with entropy -> (with
+    probability `improve_prob`, decided by the caller: `improve`) evolutionary improvement of the sampled tours and their
+    teacher-forced evaluation -> loss = L_ps + beta L_ss + alpha L_inv over [original; improved] (zoo/symnco/losses.py).
+    The reference's expressions are kept as written, including which loss is switched by which count (`loss_ps` needs
+    num_starts > 1, `loss_ss` num_augment > 1) and the row grouping of the invariance loss.  num_starts > 1: the improved
+    tours get their start column back before the evaluation, as in `eam_loss`.
+    Returns dict(loss, loss_ps, loss_ss, loss_inv, reward, log_likelihood, actions[, improved_*])."""
+    from .evolution import evolution_worker
+    from .utils import StateAugmentation
+
+    n_aug, n_start = int(num_augment), int(num_starts)
+    if n_aug > 1:
+        td = (augment or StateAugmentation(num_augment=n_aug))(td)
+    init_td = td.clone()
+    kw = dict(num_starts=n_start) if n_start > 1 else {}
+    with torch.enable_grad():
+        out = policy(td, env, phase="train", return_entropy=True, **kw)
+    res = {"reward": out["reward"], "log_likelihood": out["log_likelihood"], "actions": out["actions"], "entropy": out.get("entropy")}
+    rs, lls, projs = [unbatchify(out["reward"], (n_aug, n_start))], [unbatchify(out["log_likelihood"], (n_aug, n_start))], \
+        [out["proj_embeddings"]]
+    if improve:
+        with torch.no_grad():
+            improved, _ = evolution_worker(out["actions"], init_td, ea, env, draws=draws, generator=generator)
+            if improved is not None and improved.shape[-1] + 1 == out["actions"].shape[-1]:
+                improved = torch.cat([out["actions"][:, :1], improved], dim=-1)
+        if improved is not None:
+            with torch.enable_grad():
+                out2 = policy(init_td, env, phase="train", actions=improved.to(out["actions"].device), **kw)
+            rs.append(unbatchify(out2["reward"], (n_aug, n_start)))
+            lls.append(unbatchify(out2["log_likelihood"], (n_aug, n_start)))
+            projs.append(out2["proj_embeddings"])
+            res.update(improved_actions=improved, improved_reward=out2["reward"], improved_log_likelihood=out2["log_likelihood"])
+    reward, ll, proj = torch.cat(rs, 0), torch.cat(lls, 0), torch.cat(projs, 0)
+    loss_ps = problem_symmetricity_loss(reward, ll) if n_start > 1 else 0
+    loss_ss = solution_symmetricity_loss(reward, ll) if n_aug > 1 else 0
+    loss_inv = invariance_loss(proj, n_aug) if n_aug > 1 else 0
+    res.update(loss=loss_ps + beta * loss_ss + alpha * loss_inv, loss_ps=loss_ps, loss_ss=loss_ss, loss_inv=loss_inv)
     return res
 
 

@@ -6,6 +6,7 @@ reference's trainers run on it unchanged.  The tests restate `REINFORCE.calculat
 for line around the policy call, backpropagate, and compare with gradients recorded from the reference itself
 (`tests/golden/make_golden.py train`: the reference policy in train() mode, sampling with recorded noise).
 """
+import math
 import os
 
 import numpy as np
@@ -682,3 +683,81 @@ def test_gradients_through_filtering_and_select_best(env_name, kw):
         assert (a is None) == (b is None)
         if a is not None:
             assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-6 * top
+
+
+@pytest.mark.parametrize("env_name,S", [("tsp", 0), ("cvrp", 0), ("tsp", 6)])
+def test_symeam_shared_step_restated_runs_on_the_policy(env_name, S):
+    """SymEAM.shared_step's training branch (zoo/earl/model.py:535-660; the fork's second trainer) restated line by line around
+    SymNCOPolicy, StateAugmentation and evolution_worker, with SymNCO's three losses written out (zoo/symnco/losses.py) -- and
+    train.symeam_loss gives the same loss and gradients for the same angles, noise and evolution draws.  (No fixture from the
+    reference: its SymNCOPolicy needs torchrl's MLP, absent here -- parity of this trainer step is unpinned beyond the pieces
+    it is built from, which are pinned.)"""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import train
+    from eam_rl4co_amd.utils import StateAugmentation
+
+    B, A, N = 4, 4, 20
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=12)
+    torch.manual_seed(12)
+    td0 = env.reset(batch_size=[B]).to(DEV)
+    pol = ea.SymNCOPolicy(env_name=env_name).to(DEV).train()
+    sd = pol.state_dict()
+    for k, v in golden_weights("am_" + env_name).items():
+        sd[k].copy_(torch.from_numpy(v))
+    runner = ea.EA(env, dict(num_generations=2, mutation_rate=0.3, crossover_rate=0.8, selection_rate=0.6))
+    phi = torch.rand(A * B, generator=torch.Generator().manual_seed(4)) * 4 * math.pi
+    aug = StateAugmentation(num_augment=A, phi=phi)
+    M = td0["locs"].shape[1]
+    noise = torch.empty(A * B * max(S, 1), 3 * M + 1, M, device=DEV).exponential_(1)
+    orig_forward = pol.forward
+
+    def with_noise(td_, env_=None, **kw):            # both versions sample with the recorded noise
+        if kw.get("actions") is None:
+            kw["noise"] = noise
+        return orig_forward(td_, env_, **kw)
+
+    pol.forward = with_noise
+    try:
+        # ---- the reference's lines -----------------------------------------------------------------------------------
+        td = aug(td0.clone())
+        init_td = td.clone()
+        kw = dict(num_starts=S) if S > 1 else {}
+        original_out = pol(td, env, phase="train", return_entropy=True, **kw)
+        assert original_out["proj_embeddings"].requires_grad and original_out["proj_embeddings"].shape == (A * B, M, 128)
+        gen = torch.Generator(device=DEV).manual_seed(9)
+        improved_actions, _ = ea.evolution_worker(original_out["actions"], init_td, runner, env, generator=gen)
+        if improved_actions.shape[-1] + 1 == original_out["actions"].shape[-1]:
+            improved_actions = torch.cat([original_out["actions"][:, :1], improved_actions], -1)
+        improved_out = pol(init_td, env, phase="train", actions=improved_actions, **kw)
+        reward = torch.cat([ea.unbatchify(original_out["reward"], (A, S)), ea.unbatchify(improved_out["reward"], (A, S))], 0)
+        ll = torch.cat([ea.unbatchify(original_out["log_likelihood"], (A, S)),
+                        ea.unbatchify(improved_out["log_likelihood"], (A, S))], 0)
+        proj = torch.cat([original_out["proj_embeddings"], improved_out["proj_embeddings"]], 0)
+
+        def reinforce(r, l, dim):
+            return (-(r - r.mean(dim=dim, keepdim=True)) * l).mean() if r.shape[dim] >= 2 else 0
+
+        loss_ps = reinforce(reward, ll, 1) if S > 1 else 0
+        loss_ss = reinforce(reward, ll, -1) if A > 1 else 0
+        pe = proj.reshape(proj.shape[0] // A, A, *proj.shape[1:])
+        loss_inv = sum(F.cosine_similarity(pe[:, 0], pe[:, i], dim=-1) for i in range(1, A)).mean()
+        loss = loss_ps + 1.0 * loss_ss + 0.2 * loss_inv
+        pol.zero_grad()
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in pol.named_parameters() if p.grad is not None}
+        assert all(torch.isfinite(g).all() for g in grads.values())
+        assert float(grads["projection_head.2.weight"].norm()) > 0 and float(grads["encoder.init_embedding.init_embed.weight"].norm()) > 0
+        # ---- the packaged step -----------------------------------------------------------------------------------------
+        pol.zero_grad()
+        gen = torch.Generator(device=DEV).manual_seed(9)
+        res = train.symeam_loss(pol, env, td0.clone(), runner, num_augment=A, num_starts=S, augment=aug, generator=gen)
+    finally:
+        pol.forward = orig_forward
+    assert torch.equal(res["improved_actions"], improved_actions)
+    np.testing.assert_allclose(float(res["loss"].detach()), float(loss.detach()), rtol=1e-5)
+    res["loss"].backward()
+    gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
+    for k, p_ in pol.named_parameters():
+        if k in grads:
+            rel = float((p_.grad.double() - grads[k].double()).norm()) / max(float(grads[k].double().norm()), 1e-2 * gnorm)
+            assert rel <= 1e-4, (k, rel)
