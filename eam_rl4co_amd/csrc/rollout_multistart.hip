@@ -117,12 +117,17 @@ __device__ __forceinline__ int half_min(int v)
 // CC: the node-chunk length ceil(M / 4) as a compile-time value (0: run time).  With it every "does k-step t touch chunk g"
 // decision folds away; left to run time the ~100 uniform conditions are hoisted out of the loops into SGPRs that spill
 // (measured: 256 VGPRs + scratch vs 167 VGPRs), so the common sizes get their own instantiation.
-// ENV: EAMRL_ENV_TSP or EAMRL_ENV_CVRP (state machine of the starts: bit-set masks either way; CVRP adds the visited set, the
+// ENV: EAMRL_ENV_TSP, _CVRP, and (round 3) _CVRPTW, _PCTSP, _OP (state machine of the starts: bit-set masks either way; the depot envs add the visited set, the
 // load of the vehicle and the per-step mask recomputation, cvrp/env.py:68-144).
 template <int RTT, int CC, int ENV>
 __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, int nsplit)
 {
-    constexpr bool CV = ENV == EAMRL_ENV_CVRP;
+    constexpr bool TW = ENV == EAMRL_ENV_CVRPTW;        // CVRP + clock and time windows
+    constexpr bool CV = ENV == EAMRL_ENV_CVRP || TW;    // vehicle load against the demands
+    constexpr bool PC = ENV == EAMRL_ENV_PCTSP;         // prize collecting: used = collected prize, cap = required prize
+    constexpr bool OP = ENV == EAMRL_ENV_OP;            // orienteering: used = tour length, s_dem = arrival limit per node
+    constexpr bool DEP = ENV != EAMRL_ENV_TSP;          // depot envs: visited set, half-wavefront transition
+    constexpr bool XY = OP || TW;                       // the transition needs distances
     __shared__ __attribute__((aligned(16))) float QT[16 * TS];
     __shared__ __attribute__((aligned(16))) float HT[16 * TS];
     constexpr int US = 16 * RTT + 4;                                // row stride of UT (16-byte aligned rows)
@@ -130,8 +135,12 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
     __shared__ float LPSEL[16];                                     // log-prob of each query's pick
     __shared__ __attribute__((aligned(16))) uint32_t s_bits[SMAX][4];
     __shared__ int s_cur[SMAX], s_first[SMAX], s_istep[SMAX], s_cnt[SMAX], s_done[SMAX];
-    __shared__ __attribute__((aligned(16))) uint32_t s_vis[CV ? SMAX : 1][4];       // CVRP: visited nodes (depot = bit 0)
-    __shared__ float s_used[CV ? SMAX : 1], s_cap[CV ? SMAX : 1], s_dem[CV ? 128 : 1];   // load, capacity; demand of node n
+    __shared__ __attribute__((aligned(16))) uint32_t s_vis[DEP ? SMAX : 1][4];      // depot envs: visited nodes (depot = bit 0)
+    __shared__ float s_used[DEP ? SMAX : 1], s_cap[DEP ? SMAX : 1], s_dem[DEP ? 128 : 1];  // load / prize / length, its bound; per-node
+                                                                                           // demand (CVRP), prize (PCTSP), arrival limit (OP)
+    __shared__ float s_time[TW ? SMAX : 1];                                          // CVRPTW: clock of each start
+    __shared__ int s_i0[(PC || OP) ? SMAX : 1];                                      // PCTSP / OP: the step counter the launch started from
+    __shared__ float s_xy[XY ? 256 : 2], s_tw0[TW ? 128 : 1], s_tw1[TW ? 128 : 1], s_dur[TW ? 128 : 1];   // coordinates, windows, service
     __shared__ uint32_t s_flags;
     extern __shared__ __attribute__((aligned(16))) float LPF[];    // [RTT waves][32 k-steps][64 lanes]: the logit-key (Lp) A fragments
                                                                     // (kept in LDS, lane-linear: 32 VGPRs fewer per wave)
@@ -191,14 +200,16 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
             if (a.mask[r * M + n]) { w[n >> 5] |= 1u << (n & 31); ++cnt; }
         s_bits[s][0] = w[0]; s_bits[s][1] = w[1]; s_bits[s][2] = w[2]; s_bits[s][3] = w[3];
         s_cur[s] = (int)a.cur[r];
-        if (CV) {
+        if (DEP) {
             uint32_t v[4] = {0, 0, 0, 0};
-            cnt = 0;                                   // CVRP: nodes visited so far (the episode ends at M, depot included)
-            for (int n = 0; n < M; ++n)
-                if (a.visited[r * M + n]) { v[n >> 5] |= 1u << (n & 31); ++cnt; }
+            cnt = 0;                                   // CVRP: nodes visited so far (the episode ends at M, depot included);
+            for (int n = 0; n < M; ++n)                // PCTSP: customers visited so far
+                if (a.visited[r * M + n]) { v[n >> 5] |= 1u << (n & 31); if (!(PC && n == 0)) ++cnt; }
             s_vis[s][0] = v[0]; s_vis[s][1] = v[1]; s_vis[s][2] = v[2]; s_vis[s][3] = v[3];
             s_used[s] = a.used[r];
             s_cap[s] = a.vcap[r];
+            if (TW) s_time[s] = a.time[r];
+            if (PC || OP) { s_istep[s] = (int)a.istep[r]; s_i0[s] = (int)a.istep[r]; }
         } else {
             s_first[s] = (int)a.first[r];
             s_istep[s] = (int)a.istep[r];
@@ -206,8 +217,17 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
         s_cnt[s] = cnt;
         s_done[s] = a.done[r] != 0;
     }
-    if (CV)
-        for (int n = tid; n < 128; n += blockDim.x) s_dem[n] = (n >= 1 && n < M) ? a.demand[b * (M - 1) + n - 1] : 0.0f;
+    if (DEP)
+        for (int n = tid; n < 128; n += blockDim.x) {
+            if (CV) s_dem[n] = (n >= 1 && n < M) ? a.demand[b * (M - 1) + n - 1] : 0.0f;     // demand of customer n
+            else s_dem[n] = n < M ? a.demand[b * M + n] : 0.0f;                                // prize / arrival limit of node n
+            if (XY) { s_xy[2 * n] = n < M ? a.locs[(b * M + n) * 2] : 0.0f; s_xy[2 * n + 1] = n < M ? a.locs[(b * M + n) * 2 + 1] : 0.0f; }
+            if (TW) {
+                s_tw0[n] = n < M ? a.tw[(b * M + n) * 2] : 0.0f;
+                s_tw1[n] = n < M ? a.tw[(b * M + n) * 2 + 1] : 0.0f;
+                s_dur[n] = n < M ? a.dur[b * M + n] : 0.0f;
+            }
+        }
     if (tid == 0) s_flags = 0;
     __syncthreads();
 
@@ -221,12 +241,19 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
         if (s < S && !s_done[s]) {
             float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.gctx) g4 = *reinterpret_cast<const float4*>(a.gctx + b * ME + 4 * e4);
-            if (CV) {               // VRPContext: fma(capacity column, free capacity, Pa[current]) + graph context
+            if (DEP) {              // EnvContext: fma(state column, state scalar, Pa[current]) + graph context -- free capacity (VRPContext),
+                                    // prize still to collect clamped at 0 (PCTSPContext), length still allowed (OPContext); CVRPTW: + the clock column
                 const float4 c4 = *reinterpret_cast<const float4*>(a.cvec + 4 * e4);
                 const float4 p = *reinterpret_cast<const float4*>(a.Pa + (b * M + s_cur[s]) * ld + 4 * e4);
-                const float fr = s_cap[s] - s_used[s];
-                v = make_float4(fma_(c4.x, fr, p.x) + g4.x, fma_(c4.y, fr, p.y) + g4.y, fma_(c4.z, fr, p.z) + g4.z,
-                                fma_(c4.w, fr, p.w) + g4.w);
+                float fr = s_cap[s] - s_used[s];
+                if (PC) fr = fr < 0.0f ? 0.0f : fr;
+                float4 y = make_float4(fma_(c4.x, fr, p.x), fma_(c4.y, fr, p.y), fma_(c4.z, fr, p.z), fma_(c4.w, fr, p.w));
+                if (TW) {
+                    const float4 c2 = *reinterpret_cast<const float4*>(a.cvec + ME + 4 * e4);
+                    const float now = s_time[s];
+                    y = make_float4(fma_(c2.x, now, y.x), fma_(c2.y, now, y.y), fma_(c2.z, now, y.z), fma_(c2.w, now, y.w));
+                }
+                v = make_float4(y.x + g4.x, y.y + g4.y, y.z + g4.z, y.w + g4.w);
             } else if (s_istep[s] == 0) {
                 const float4 c4 = *reinterpret_cast<const float4*>(a.cvec + 4 * e4);
                 v = make_float4(c4.x + g4.x, c4.y + g4.y, c4.z + g4.z, c4.w + g4.w);
@@ -498,7 +525,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 __builtin_amdgcn_wave_barrier();        // LPSEL is read by lanes of the same wavefront: LDS keeps its accesses in order
                 MSTAMP(12);
                 // ---- env transition (TSPEnv._step, tsp/env.py:62-88): lane 0 of the half-wavefront ---------------------------------
-                if (!CV && l32 == 0 && live2) {
+                if (!DEP && l32 == 0 && live2) {
                     const int s = s2, sl = sel;
                     a.action[r2 * a.t_max + t] = sl;
                     a.logp[r2 * a.t_max + t] = LPSEL[jq2];
@@ -512,9 +539,10 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                     s_cnt[s] -= (wd & bit) != 0;
                     s_done[s] = s_cnt[s] == 0;
                 }
-                // ---- CVRP: CVRPEnv._step + get_action_mask (cvrp/env.py:68-100,132-144): every lane of the half-wavefront knows the
-                // pick, lane l tests nodes l, l + 32, l + 64, l + 96, the ballots are the new mask words ------------------------------
-                if (CV && live2) {
+                // ---- depot envs: the env's _step + get_action_mask (cvrp/env.py:68-144, cvrptw/env.py:103-138, pctsp/env.py:64-97,156-163,
+                // op/env.py:69-102,149-165; the expressions of k_rollout_resident's finish): every lane of the half-wavefront knows the
+                // pick, lane l tests nodes l, l + 32, l + 64, l + 96, the ballots are the new mask words ----------------------------------
+                if (DEP && live2) {
                     const int s = s2, sl = sel, hw = lane >> 5;
                     const float lpv = LPSEL[jq2];
                     const uint4 ob = mb2;
@@ -525,21 +553,76 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                     const uint32_t vword = wi == 0 ? vw.x : wi == 1 ? vw.y : wi == 2 ? vw.z : vw.w;
                     const bool was_vis = (vword & bit) != 0;
                     if (wi == 0) vw.x |= bit; else if (wi == 1) vw.y |= bit; else if (wi == 2) vw.z |= bit; else vw.w |= bit;
-                    int di = sl - 1;
-                    di = di < 0 ? 0 : (di > M - 2 ? M - 2 : di);
-                    const float u = (s_used[s] + s_dem[di + 1]) * (sl != 0 ? 1.0f : 0.0f);
+                    const int curn = s_cur[s];
+                    float u = s_used[s], now = 0.0f, cx = 0.0f, cy = 0.0f;
+                    int cnt = s_cnt[s], ist = 0;
+                    bool done_new;
+                    if (XY) { cx = s_xy[2 * sl]; cy = s_xy[2 * sl + 1]; }
+                    if (OP) {
+                        ist = s_istep[s];
+                        const float dx = cx - s_xy[2 * curn], dy = cy - s_xy[2 * curn + 1];
+                        u = u + __builtin_sqrtf(fma_(dy, dy, dx * dx));
+                        done_new = (sl == 0) && (ist > 0);
+                    } else if (PC) {
+                        ist = s_istep[s];
+                        u = u + s_dem[sl];
+                        done_new = (ist > 0) && (sl == 0);
+                        cnt += (sl != 0 && !was_vis);
+                    } else {
+                        if (TW) {       // clock (cvrptw/env.py:118-138)
+                            now = s_time[s];
+                            const float dx = s_xy[2 * curn] - cx, dy = s_xy[2 * curn + 1] - cy;
+                            const float arrive = now + __builtin_sqrtf(fma_(dy, dy, dx * dx));
+                            const float ws = s_tw0[sl];
+                            const float start = arrive > ws ? arrive : ws;
+                            now = (sl != 0 ? 1.0f : 0.0f) * (start + s_dur[sl]);
+                        }
+                        int di = sl - 1;
+                        di = di < 0 ? 0 : (di > M - 2 ? M - 2 : di);
+                        u = (u + s_dem[di + 1]) * (sl != 0 ? 1.0f : 0.0f);
+                        cnt += was_vis ? 0 : 1;
+                        done_new = cnt == M;
+                    }
+                    const bool v0 = (vw.x & 1u) != 0;               // the depot has been visited (after this step)
                     const float lim = s_cap[s] + 1e-5f;
-                    uint32_t nb[4];
+                    uint32_t nb[4], fr = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int n = 32 * k + l32;
                         const uint32_t vk = k == 0 ? vw.x : k == 1 ? vw.y : k == 2 ? vw.z : vw.w;
-                        const bool ok = n >= 1 && n < M && !((vk >> l32) & 1u) && !((s_dem[n] + u) > lim);
-                        const unsigned long long bl = __ballot(ok);
-                        nb[k] = (uint32_t)(bl >> (32 * hw));
+                        const bool vis_n = (vk >> l32) & 1u;
+                        const bool cust = n >= 1 && n < M;
+                        bool ok, freeb = false;
+                        if (PC) {
+                            ok = cust && !(vis_n | v0);
+                        } else if (OP) {
+                            const float dx = s_xy[2 * n] - cx, dy = s_xy[2 * n + 1] - cy;
+                            const bool exceeds = (u + __builtin_sqrtf(fma_(dy, dy, dx * dx))) > s_dem[n];
+                            ok = cust && !(vis_n | v0 | exceeds);
+                        } else {
+                            freeb = cust && !(vis_n | ((s_dem[n] + u) > lim));
+                            ok = freeb;
+                            if (TW) {
+                                const float dx = cx - s_xy[2 * n], dy = cy - s_xy[2 * n + 1];
+                                ok = ok && (now + __builtin_sqrtf(fma_(dy, dy, dx * dx))) <= s_tw1[n];
+                            }
+                        }
+                        nb[k] = (uint32_t)(__ballot(ok) >> (32 * hw));
+                        if (CV) fr |= (uint32_t)(__ballot(freeb) >> (32 * hw));
                     }
-                    const bool any_free = (nb[0] | nb[1] | nb[2] | nb[3]) != 0u;
-                    if (!((sl == 0) && any_free)) nb[0] |= 1u;          // the depot: closed only while at it with customers left
+                    // the depot's bit
+                    if (PC) {
+                        if (!((u < 1.0f) && (cnt < M - 1))) nb[0] |= 1u;     // opens once the prize is collected (or everyone visited)
+                    } else if (OP) {
+                        nb[0] |= 1u;                                          // always feasible (and ends the episode)
+                    } else {
+                        bool ok0 = !((sl == 0) && fr != 0u);                  // closed only while at it with customers left
+                        if (TW) {
+                            const float dx = cx - s_xy[0], dy = cy - s_xy[1];
+                            ok0 = ok0 && (now + __builtin_sqrtf(fma_(dy, dy, dx * dx))) <= s_tw1[0];
+                        }
+                        if (ok0) nb[0] |= 1u;
+                    }
                     if (l32 == 0) {
                         a.action[r2 * a.t_max + t] = sl;
                         a.logp[r2 * a.t_max + t] = lpv;
@@ -548,9 +631,10 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                         *reinterpret_cast<uint4*>(&s_vis[s][0]) = vw;
                         s_used[s] = u;
                         s_cur[s] = sl;
-                        const int cnt = s_cnt[s] + (was_vis ? 0 : 1);
                         s_cnt[s] = cnt;
-                        s_done[s] = cnt == M;
+                        s_done[s] = done_new;
+                        if (TW) s_time[s] = now;
+                        if (PC || OP) s_istep[s] = ist + 1;
                     }
                 }
             }
@@ -581,9 +665,11 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
         const int64_t r = (int64_t)s * a.B + b;
         for (int n = 0; n < M; ++n) a.mask[r * M + n] = (s_bits[s][n >> 5] >> (n & 31)) & 1u;
         a.cur[r] = s_cur[s];
-        if (CV) {
+        if (DEP) {
             for (int n = 0; n < M; ++n) a.visited[r * M + n] = (s_vis[s][n >> 5] >> (n & 31)) & 1u;
             a.used[r] = s_used[s];
+            if (TW) a.time[r] = s_time[s];
+            if (PC || OP) a.istep[r] = s_i0[s];         // launch_rollout_pad adds the batch's step count
         } else {
             a.first[r] = s_first[s];
             a.istep[r] = s_istep[s];
@@ -618,9 +704,16 @@ int launch_t(const DecArgs& a, int S, hipStream_t st)
 template <int ENV>
 int launch_env_t(const DecArgs& a, int S, int C, hipStream_t st)
 {
-    if (a.M <= 32) return C == 5 ? launch_t<2, 5, ENV>(a, S, st) : C == 6 ? launch_t<2, 6, ENV>(a, S, st) : launch_t<2, 0, ENV>(a, S, st);
+    // compile-time chunk lengths for the common sizes: TSP-20 / 50 / 100 (C = 5, 13, 25) and the depot envs' 21 / 51 / 101 nodes
+    // (C = 6, 13, 26); everything else runs the run-time variant
+    constexpr bool T = ENV == EAMRL_ENV_TSP || ENV == EAMRL_ENV_CVRP;       // (the sibling envs: fewer instantiations)
+    if (a.M <= 32) {
+        if (T && C == 5) return launch_t<2, T ? 5 : 6, ENV>(a, S, st);
+        return C == 6 ? launch_t<2, 6, ENV>(a, S, st) : launch_t<2, 0, ENV>(a, S, st);
+    }
     if (a.M <= 64) return C == 13 ? launch_t<4, 13, ENV>(a, S, st) : launch_t<4, 0, ENV>(a, S, st);
-    return C == 25 ? launch_t<7, 25, ENV>(a, S, st) : C == 26 ? launch_t<7, 26, ENV>(a, S, st) : launch_t<7, 0, ENV>(a, S, st);
+    if (T && C == 25) return launch_t<7, T ? 25 : 26, ENV>(a, S, st);
+    return C == 26 ? launch_t<7, 26, ENV>(a, S, st) : launch_t<7, 0, ENV>(a, S, st);
 }
 
 }  // namespace
@@ -640,8 +733,12 @@ extern "C" __attribute__((visibility("default"))) int eamrl_debug_read_ms_stamps
 // shape_only: the question eamrl_rollout_rng_native asks before the state exists (cache shape and row count alone)
 bool rollout_ms_mfma_supports(int env, const DecArgs& a, bool shape_only)
 {
-    if ((env != EAMRL_ENV_TSP && env != EAMRL_ENV_CVRP) || a.E != ME || a.H != MH || a.M < 2 || a.M > 112 || a.ld % 4 != 0) return false;
-    if (env == EAMRL_ENV_CVRP && (g_debug[14] || (!shape_only && (!a.visited || !a.used || !a.vcap || !a.demand)))) return false;
+    const bool depot_env = env == EAMRL_ENV_CVRP || env == EAMRL_ENV_CVRPTW || env == EAMRL_ENV_PCTSP || env == EAMRL_ENV_OP;
+    if ((env != EAMRL_ENV_TSP && !depot_env) || a.E != ME || a.H != MH || a.M < 2 || a.M > 112 || a.ld % 4 != 0) return false;
+    if (depot_env && (g_debug[14] || (!shape_only && (!a.visited || !a.used || !a.vcap || !a.demand)))) return false;
+    if (!shape_only && (env == EAMRL_ENV_OP || env == EAMRL_ENV_CVRPTW) && !a.locs) return false;
+    if (!shape_only && env == EAMRL_ENV_CVRPTW && (!a.time || !a.tw || !a.dur)) return false;
+    if (!shape_only && (env == EAMRL_ENV_PCTSP || env == EAMRL_ENV_OP) && !a.istep) return false;
     if (a.R % a.B != 0) return false;
     const int64_t S = a.R / a.B;
     return S >= 2 && S <= SMAX && a.top_k == 0 && !(a.top_p > 0.0f && a.top_p < 1.0f);
@@ -651,13 +748,13 @@ int launch_rollout_ms_mfma(int env, const DecArgs& a, hipStream_t st)
 {
     const int S = (int)(a.R / a.B);
     const int C = (a.M + EAMRL_NCHUNK - 1) / EAMRL_NCHUNK;
-    if (env == EAMRL_ENV_CVRP) {
-        const int rc = launch_env_t<EAMRL_ENV_CVRP>(a, S, C, st);
-        if (rc) return rc;
-        launch_rollout_pad(env, a, st);          // rows that finished early end at the depot with an empty vehicle
-        return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
-    }
-    return launch_env_t<EAMRL_ENV_TSP>(a, S, C, st);
+    if (env == EAMRL_ENV_TSP) return launch_env_t<EAMRL_ENV_TSP>(a, S, C, st);
+    const int rc = env == EAMRL_ENV_CVRP ? launch_env_t<EAMRL_ENV_CVRP>(a, S, C, st)
+                 : env == EAMRL_ENV_CVRPTW ? launch_env_t<EAMRL_ENV_CVRPTW>(a, S, C, st)
+                 : env == EAMRL_ENV_PCTSP ? launch_env_t<EAMRL_ENV_PCTSP>(a, S, C, st) : launch_env_t<EAMRL_ENV_OP>(a, S, C, st);
+    if (rc) return rc;
+    launch_rollout_pad(env, a, st);              // rows that finished early end at the depot (and PCTSP / OP get their step counters)
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

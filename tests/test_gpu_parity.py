@@ -803,3 +803,50 @@ def test_full_size_pomo_cvrp_256x100_mfma_kernel_equals_valu_kernel():
     lens = (acts != 0).sum(1)
     assert (lens == N).all() and acts.shape[1] > N          # every customer once, depot returns in between
 
+
+
+@pytest.mark.parametrize("env_name,N,B,S", [("cvrptw", 100, 48, 100), ("pctsp", 100, 64, 100), ("op", 100, 64, 100),
+                                            ("cvrptw", 20, 7, 20), ("pctsp", 50, 5, 50), ("op", 20, 6, 20)])
+def test_sibling_env_multistart_mfma_kernel_equals_valu_kernel(env_name, N, B, S):
+    """Round 3: the MFMA start-sharing kernel also rolls out CVRPTW, PCTSP and OP multistart batches (their state machines run
+    per half-wavefront inside it).  Against the register-resident VALU start-sharing kernel (debug key 14) on the same
+    multistart-sampling batch and noise field: bit-identical tours, log-probs, rewards and final env state."""
+    import time
+
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd import _lib, ops
+    from eam_rl4co_amd.policy import _max_decode_steps
+
+    pol = make_policy("am_" + env_name)
+    env = ea.get_env(env_name, generator_params=dict(num_loc=N), seed=4000 + N)
+    torch.manual_seed(N + B)
+    td = env.reset(batch_size=[B]).to(DEV)
+    # forced start nodes must be feasible first actions (OP / PCTSP resample infeasible ones at random: pin them instead)
+    starts = (torch.arange(S, device=DEV).repeat_interleave(B) % N) + 1
+    ok = td["action_mask"].repeat(S, 1).gather(1, starts[:, None]).squeeze(1)
+    first_ok = td["action_mask"][:, 1:].float().argmax(1).repeat(S) + 1
+    starts = torch.where(ok, starts, first_ok)
+    kw = dict(decode_type="multistart_sampling", num_starts=S, return_sum_log_likelihood=False,
+              select_start_nodes_fn=lambda td_, env_, n: starts)
+    M = N + 1
+    noise = ops.exp1_noise(1234 + N, B * S, _max_decode_steps(env_name, M, 1), M, DEV)
+    outs, tds, ms = [], [], []
+    for valu in (0, 1):
+        _lib.load().eamrl_debug_set(14, valu)
+        try:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            outs.append(pol(td.clone(), env, phase="test", noise=noise, **kw))
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
+            tds.append(pol._last_td)
+        finally:
+            _lib.load().eamrl_debug_set(14, 0)
+    a, b = outs
+    print(f"{env_name}-{N} x {B} x {S}: MFMA start-sharing kernel {ms[0]:.1f} ms, VALU start-sharing kernel {ms[1]:.1f} ms (first calls)")
+    assert torch.equal(a["actions"], b["actions"]), "tours differ between the MFMA and the VALU kernel"
+    assert torch.equal(a["log_likelihood"].view(torch.int32), b["log_likelihood"].view(torch.int32)), "log-probs differ"
+    assert torch.equal(a["reward"], b["reward"])
+    for k in tds[0].keys():
+        if isinstance(tds[0][k], torch.Tensor):
+            assert torch.equal(tds[0][k], tds[1][k]), k

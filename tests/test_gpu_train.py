@@ -285,8 +285,8 @@ def test_forward_is_not_differentiated_outside_training():
     out2 = pol(td, env, phase="train", actions=out["actions"])       # teacher forcing (EAM, earl/model.py:189-195)
     assert out2["log_likelihood"].requires_grad
     assert torch.equal(out2["reward"], out["reward"])
-    with pytest.raises(NotImplementedError):
-        pol(td, env, phase="train", num_starts=4, select_best=True)
+    best = pol(td, env, phase="train", num_starts=4, select_best=True)      # (round 3: differentiable too; values and gradients
+    assert best["log_likelihood"].requires_grad and best["log_likelihood"].shape == (4,)     # in test_gradients_through_filtering_...)
 
 
 def test_checkpointed_reevaluation_gives_the_same_gradients():
