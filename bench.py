@@ -127,7 +127,7 @@ def measured_traffic(workload, batch, suffix=""):
     """HBM bytes per decode-loop launch from the committed PMC passes (profiles/r0N_traffic.json): rocprofv3 counters
     cannot be collected from inside the timed run, so `traffic` is the separately profiled value for exactly this
     workload, or None."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f).get(f"{workload}_b{batch}{suffix}", {}).get("traffic_bytes")
