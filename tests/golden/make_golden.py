@@ -392,7 +392,7 @@ def run_train_case(name, env_name, num_loc, batch, policy_kw=None, num_starts=No
     tensors for the small ones) and the BatchNorm running statistics after the forward."""
     from rl4co.utils.ops import unbatchify as ref_unbatchify
 
-    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv}[env_name]
+    Env = {"tsp": TSPEnv, "cvrp": CVRPEnv, "sdvrp": SDVRPEnv}[env_name]
     env = Env(generator_params=gen_params(env_name, num_loc), seed=data_seed)
     torch.manual_seed(data_seed)
     td_init = env.reset(batch_size=[batch])
@@ -422,7 +422,7 @@ def run_train_case(name, env_name, num_loc, batch, policy_kw=None, num_starts=No
         "loss": np_(loss), "noise": np.stack([np_(q) for q in rec.noise], 1),
         "embeddings": np_(out["hidden"].node_embeddings),
     }
-    if env_name == "cvrp":
+    if env_name in ("cvrp", "sdvrp"):
         fx["demand"] = np_(td_init["demand"])
     for k, v in (policy_kw or {}).items():
         fx["policy_kw_" + k] = np.array(v)
@@ -586,6 +586,7 @@ def train():
     run_train_case("train_am_tsp20_bn", "tsp", 20, 8, baseline="no", data_seed=11)
     run_train_case("train_am_cvrp20_bn", "cvrp", 20, 8, baseline="no", data_seed=12)
     run_train_case("train_am_tsp20_bn_multistart", "tsp", 20, 4, num_starts=10, baseline="shared", data_seed=13)
+    run_train_case("train_am_sdvrp20", "sdvrp", 20, 6, baseline="no", data_seed=14)      # round 3: the split-delivery gradient path
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ from test_gpu_parity import DEV, assert_bits_equal, make_policy, make_td, t
 
 pytestmark = pytest.mark.gpu
 
-TRAIN_CASES = ["train_pomo_tsp20", "train_am_tsp20_bn", "train_am_cvrp20_bn", "train_am_tsp20_bn_multistart"]
+TRAIN_CASES = ["train_pomo_tsp20", "train_am_tsp20_bn", "train_am_cvrp20_bn", "train_am_tsp20_bn_multistart", "train_am_sdvrp20"]
 
 
 class NoBaseline:
