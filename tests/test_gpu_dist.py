@@ -43,8 +43,13 @@ print("RCCL_OK", m)
 
 
 def test_training_step_collective_runs_on_rccl():
+    import socket
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, EAMRL_ROOT=root, EAMRL_PORT="29611", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, EAMRL_ROOT=root, EAMRL_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=600, env=env)
