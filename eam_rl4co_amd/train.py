@@ -192,7 +192,7 @@ def _normalize(norm: nn.Module, x: torch.Tensor, training: bool) -> torch.Tensor
         # Batch statistics when training, as the reference (nn/ops.py:45-47) and as the native rollout that drew the
         # actions (ops.batchnorm_train_); the running statistics were updated by that rollout, not again here.
         x2 = x.reshape(-1, x.size(-1))
-        if training and x2.is_cuda and x2.dtype == torch.float32 and n.weight is not None and x2.size(-1) % 4 == 0 \
+        if training and x2.is_cuda and x2.dtype == torch.float32 and n.weight is not None and n.bias is not None and x2.size(-1) % 4 == 0 \
                 and os.environ.get("EAMRL_TORCH_BATCHNORM", "0") != "1":
             y = _BatchNormTrainFn.apply(x2, n.weight, n.bias, float(n.eps))
         elif training:
