@@ -84,9 +84,9 @@ __device__ __forceinline__ f32x2 d_expf2(f32x2 x)
 __device__ __forceinline__ float vmax_raw(float a, float b);
 __device__ __forceinline__ f32x2 d_expf2_nonpos(f32x2 x)
 {
-    f32x2 xc;
-    xc.x = vmax_raw(x.x, -88.0f);                   // -inf / NaN -> -88; the result of that lane is replaced by 0 below
-    xc.y = vmax_raw(x.y, -88.0f);
+    // no lower clamp (round 3): whatever the polynomial path makes of an argument below -87 (a garbage exponent, an infinity or a
+    // NaN for -inf) is replaced by the exact 0 in the final select, and the in-range path is untouched -- two v_max fewer per pair
+    const f32x2 xc = x;
     const f32x2 t = xc * splat2(1.44269504088896341f);
     // n = rint(t) as (t + 1.5 * 2^23) - 1.5 * 2^23 (round to nearest even, exact for |t| < 2^22): two packed adds instead of two
     // v_rndne + two v_cvt, and the sum's low mantissa bits ARE the integer -- (bits << 23) + 0x3F800000 == (n + 127) << 23
@@ -149,8 +149,11 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 {
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a low and a high one: integer multiplies are
+        // quarter-rate instructions, and the 40 of a call were a tenth of the multistart kernel's issue time
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -158,17 +161,22 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return u32x4{c0, c1, c2, c3};
 }
 __device__ __forceinline__ float d_logf(float x);
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4m d_logf4(f32x4m x);
 __device__ __forceinline__ float exp1_from_bits(uint32_t x)
 {
     const float u = (float)(2u * (x >> 9) + 1u) * 5.9604644775390625e-8f;      // * 2^-24, exact
     return 0.0f - d_logf(u);
 }
-// noise of nodes 4 quad .. 4 quad + 3 of (row, step)
+// noise of nodes 4 quad .. 4 quad + 3 of (row, step); the four logarithms as one four-wide sequence (== exp1_from_bits each)
 __device__ __forceinline__ void exp1_noise4(uint64_t seed, int64_t row, int step, int quad, float (&out)[4])
 {
     const u32x4 r = philox4x32_10((uint32_t)quad, (uint32_t)step, (uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)seed,
                                   (uint32_t)(seed >> 32));
-    out[0] = exp1_from_bits(r.x); out[1] = exp1_from_bits(r.y); out[2] = exp1_from_bits(r.z); out[3] = exp1_from_bits(r.w);
+    f32x4m u = {(float)(2u * (r.x >> 9) + 1u), (float)(2u * (r.y >> 9) + 1u), (float)(2u * (r.z >> 9) + 1u), (float)(2u * (r.w >> 9) + 1u)};
+    u = u * (f32x4m){5.9604644775390625e-8f, 5.9604644775390625e-8f, 5.9604644775390625e-8f, 5.9604644775390625e-8f};
+    const f32x4m q = (f32x4m){0.0f, 0.0f, 0.0f, 0.0f} - d_logf4(u);
+    out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3];
 }
 
 // log(x), x a normal positive number.
@@ -266,6 +274,111 @@ __device__ __forceinline__ f32x2 d_tanhf2(f32x2 x)
     return t;
 }
 
+// Four-wide forms (round 3): the same operation sequence on two packed pairs at once.  Each statement becomes two adjacent
+// v_pk_*_f32 on independent registers, so a pair never waits on its own previous result -- written pair after pair, the compiler
+// kept each chain together and filled the 1-cycle dependent-issue bubble of the packed ops with an s_nop per step (a sixth of the
+// multistart kernel's finish phase).  Element i is bit-identical to the scalar function of element i.
+__device__ __forceinline__ f32x4m pk_fma4(f32x4m a, f32x4m b, f32x4m c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x4m splat4(float v) { return (f32x4m){v, v, v, v}; }
+
+template <bool NONPOS>
+__device__ __forceinline__ f32x4m d_expf4_t(f32x4m x)
+{
+    f32x4m xc = x;
+    if (!NONPOS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xc[i] = (x[i] >= -87.0f) ? x[i] : 0.0f;
+            xc[i] = xc[i] > 88.0f ? 88.0f : xc[i];
+        }
+    }
+    const f32x4m t = xc * splat4(1.44269504088896341f);
+    const f32x4m tm = t + splat4(12582912.0f);
+    const f32x4m n = tm - splat4(12582912.0f);
+    f32x4m r = pk_fma4(n, splat4(-0.693359375f), xc);
+    r = pk_fma4(n, splat4(2.12194440e-4f), r);
+    f32x4m p = splat4(1.9875691500e-4f);
+    p = pk_fma4(p, r, splat4(1.3981999507e-3f));
+    p = pk_fma4(p, r, splat4(8.3334519073e-3f));
+    p = pk_fma4(p, r, splat4(4.1665795894e-2f));
+    p = pk_fma4(p, r, splat4(1.6666665459e-1f));
+    p = pk_fma4(p, r, splat4(5.0000001201e-1f));
+    const f32x4m r2 = r * r;
+    const f32x4m y = pk_fma4(p, r2, r) + splat4(1.0f);
+    f32x4m res;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) res[i] = y[i] * __uint_as_float((__float_as_uint(tm[i]) << 23) + 0x3F800000u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) res[i] = (x[i] >= -87.0f) ? res[i] : 0.0f;
+    return res;
+}
+// four-wide d_logf (x normal positive numbers)
+__device__ __forceinline__ f32x4m d_logf4(f32x4m x)
+{
+    f32x4m m, fe;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t u = __float_as_uint(x[i]);
+        int e = (int)(u >> 23) - 126;
+        const float mi = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
+        const bool low = mi < 0.707106781186547524f;
+        e = low ? e - 1 : e;
+        m[i] = low ? (mi + mi) - 1.0f : mi - 1.0f;
+        fe[i] = (float)e;
+    }
+    const f32x4m z = m * m;
+    f32x4m p = splat4(7.0376836292e-2f);
+    p = pk_fma4(p, m, splat4(-1.1514610310e-1f));
+    p = pk_fma4(p, m, splat4(1.1676998740e-1f));
+    p = pk_fma4(p, m, splat4(-1.2420140846e-1f));
+    p = pk_fma4(p, m, splat4(1.4249322787e-1f));
+    p = pk_fma4(p, m, splat4(-1.6668057665e-1f));
+    p = pk_fma4(p, m, splat4(2.0000714765e-1f));
+    p = pk_fma4(p, m, splat4(-2.4999993993e-1f));
+    p = pk_fma4(p, m, splat4(3.3333331174e-1f));
+    f32x4m y = (p * m) * z;
+    y = pk_fma4(splat4(-2.12194440e-4f), fe, y);
+    y = pk_fma4(splat4(-0.5f), z, y);
+    const f32x4m r = m + y;
+    return pk_fma4(splat4(0.693359375f), fe, r);
+}
+__device__ __forceinline__ f32x4m d_expf4(f32x4m x) { return d_expf4_t<false>(x); }
+__device__ __forceinline__ f32x4m d_expf4_nonpos(f32x4m x) { return d_expf4_t<true>(x); }
+
+__device__ __forceinline__ f32x4m d_tanhf4(f32x4m x)
+{
+    f32x4m a, ac;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = __builtin_fabsf(x[i]);
+    const f32x4m z = a * a;
+    f32x4m p = splat4(-5.70498872745e-3f);
+    p = pk_fma4(p, z, splat4(2.06390887954e-2f));
+    p = pk_fma4(p, z, splat4(-5.37397155531e-2f));
+    p = pk_fma4(p, z, splat4(1.33314422036e-1f));
+    p = pk_fma4(p, z, splat4(-3.33332819422e-1f));
+    const f32x4m t_small = pk_fma4(p * z, a, a);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ac[i] = a[i] > 9.0f ? 9.0f : a[i];
+    const f32x4m e = d_expf4(ac + ac);
+    const f32x4m x1 = e + splat4(1.0f);
+    f32x4m r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __uint_as_float(0x7EF311C7u - __float_as_uint(x1[i]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const f32x4m t = pk_fma4(-x1, r, splat4(1.0f));
+        r = pk_fma4(r, t, r);
+    }
+    const f32x4m t_big = pk_fma4(splat4(-2.0f), r, splat4(1.0f));
+    f32x4m t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        t[i] = (a[i] < 0.625f) ? t_small[i] : ((a[i] > 9.0f) ? 1.0f : t_big[i]);
+        t[i] = __builtin_copysignf(t[i], x[i]);
+    }
+    return t;
+}
+
 // ---- cross-lane exchange steps of a 64-lane butterfly, without LDS traffic -------------------------------
 // Levels 1,2: quad_perm DPP; 4,8: row_half_mirror / row_mirror DPP (the partner lane differs from i^4 / i^8
 // but holds the same value, because after the previous level a value is uniform inside its 4- / 8-lane
@@ -309,6 +422,15 @@ __device__ __forceinline__ float vmax3_raw(float a, float b, float c)
 {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// m = max(m, v0 .. v3) as two v_max3_f32 in ONE asm statement (the compiler puts an s_nop after every asm statement that feeds
+// the next one, so a chain of single-instruction statements costs two issue slots per value).  NaN operands are ignored like
+// v_max_f32 ignores them (the result is a NaN only if all are).
+__device__ __forceinline__ float vmax5_raw(float m, float v0, float v1, float v2, float v3)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5" : "=&v"(r) : "v"(m), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
     return r;
 }
 // one butterfly level of a max: max(v, v of the DPP partner lane); s_nop 1 = the 2 wait states a DPP read needs

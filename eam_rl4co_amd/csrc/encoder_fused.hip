@@ -155,7 +155,6 @@ __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[RTW][CT], const float* ar
     }
 }
 
-__device__ __forceinline__ f32x4 splat4(float v) { return (f32x4){v, v, v, v}; }
 
 // y = norm(res + acc) for the two column tiles of a wave, written back to HB in place (batch norm: per-column affine;
 // instance norm: the sums are written here and normalised per channel after a barrier).

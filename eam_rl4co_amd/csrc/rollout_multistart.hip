@@ -28,6 +28,9 @@
 namespace eamrl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// a * b for operands below 2^32 (rows, steps per row: rollout_ms_mfma_supports): one v_mad_u64_u32 where the 64 x 64 product of two
+// int64 is three quarter-rate multiplies -- per-lane row offsets are computed once per tile in the finish phase
+__device__ __forceinline__ int64_t mul32w(int64_t a, int64_t b) { return (int64_t)((uint64_t)(uint32_t)a * (uint32_t)b); }
 
 #ifdef EAMRL_STAMPS   // development build only (tools/build_stamps.sh): per-phase cycle sums over all wavefronts
 __device__ unsigned long long g_ms_stamps[24];
@@ -235,31 +238,39 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
     int t = 0;
     // thread (jq, e4): four columns 4 e4 .. 4 e4 + 3 of query row jq of a tile
     const int jq = tid >> 5, e4 = tid & 31;
+    // this thread's columns of the instance's projection rows / graph context / context vectors as per-lane pointers, made once: a
+    // row is then base + node * ld with a full-rate 24-bit multiply (node < 128, ld < 2^24: rollout_ms_mfma_supports) -- the int64
+    // (b M + node) ld per load was three quarter-rate multiplies behind SGPRs the loop had to reload from spill lanes
+    const float* const pa_b = a.Pa + b * M * ld + 4 * e4;
+    const float* const pb_b = a.Pb ? a.Pb + b * M * ld + 4 * e4 : nullptr;
+    const float* const gq_b = a.gctx ? a.gctx + b * ME + 4 * e4 : nullptr;
+    const float* const cv_b = a.cvec + 4 * e4;
+    const uint32_t ld24 = (uint32_t)ld;
     auto q_load = [&](int qtile) -> float4 {
         const int s = 16 * qtile + jq;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s < S && !s_done[s]) {
             float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.gctx) g4 = *reinterpret_cast<const float4*>(a.gctx + b * ME + 4 * e4);
+            if (gq_b) g4 = *reinterpret_cast<const float4*>(gq_b);
             if (DEP) {              // EnvContext: fma(state column, state scalar, Pa[current]) + graph context -- free capacity (VRPContext),
                                     // prize still to collect clamped at 0 (PCTSPContext), length still allowed (OPContext); CVRPTW: + the clock column
-                const float4 c4 = *reinterpret_cast<const float4*>(a.cvec + 4 * e4);
-                const float4 p = *reinterpret_cast<const float4*>(a.Pa + (b * M + s_cur[s]) * ld + 4 * e4);
+                const float4 c4 = *reinterpret_cast<const float4*>(cv_b);
+                const float4 p = *reinterpret_cast<const float4*>(pa_b + __umul24((uint32_t)s_cur[s], ld24));
                 float fr = s_cap[s] - s_used[s];
                 if (PC) fr = fr < 0.0f ? 0.0f : fr;
                 float4 y = make_float4(fma_(c4.x, fr, p.x), fma_(c4.y, fr, p.y), fma_(c4.z, fr, p.z), fma_(c4.w, fr, p.w));
                 if (TW) {
-                    const float4 c2 = *reinterpret_cast<const float4*>(a.cvec + ME + 4 * e4);
+                    const float4 c2 = *reinterpret_cast<const float4*>(cv_b + ME);
                     const float now = s_time[s];
                     y = make_float4(fma_(c2.x, now, y.x), fma_(c2.y, now, y.y), fma_(c2.z, now, y.z), fma_(c2.w, now, y.w));
                 }
                 v = make_float4(y.x + g4.x, y.y + g4.y, y.z + g4.z, y.w + g4.w);
             } else if (s_istep[s] == 0) {
-                const float4 c4 = *reinterpret_cast<const float4*>(a.cvec + 4 * e4);
+                const float4 c4 = *reinterpret_cast<const float4*>(cv_b);
                 v = make_float4(c4.x + g4.x, c4.y + g4.y, c4.z + g4.z, c4.w + g4.w);
             } else {
-                const float4 p = *reinterpret_cast<const float4*>(a.Pa + (b * M + s_first[s]) * ld + 4 * e4);
-                const float4 c4 = *reinterpret_cast<const float4*>(a.Pb + (b * M + s_cur[s]) * ld + 4 * e4);
+                const float4 p = *reinterpret_cast<const float4*>(pa_b + __umul24((uint32_t)s_first[s], ld24));
+                const float4 c4 = *reinterpret_cast<const float4*>(pb_b + __umul24((uint32_t)s_cur[s], ld24));
                 v = make_float4((p.x + c4.x) + g4.x, (p.y + c4.y) + g4.y, (p.z + c4.z) + g4.z, (p.w + c4.w) + g4.w);
             }
         }
@@ -306,15 +317,23 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
 #pragma unroll
                 for (int kt = 0; kt < RTT; ++kt) s[kt] = mf(kf[kt][3], qhi.y, s[kt]);
                 float m = -INFINITY;
+                {
+                    // infeasible keys: the score is OR-ed with all ones (a quiet NaN) where the key's mask bit is clear -- v_bfe_i32 of
+                    // the inverted, pre-shifted mask word + v_or_b32, two instructions per key instead of three (bit test, compare,
+                    // select).  A NaN score behaves like the -inf it replaces everywhere it goes: v_max_f32 / v_max3_f32 return the
+                    // other operand(s), and d_expf4_nonpos turns NaN - m into the exact 0 (its final select is an ordered compare).
+                    const uint32_t iw[4] = {~mb.x >> G, ~mb.y >> G, ~mb.z >> G, ~mb.w >> G};
 #pragma unroll
-                for (int kt = 0; kt < RTT; ++kt)
+                    for (int kt = 0; kt < RTT; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n0 = 16 * kt + 4 * r;              // + G: the same 32-bit word
-                        const uint32_t w = (n0 >> 5) == 0 ? mb.x : (n0 >> 5) == 1 ? mb.y : (n0 >> 5) == 2 ? mb.z : mb.w;
-                        s[kt][r] = ((w >> ((n0 & 31) + G)) & 1u) ? s[kt][r] : -INFINITY;
-                        m = vmax_raw(m, s[kt][r]);
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            const int n0 = 16 * kt + 4 * r;          // key n0 + G: bit (n0 & 31) of the shifted word (n0 & 31 <= 28, G <= 3)
+                            const int bad = __builtin_amdgcn_sbfe(iw[n0 >> 5], n0 & 31, 1);      // 0 or -1
+                            s[kt][r] = __uint_as_float(__float_as_uint(s[kt][r]) | (uint32_t)bad);
+                        }
+#pragma unroll
+                    for (int kt = 0; kt < RTT; ++kt) m = vmax5_raw(m, s[kt][0], s[kt][1], s[kt][2], s[kt][3]);
+                }
                 m = group_max(m);
                 MSTAMP(2);
                 // softmax weights; a masked node has s = -inf and d_expf2_nonpos gives it exactly 0 (as the canonical select does)
@@ -322,9 +341,14 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 for (int kt = 0; kt < RTT; ++kt) {
                     // (compile-time chunk length: keys from 4 CC on do not exist -- their weight is the 0 a masked key gets)
                     const bool pad01 = CC > 0 && 16 * kt >= 4 * CC, pad23 = CC > 0 && 16 * kt + 8 >= 4 * CC;
-                    const f32x2 e01 = pad01 ? splat2(0.0f) : d_expf2_nonpos((f32x2){s[kt][0] - m, s[kt][1] - m});
-                    const f32x2 e23 = pad23 ? splat2(0.0f) : d_expf2_nonpos((f32x2){s[kt][2] - m, s[kt][3] - m});
-                    s[kt] = (f32x4){e01.x, e01.y, e23.x, e23.y};
+                    if (pad01) {
+                        s[kt] = z4();
+                    } else if (pad23) {
+                        const f32x2 e01 = d_expf2_nonpos((f32x2){s[kt][0] - m, s[kt][1] - m});
+                        s[kt] = (f32x4){e01.x, e01.y, 0.0f, 0.0f};
+                    } else {
+                        s[kt] = d_expf4_nonpos(s[kt] - splat4(m));     // both pairs step by step (dmath.hpp)
+                    }
                 }
                 MSTAMP(3);
                 // Value product per node chunk g = [g C, (g+1) C), chunks in ascending order: `cur` accumulates the chunk in
@@ -404,8 +428,8 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                     hp[r * TG] = hv[r];
                 }
                 if (a.heads_out && sq < S) {     // training: keep the step's glimpse output for the backward (zeros for a done row)
-                    const int64_t row = (int64_t)sq * a.B + b;
-                    *reinterpret_cast<float4*>(a.heads_out + (row * a.t_max + t) * 128 + 16 * wv + 4 * G) =
+                    const int64_t row = mul32w(sq, a.B) + b;
+                    *reinterpret_cast<float4*>(a.heads_out + (mul32w(row, a.t_max) + t) * 128 + 16 * wv + 4 * G) =
                         live ? make_float4(hv[0], hv[1], hv[2], hv[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 const bool live2 = s2 < S && !s_done[s2];
                 const int nb4 = 4 * l32;                                 // this lane's keys: nb4 + r
                 const bool inq = l32 < 4 * RTT;                          // UT holds 16 RTT keys per query
-                const int64_t r2 = (int64_t)s2 * a.B + b;
+                const int64_t r2 = mul32w(s2, a.B) + b;
                 uint4 mb2 = make_uint4(0, 0, 0, 0);
                 if (live2) mb2 = *reinterpret_cast<const uint4*>(&s_bits[s2][0]);
                 float4 u4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -452,58 +476,59 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 float nz[4] = {1.0f, 1.0f, 1.0f, 1.0f};
                 if (a.mode == EAMRL_SAMPLE && live2 && inq) {
                     if (a.use_rng) {
-                        exp1_noise4(seed, r2, t, l32, nz);
+                        // the seed goes through an opaque register pair: otherwise the ten round keys of the generator are computed
+                        // once, kept in 20 SGPRs across the whole kernel and spilled (a v_readlane per key, per tile)
+                        uint64_t sd = seed;
+                        asm volatile("" : "+s"(sd));
+                        exp1_noise4(sd, r2, t, l32, nz);
                     } else {
-                        const float* np_ = a.noise + (r2 * a.t_max + t) * (int64_t)M;
+                        const float* np_ = a.noise + (mul32w(r2, a.t_max) + t) * (int64_t)M;
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr)
                             if (nb4 + rr < M) nz[rr] = np_[nb4 + rr];
                     }
                 }
                 MSTAMP(7);
-                bool fe[4];
-                f32x2 v01, v23;
-                bool nan_seen;
+                f32x4 v;
                 {
-                    const f32x2 l01 = (f32x2){u4.x, u4.y} * splat2(inv_sqrtE), l23 = (f32x2){u4.z, u4.w} * splat2(inv_sqrtE);
-                    const uint32_t w = (nb4 >> 5) == 0 ? mb2.x : (nb4 >> 5) == 1 ? mb2.y : (nb4 >> 5) == 2 ? mb2.z : mb2.w;
+                    const f32x4 l = (f32x4){u4.x, u4.y, u4.z, u4.w} * splat4(inv_sqrtE);
+                    uint32_t w = (nb4 >> 5) == 0 ? mb2.x : (nb4 >> 5) == 1 ? mb2.y : (nb4 >> 5) == 2 ? mb2.z : mb2.w;
+                    w = inq ? ~w >> (nb4 & 31) : ~0u;              // bit r set: key nb4 + r is infeasible (or does not exist)
+                    v = (a.clip > 0.0f) ? d_tanhf4(l) * splat4(a.clip) : l;       // the four keys step by step (dmath.hpp)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) fe[r] = inq && ((w >> ((nb4 & 31) + r)) & 1u);
-                    nan_seen = (fe[0] && l01.x != l01.x) || (fe[1] && l01.y != l01.y) || (fe[2] && l23.x != l23.x) ||
-                               (fe[3] && l23.y != l23.y);
-                    v01 = (a.clip > 0.0f) ? d_tanhf2(l01) * splat2(a.clip) : l01;
-                    v23 = (a.clip > 0.0f) ? d_tanhf2(l23) * splat2(a.clip) : l23;
-                    v01.x = fe[0] ? v01.x : -INFINITY; v01.y = fe[1] ? v01.y : -INFINITY;
-                    v23.x = fe[2] ? v23.x : -INFINITY; v23.y = fe[3] ? v23.y : -INFINITY;
+                    for (int r = 0; r < 4; ++r) v[r] = ((w >> r) & 1u) ? -INFINITY : v[r];     // (no lane masks kept: see vsum below)
                     if (a.temp != 1.0f) {
                         asm volatile("" ::: "memory");
-                        v01 = v01 / splat2(a.temp);
-                        v23 = v23 / splat2(a.temp);
+                        v = v / splat4(a.temp);
                     }
                 }
-                const float mq = half_max(vmax_raw(vmax_raw(v01.x, v01.y), vmax_raw(v23.x, v23.y)));
+                // a NaN among the FEASIBLE logits (tanh, the clip and the temperature pass it on; infeasible keys are -inf by now): the sum
+                // of the lane's four values is a NaN exactly then (-inf + x = -inf for every other x the clipped logits can take)
+                const float vsum = (v[0] + v[1]) + (v[2] + v[3]);
+                const bool nan_seen = vsum != vsum;
+                const float mq = half_max(vmax5_raw(v[0], v[1], v[2], v[3], v[3]));
                 MSTAMP(8);
-                const f32x2 d01 = v01 - splat2(mq), d23 = v23 - splat2(mq);
+                const f32x4 d = v - splat4(mq);
                 float lse, lp[4];
                 {
-                    const f32x2 e01 = d_expf2_nonpos(d01), e23 = d_expf2_nonpos(d23);
-                    const float e0 = fe[0] ? e01.x : 0.0f, e1 = fe[1] ? e01.y : 0.0f, e2 = fe[2] ? e23.x : 0.0f, e3 = fe[3] ? e23.y : 0.0f;
-                    const float Zl = half_tree_sum((e0 + e1) + (e2 + e3));     // levels 1, 2 in lane; 4 .. 32 in the row; block 0 + block 1
+                    // an infeasible key has v = -inf, so d = -inf, its weight is the exact 0 and its log-prob -inf without further selects
+                    const f32x4 e = d_expf4_nonpos(d);
+                    const float Zl = half_tree_sum((e[0] + e[1]) + (e[2] + e[3]));     // levels 1, 2 in lane; 4 .. 32 in the row; block 0 + block 1
                     lse = d_logf(Zl);
-                    lp[0] = fe[0] ? d01.x - lse : -INFINITY; lp[1] = fe[1] ? d01.y - lse : -INFINITY;
-                    lp[2] = fe[2] ? d23.x - lse : -INFINITY; lp[3] = fe[3] ? d23.y - lse : -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lp[r] = d[r] - lse;
                 }
                 MSTAMP(10);
                 // ---- selection: greedy = first node whose log-prob equals the maximum (mx - mx) - lse; sampling = first node with
                 //      the largest p / noise --------------------------------------------------------------------------------------
                 int cand = 1 << 20;
                 if (a.mode == EAMRL_SAMPLE) {
-                    const f32x2 k01 = d_expf2_nonpos((f32x2){lp[0], lp[1]}) / (f32x2){nz[0], nz[1]};
-                    const f32x2 k23 = d_expf2_nonpos((f32x2){lp[2], lp[3]}) / (f32x2){nz[2], nz[3]};
+                    const f32x4 kq = d_expf4_nonpos((f32x4){lp[0], lp[1], lp[2], lp[3]}) / (f32x4){nz[0], nz[1], nz[2], nz[3]};
                     float key[4];
-                    key[0] = (inq && nb4 + 0 < M) ? k01.x : -INFINITY; key[1] = (inq && nb4 + 1 < M) ? k01.y : -INFINITY;
-                    key[2] = (inq && nb4 + 2 < M) ? k23.x : -INFINITY; key[3] = (inq && nb4 + 3 < M) ? k23.y : -INFINITY;
-                    const float top = half_max(vmax_raw(vmax_raw(key[0], key[1]), vmax_raw(key[2], key[3])));
+                    // (a key that is infeasible or does not exist has p = exp(-inf) = 0, so its ratio is 0 and below the row's best)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) key[r] = kq[r];
+                    const float top = half_max(vmax5_raw(key[0], key[1], key[2], key[3], key[3]));
 #pragma unroll
                     for (int r = 3; r >= 0; --r)
                         if (key[r] == top) cand = nb4 + r;
@@ -511,10 +536,10 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                     const float top = 0.0f - lse;
 #pragma unroll
                     for (int r = 3; r >= 0; --r)
-                        if (inq && nb4 + r < M && lp[r] == top) cand = nb4 + r;
+                        if (lp[r] == top) cand = nb4 + r;           // (-inf for a key that is infeasible or does not exist)
                 }
                 int sel = half_min(cand);
-                if (a.mode == EAMRL_EVALUATE && live2) sel = (t < a.t_given) ? (int)a.given[r2 * a.t_given + t] : 0;
+                if (a.mode == EAMRL_EVALUATE && live2) sel = (t < a.t_given) ? (int)a.given[mul32w(r2, a.t_given) + t] : 0;
                 uint32_t fl = 0;
                 if (live2) {
                     if (nan_seen) fl |= EAMRL_ST_NAN_LOGITS;
@@ -527,8 +552,8 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 // ---- env transition (TSPEnv._step, tsp/env.py:62-88): lane 0 of the half-wavefront ---------------------------------
                 if (!DEP && l32 == 0 && live2) {
                     const int s = s2, sl = sel;
-                    a.action[r2 * a.t_max + t] = sl;
-                    a.logp[r2 * a.t_max + t] = LPSEL[jq2];
+                    a.action[mul32w(r2, a.t_max) + t] = sl;
+                    a.logp[mul32w(r2, a.t_max) + t] = LPSEL[jq2];
                     const uint32_t bit = 1u << (sl & 31);
                     const uint32_t wd = s_bits[s][sl >> 5];
                     if (!(wd & bit)) atomicOr(&s_flags, EAMRL_ST_INFEASIBLE);
@@ -624,8 +649,8 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                         if (ok0) nb[0] |= 1u;
                     }
                     if (l32 == 0) {
-                        a.action[r2 * a.t_max + t] = sl;
-                        a.logp[r2 * a.t_max + t] = lpv;
+                        a.action[mul32w(r2, a.t_max) + t] = sl;
+                        a.logp[mul32w(r2, a.t_max) + t] = lpv;
                         if (!(oword & bit)) atomicOr(&s_flags, EAMRL_ST_INFEASIBLE);
                         *reinterpret_cast<uint4*>(&s_bits[s][0]) = make_uint4(nb[0], nb[1], nb[2], nb[3]);
                         *reinterpret_cast<uint4*>(&s_vis[s][0]) = vw;
@@ -734,12 +759,12 @@ extern "C" __attribute__((visibility("default"))) int eamrl_debug_read_ms_stamps
 bool rollout_ms_mfma_supports(int env, const DecArgs& a, bool shape_only)
 {
     const bool depot_env = env == EAMRL_ENV_CVRP || env == EAMRL_ENV_CVRPTW || env == EAMRL_ENV_PCTSP || env == EAMRL_ENV_OP;
-    if ((env != EAMRL_ENV_TSP && !depot_env) || a.E != ME || a.H != MH || a.M < 2 || a.M > 112 || a.ld % 4 != 0) return false;
+    if ((env != EAMRL_ENV_TSP && !depot_env) || a.E != ME || a.H != MH || a.M < 2 || a.M > 112 || a.ld % 4 != 0 || a.ld >= (1 << 24)) return false;
     if (depot_env && (g_debug[14] || (!shape_only && (!a.visited || !a.used || !a.vcap || !a.demand)))) return false;
     if (!shape_only && (env == EAMRL_ENV_OP || env == EAMRL_ENV_CVRPTW) && !a.locs) return false;
     if (!shape_only && env == EAMRL_ENV_CVRPTW && (!a.time || !a.tw || !a.dur)) return false;
     if (!shape_only && (env == EAMRL_ENV_PCTSP || env == EAMRL_ENV_OP) && !a.istep) return false;
-    if (a.R % a.B != 0) return false;
+    if (a.R % a.B != 0 || a.R >= (1ll << 31)) return false;    // mul32w below
     const int64_t S = a.R / a.B;
     return S >= 2 && S <= SMAX && a.top_k == 0 && !(a.top_p > 0.0f && a.top_p < 1.0f);
 }
