@@ -111,6 +111,35 @@ __device__ __forceinline__ f32x2 d_expf2_nonpos(f32x2 x)
     return res;
 }
 
+// Two pairs at once, statement by statement (round 3): the packed operations of the two pairs alternate, so neither waits on its own
+// previous result (a pair on its own pays a wait state per dependent v_pk_*_f32).  Each element == d_expf2_nonpos of its pair.
+__device__ __forceinline__ void d_expf2_nonpos_x2(f32x2& a, f32x2& b)
+{
+    const f32x2 xa = a, xb = b;
+    const f32x2 ta = xa * splat2(1.44269504088896341f), tb = xb * splat2(1.44269504088896341f);
+    const f32x2 tma = ta + splat2(12582912.0f), tmb = tb + splat2(12582912.0f);
+    const f32x2 na = tma - splat2(12582912.0f), nb = tmb - splat2(12582912.0f);
+    f32x2 ra = pk_fma(na, splat2(-0.693359375f), xa), rb = pk_fma(nb, splat2(-0.693359375f), xb);
+    ra = pk_fma(na, splat2(2.12194440e-4f), ra); rb = pk_fma(nb, splat2(2.12194440e-4f), rb);
+    f32x2 pa = splat2(1.9875691500e-4f), pb = splat2(1.9875691500e-4f);
+    pa = pk_fma(pa, ra, splat2(1.3981999507e-3f)); pb = pk_fma(pb, rb, splat2(1.3981999507e-3f));
+    pa = pk_fma(pa, ra, splat2(8.3334519073e-3f)); pb = pk_fma(pb, rb, splat2(8.3334519073e-3f));
+    pa = pk_fma(pa, ra, splat2(4.1665795894e-2f)); pb = pk_fma(pb, rb, splat2(4.1665795894e-2f));
+    pa = pk_fma(pa, ra, splat2(1.6666665459e-1f)); pb = pk_fma(pb, rb, splat2(1.6666665459e-1f));
+    pa = pk_fma(pa, ra, splat2(5.0000001201e-1f)); pb = pk_fma(pb, rb, splat2(5.0000001201e-1f));
+    const f32x2 r2a = ra * ra, r2b = rb * rb;
+    const f32x2 ya = pk_fma(pa, r2a, ra) + splat2(1.0f), yb = pk_fma(pb, r2b, rb) + splat2(1.0f);
+    f32x2 sa, sb;
+    sa.x = __uint_as_float((__float_as_uint(tma.x) << 23) + 0x3F800000u);
+    sb.x = __uint_as_float((__float_as_uint(tmb.x) << 23) + 0x3F800000u);
+    sa.y = __uint_as_float((__float_as_uint(tma.y) << 23) + 0x3F800000u);
+    sb.y = __uint_as_float((__float_as_uint(tmb.y) << 23) + 0x3F800000u);
+    f32x2 qa = ya * sa, qb = yb * sb;
+    qa.x = (xa.x >= -87.0f) ? qa.x : 0.0f; qb.x = (xb.x >= -87.0f) ? qb.x : 0.0f;
+    qa.y = (xa.y >= -87.0f) ? qa.y : 0.0f; qb.y = (xb.y >= -87.0f) ? qb.y : 0.0f;
+    a = qa; b = qb;
+}
+
 // The softmax denominators of the path (canonical order): four interleaved partial sums, P_r = sequential sum of the weights of
 // the nodes n = r (mod 4) in ascending order, combined as (P0 + P1) + (P2 + P3).  (The order a 16x16x4 MFMA score tile holds per
 // lane; a plain sequential sum costs the MFMA kernels a third of their attention issue slots.)  Loops keep the four sums in a

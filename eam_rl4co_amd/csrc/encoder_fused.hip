@@ -398,6 +398,7 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
                 }
                 float vf[4 * RTT];
                 const int NT = (M + 3) >> 2;             // value k-steps (4 keys each)
+                constexpr int FULLT = RTT == 7 ? 4 : RTT == 4 ? 2 : 0;       // launch_encoder_fused: M > 64 / M > 32 / any
 #pragma unroll
                 for (int t = 0; t < 4 * RTT; ++t) vf[t] = (t < NT) ? VT[(16 * cw + j) * SV + 4 * t + G] : 0.0f;
                 for (int q = 0; q < nrt; ++q) {
@@ -418,13 +419,13 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
                     for (int kt = 0; kt < RTT; ++kt) s[kt] = mfma4(kf[kt][3], qhi.y, s[kt]);
 #pragma unroll
                     for (int kt = 0; kt < RTT; ++kt) {
-                        if (16 * kt + 16 > M) {                                       // (uniform) the tile holds padded keys
+                        // (uniform) the tile holds padded keys: the variant's M range leaves the first FULLT tiles always full
+                        if (kt >= FULLT && 16 * kt + 16 > M) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
                                 if (16 * kt + 4 * r + G >= M) s[kt][r] = -INFINITY;
                         }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) m = vmax_raw(m, s[kt][r]);
+                        m = vmax5_raw(m, s[kt][0], s[kt][1], s[kt][2], s[kt][3]);      // two v_max3_f32, one asm statement
                     }
                     {   // the four lane groups G share a query: max over lanes l, l^16, l^32, l^48
                         auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
@@ -433,9 +434,9 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
                         m = vmax_raw(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
                     }
 #pragma unroll
-                    for (int kt = 0; kt < RTT; ++kt) {      // packed fp32 math: each half bit-identical to d_expf
-                        const f32x2 e01 = d_expf2_nonpos((f32x2){s[kt][0] - m, s[kt][1] - m});
-                        const f32x2 e23 = d_expf2_nonpos((f32x2){s[kt][2] - m, s[kt][3] - m});
+                    for (int kt = 0; kt < RTT; ++kt) {      // packed fp32 math, the two pairs of a tile statement by statement: each
+                        f32x2 e01 = (f32x2){s[kt][0], s[kt][1]} - splat2(m), e23 = (f32x2){s[kt][2], s[kt][3]} - splat2(m);
+                        d_expf2_nonpos_x2(e01, e23);                                          // element bit-identical to d_expf
                         s[kt] = (f32x4){e01.x, e01.y, e23.x, e23.y};
                     }
                     // Z (canonical order, encoder.hip ZRot): this lane holds the keys 4 r + G of every tile, i.e. one residue class
@@ -451,8 +452,13 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
                     }
                     f32x4 o = splat4(0.0f);
 #pragma unroll
-                    for (int t = 0; t < 4 * RTT; ++t)
-                        if (t < NT) o = mfma4(vf[t], s[t >> 2][t & 3], o);
+                    for (int kt = 0; kt < RTT; ++kt)        // a (uniform) test per key tile that may be empty, none per k-step: the padded
+                                                            // k-steps of a started tile multiply zero weights with zero values, and
+                                                            // fma(0, 0, o) == o (o is never -0: it starts from +0)
+                        if (kt < FULLT || 16 * kt < M) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o = mfma4(vf[4 * kt + r], s[kt][r], o);
+                        }
                     // o: lane (query j, G), reg r -> head column e = 4 G + r -> A layout (g = r, t = 4 cw + G); overwrites q
                     float* op = QA + qrow * SQ + 4 * cw + G;
 #pragma unroll
