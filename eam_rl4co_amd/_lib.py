@@ -51,7 +51,7 @@ class Reeval(C.Structure):
                 ("logp", _vp), ("lse", _vp), ("glogp", _vp), ("dheads", _vp), ("heads", _vp), ("heads_T", C.c_int32),
                 ("entropy", _vp),
                 ("dK", _vp), ("dV", _vp), ("dLp", _vp), ("dPa", _vp), ("dPb", _vp), ("ldg", _i64),
-                ("dgctx", _vp), ("dCvec", _vp)]
+                ("dgctx", _vp), ("dCvec", _vp), ("rem", _vp), ("dyn", _vp), ("ddyn", _vp)]
 
 
 class State(C.Structure):
@@ -118,6 +118,7 @@ PROTOTYPES = {
     "eamrl_instance_norm_forward": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _f32, _vp],
     "eamrl_instance_norm_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "eamrl_replay_states": [_i32, C.POINTER(State), _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp],
+    "eamrl_replay_states_sdvrp": [C.POINTER(State), _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "eamrl_check_solution": [_i32, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp],
     "eamrl_beam_topk": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "eamrl_ea_cvrp_run": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, C.c_double, C.c_double, C.c_double, _i32,

@@ -400,6 +400,8 @@ static int check_reeval(const eamrl_reeval* p, const char* what, bool bwd)
     REQUIRE(p->ld >= 128 && p->ld % 4 == 0 && p->NC >= 0 && p->NC <= 4 && (p->NC == 0 || (p->Cvec && p->sc)), what);
     REQUIRE(p->temp > 0.0f && p->tstart >= 0, what);
     REQUIRE(!p->heads || (p->heads_T > 0 && (uintptr_t)p->heads % 16 == 0), what);
+    REQUIRE((p->dyn == nullptr) == (p->rem == nullptr), what);
+    REQUIRE(!p->dyn || (!p->heads && (uintptr_t)p->rem % 16 == 0 && (!bwd || p->ddyn)), what);
     REQUIRE(((uintptr_t)p->Pa % 16 == 0) && (!p->Pb || (uintptr_t)p->Pb % 16 == 0) && (!p->gctx || (uintptr_t)p->gctx % 16 == 0) &&
                 (!p->Cvec || (uintptr_t)p->Cvec % 16 == 0) && ((uintptr_t)p->maskbits % 16 == 0), what);
     if (bwd) {
@@ -442,6 +444,18 @@ __attribute__((visibility("default"))) int eamrl_replay_states(int env, const ea
     return launched(launch_replay_states(env, s->mask, s->visited, s->used, s->vcap, s->cur, s->istep, s->time, s->demand, s->locs,
                                          s->tw, s->dur, actions, bits, idxA, sc, R, B, M, T, (hipStream_t)stream),
                     "eamrl_replay_states");
+}
+
+__attribute__((visibility("default"))) int eamrl_replay_states_sdvrp(const eamrl_state* s, int64_t R, int M, const int64_t* actions,
+                                                                    int T, uint32_t* bits, int32_t* idxA, float* sc,
+                                                                    float* rem_out, void* stream)
+{
+    REQUIRE(s && actions && bits && idxA && sc && rem_out && R >= 0 && M >= 2 && M <= 128 && T > 0 && ((uintptr_t)bits % 16 == 0),
+            "eamrl_replay_states_sdvrp");
+    REQUIRE(s->rem && s->used && s->vcap && s->cur, "eamrl_replay_states_sdvrp (state)");
+    if (R == 0) return 0;
+    return launched(launch_replay_sdvrp(s->rem, s->used, s->vcap, s->cur, actions, bits, idxA, sc, rem_out, R, M, T,
+                                        (hipStream_t)stream), "eamrl_replay_states_sdvrp");
 }
 
 __attribute__((visibility("default"))) int eamrl_pack_mask_bits(const uint8_t* mask, uint32_t* bits, int64_t R, int M, int T,

@@ -731,6 +731,60 @@ __global__ __launch_bounds__(EB) void k_replay_states(ReplayArgs a)
     }
 }
 
+// SDVRP: the same recording for SDVRPEnv (sdvrp/env.py:58-92,137-146) -- the state is the remaining-demand row itself, kept in
+// registers (nodes lane and lane + 64); additionally every step's row goes to rem_out [R][T][128] (zero padded), which is what the
+// re-evaluation's dynamic embedding multiplies.  Arithmetic of k_sdvrp_step_mask.
+__global__ __launch_bounds__(EB) void k_replay_sdvrp(const float* __restrict__ rem, const float* __restrict__ used,
+                                                     const float* __restrict__ vcap, const int64_t* __restrict__ cur,
+                                                     const int64_t* __restrict__ actions, uint32_t* __restrict__ bits,
+                                                     int32_t* __restrict__ idxA, float* __restrict__ sc, float* __restrict__ rem_out,
+                                                     int64_t R, int M, int T)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int n0 = lane, n1 = lane + 64;
+    float r0 = n0 < M ? rem[r * M + n0] : 0.0f, r1 = n1 < M ? rem[r * M + n1] : 0.0f;
+    float u = used[r];
+    const float cap = vcap[r];
+    int c = (int)cur[r];
+    for (int t = 0; t < T; ++t) {
+        // ---- record: mask (get_action_mask), current node, free capacity, the remaining demands -------------------------------
+        const bool full = u >= cap;
+        const bool ok0 = n0 >= 1 && n0 < M && !((r0 == 0.0f) | full), ok1 = n1 < M && !((r1 == 0.0f) | full);
+        unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1);
+        const bool any_free = (b0 | b1) != 0ull;
+        if (!((c == 0) && any_free)) b0 |= 1ull;                         // the depot
+        const int64_t q = r * T + t;
+        if (lane == 0) {
+            *reinterpret_cast<uint4*>(bits + q * 4) = make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32));
+            idxA[q] = c;
+            sc[q] = cap - u;
+        }
+        rem_out[q * 128 + n0] = r0;
+        rem_out[q * 128 + n1] = r1;
+        // ---- SDVRPEnv._step: deliver min(remaining demand, free capacity) ---------------------------------------------------------
+        int a = __builtin_amdgcn_readfirstlane((int)actions[q]);
+        a = a < 0 ? 0 : (a > M - 1 ? M - 1 : a);
+        const float sel = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a < 64 ? r0 : r1), a & 63));
+        const float free_cap = cap - u;
+        const float delivered = sel < free_cap ? sel : free_cap;
+        u = (u + delivered) * (a != 0 ? 1.0f : 0.0f);
+        const float left = sel + (-delivered);
+        if (n0 == a) r0 = left;
+        if (n1 == a) r1 = left;
+        c = a;
+    }
+}
+
+int launch_replay_sdvrp(const float* rem, const float* used, const float* vcap, const int64_t* cur, const int64_t* actions,
+                        uint32_t* bits, int32_t* idxA, float* sc, float* rem_out, int64_t R, int M, int T, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_replay_sdvrp, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(EB), 0, st, rem, used, vcap, cur, actions, bits, idxA, sc, rem_out,
+                       R, M, T);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Rollout epilogue in one launch (TSP / CVRP): reward (k_tour_length), validity (k_check_solution) and the log-likelihood
 // (k_sum_logp) of a row by one wavefront, in exactly the orders of the three kernels it replaces.

@@ -96,6 +96,8 @@ int launch_sum_logp(const float* logp, int64_t ld, float* out, int64_t R, int T,
 int launch_rollout_finish(int env, const float* locs, const int64_t* actions, const float* logp, int64_t ld, const float* demand,
                           const float* vcap, float* reward, float* ll, int32_t* bad, int64_t R, int64_t B, int M, int T,
                           hipStream_t st);
+int launch_replay_sdvrp(const float* rem, const float* used, const float* vcap, const int64_t* cur, const int64_t* actions,
+                        uint32_t* bits, int32_t* idxA, float* sc, float* rem_out, int64_t R, int M, int T, hipStream_t st);
 int launch_replay_states(int env, const uint8_t* mask, const uint8_t* visited, const float* used, const float* vcap,
                          const int64_t* cur, const int64_t* istep, const float* time, const float* demand, const float* locs,
                          const float* tw, const float* dur, const int64_t* actions, uint32_t* bits, int32_t* idxA, float* sc,

@@ -51,6 +51,61 @@ __device__ __forceinline__ float group_sum(float v)
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// ---- SDVRP: the dynamic embedding (rl4co/models/nn/env_embeddings/dynamic.py:59-78) ---------------------------------------
+// Every step adds rem[n] * (wk | wv | wl) to row n of the glimpse key / value / logit key, rem = the remaining demands of the
+// row at that step (demand_with_depot).  The update is rank one, so it never touches the instance's K / V / Lp fragments:
+//   scores   s[n] += rem[n] (q~ . wk_h)                    heads_h += (sum_n a[n] rem[n]) wv_h
+//   logits   u[n] += rem[n] (heads . lw),  lw = wl folded through project_out like Lp
+// and in the backward  dheads += (sum_n du[n] rem[n]) lw,  da[n] += rem[n] (wv_h . dO_h),  dq~_h += (sum_n ds[n] rem[n]) wk_h,
+//   dlw += sum_q (sum_n du rem) heads_q,  dwv_h += sum_q (sum_n a rem) dO_h,  dwk_h += sum_q (sum_n ds rem) q~_h.
+// a.dyn = wk | wv | lw [3][E]; a.rem [R][T][RMP] (zero padded rows, recorded by eamrl_replay_states_sdvrp); a.ddyn accumulates.
+// A tile's rem rows are staged in LDS so that lane (query j, G) reads the keys of its accumulator registers, 16 kt + 4 r + G
+// (r = 0..3), as one float4: element (q, n) at q * 16 RTT + (n >> 4) * 16 + (n & 3) * 4 + ((n & 15) >> 2).
+constexpr int RMP = 128;
+
+// wk | wv live in LDS (DYNL[2][E], filled once per workgroup) and are read where they are used: the RTT = 7 backward kernels
+// have no registers to hold a lane's 16 entries across a tile (volatile: or the compiler hoists the reads and spills instead).
+__device__ __forceinline__ float lds_vread(const float* p)
+{
+    return *reinterpret_cast<const volatile __attribute__((address_space(3))) float*>((const __attribute__((address_space(3))) float*)p);
+}
+struct DynLane {
+    const float* base;      // DYNL
+    int h, G;
+    // [16 h + 4 i + G]: the layout of the staged q~ / dO operands;  [16 h + 4 G + r]: that of the dq~ / heads accumulators
+    __device__ __forceinline__ float wk_in(int i) const { return lds_vread(base + 16 * h + 4 * i + G); }
+    __device__ __forceinline__ float wv_in(int i) const { return lds_vread(base + RE + 16 * h + 4 * i + G); }
+    __device__ __forceinline__ float wk_out(int r) const { return lds_vread(base + 16 * h + 4 * G + r); }
+    __device__ __forceinline__ float wv_out(int r) const { return lds_vread(base + RE + 16 * h + 4 * G + r); }
+};
+__device__ __forceinline__ void fill_dyn_lds(const float* dyn, float* DYNL)     // (a barrier before the first use)
+{
+    for (int i = threadIdx.x; i < 2 * RE; i += blockDim.x) DYNL[i] = dyn[i];
+}
+// thread (query jq, float4 e4 of the row): rem[q][4 e4 .. 4 e4 + 3] -> the staged tile
+template <int RTT>
+__device__ __forceinline__ void stage_rem(float* REM, int jq, int e4, const float4& v, bool ok)
+{
+    if (e4 < 4 * RTT) {            // n = 4 e4 + i: key tile e4 >> 2, register e4 & 3, lane group i
+        float* p = REM + jq * (16 * RTT) + (e4 >> 2) * 16 + (e4 & 3);
+        p[0] = ok ? v.x : 0.0f; p[4] = ok ? v.y : 0.0f; p[8] = ok ? v.z : 0.0f; p[12] = ok ? v.w : 0.0f;
+    }
+}
+template <int RTT>
+__device__ __forceinline__ f32x4 rem_quad(const float* REM, int j, int kt, int G)
+{
+    const float4 v = *reinterpret_cast<const float4*>(REM + j * (16 * RTT) + kt * 16 + G * 4);
+    return (f32x4){v.x, v.y, v.z, v.w};
+}
+template <int RTT>
+__device__ __forceinline__ const float* rem_lane(const float* REM, int j, int G) { return REM + j * (16 * RTT) + G * 4; }
+__device__ __forceinline__ f32x4 rem_at(const float* remq, int kt)
+{
+    // (read through a volatile LDS pointer: otherwise the compiler keeps the value of the first read in a register for the later ones)
+    return *reinterpret_cast<const volatile __attribute__((address_space(3))) f32x4*>(
+        (const __attribute__((address_space(3))) float*)remq + kt * 16);
+}
+
 struct Q {        // the tile's query of this lane (query j = lane & 15)
     int64_t qi;   // r * T + t, or -1
     int64_t r;
@@ -126,9 +181,11 @@ __device__ __forceinline__ void load_head_frags(const ReevalArgs& a, int64_t b, 
 }
 
 // softmax weights of head h for the tile's queries: s[kt][r] <- w (unnormalised), returns 1 / Z (0 when nothing is feasible)
-template <int RTT>
+// DYN: remq = this lane's float4 column of the staged remaining demands (rem_lane), re-read at every use instead of held in 28
+// registers (the RTT = 7 backward kernels have none to spare)
+template <int RTT, bool DYN = false>
 __device__ __forceinline__ float head_softmax(const float (&kf)[RTT][4], const float* QT, int h, int lane, const uint4& mb, int M,
-                                              f32x4 (&s)[RTT])
+                                              f32x4 (&s)[RTT], const float* remq = nullptr, const DynLane* dl = nullptr)
 {
     const int j = lane & 15, G = lane >> 4;
     const float* qp = QT + j * TS + G * TG + 4 * h;
@@ -141,6 +198,15 @@ __device__ __forceinline__ float head_softmax(const float (&kf)[RTT][4], const f
     for (int kt = 0; kt < RTT; ++kt) s[kt] = mf(kf[kt][2], qhi.x, s[kt]);
 #pragma unroll
     for (int kt = 0; kt < RTT; ++kt) s[kt] = mf(kf[kt][3], qhi.y, s[kt]);
+    if (DYN) {
+        const float c = group_sum(fmaf(qhi.y, dl->wk_in(3), fmaf(qhi.x, dl->wk_in(2), fmaf(qlo.y, dl->wk_in(1), qlo.x * dl->wk_in(0)))));   // q~_h . wk_h
+#pragma unroll
+        for (int kt = 0; kt < RTT; ++kt) {
+            const f32x4 rv = rem_at(remq, kt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][r] = fmaf(rv[r], c, s[kt][r]);
+        }
+    }
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < RTT; ++kt)
@@ -167,16 +233,30 @@ __device__ __forceinline__ float head_softmax(const float (&kf)[RTT][4], const f
 }
 
 // heads tile of all heads -> HT (A layout): wave h computes head h
-template <int RTT>
+template <int RTT, bool DYN = false>
 __device__ __forceinline__ void glimpse_tile(const float (&kf)[RTT][4], const float (&vtf)[4 * RTT], const float* QT, float* HT,
-                                             int h, int lane, const uint4& mb, int M)
+                                             int h, int lane, const uint4& mb, int M, const float* REM = nullptr,
+                                             const DynLane* dl = nullptr)
 {
     const int j = lane & 15, G = lane >> 4;
     f32x4 s[RTT];
-    const float iz = head_softmax<RTT>(kf, QT, h, lane, mb, M, s);
+    const float* remq = DYN ? rem_lane<RTT>(REM, j, G) : nullptr;
+    const float iz = head_softmax<RTT, DYN>(kf, QT, h, lane, mb, M, s, remq, dl);
     f32x4 o = z4();
 #pragma unroll
     for (int t = 0; t < 4 * RTT; ++t) o = mf(vtf[t], s[t >> 2][t & 3], o);
+    if (DYN) {
+        float ra = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < RTT; ++kt) {
+            const f32x4 rv = rem_at(remq, kt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ra = fmaf(s[kt][r], rv[r], ra);
+        }
+        ra = group_sum(ra);                        // sum_n w[n] rem[n] (unnormalised, like o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaf(ra, dl->wv_out(r), o[r]);
+    }
     float* hp = HT + j * TS + 4 * h + G;           // element (j, c = 16 h + 4 G + r) -> (g = r, t = 4 h + G)
 #pragma unroll
     for (int r = 0; r < 4; ++r) hp[r * TG] = o[r] * iz;
@@ -197,6 +277,35 @@ __device__ __forceinline__ f32x4 logit_tile(const float (&lpf)[32], const float*
         u = mf(lpf[4 * g4 + 3], hi.y, u);
     }
     return u;
+}
+
+// DYN: also hl = heads[j] . lw for the lane's query (lw_in[4 g4 + i] = lw[16 g4 + 4 i + G], the staged heads' layout; registers in
+// the forward kernel, an LDS copy [G][32] in the backward one, which has none to spare)
+template <typename LW>
+__device__ __forceinline__ f32x4 logit_tile_dyn(const float (&lpf)[32], const float* HT, int lane, const LW& lw_in, float& hl)
+{
+    const int j = lane & 15, G = lane >> 4;
+    const float* hp = HT + j * TS + G * TG;
+    f32x4 u = z4();
+    float acc = 0.0f;
+#pragma unroll
+    for (int g4 = 0; g4 < 8; ++g4) {
+        const float2 lo = *reinterpret_cast<const float2*>(hp + 4 * g4), hi = *reinterpret_cast<const float2*>(hp + 4 * g4 + 2);
+        u = mf(lpf[4 * g4 + 0], lo.x, u);
+        u = mf(lpf[4 * g4 + 1], lo.y, u);
+        u = mf(lpf[4 * g4 + 2], hi.x, u);
+        u = mf(lpf[4 * g4 + 3], hi.y, u);
+        acc = fmaf(hi.y, lw_in[4 * g4 + 3], fmaf(hi.x, lw_in[4 * g4 + 2], fmaf(lo.y, lw_in[4 * g4 + 1], fmaf(lo.x, lw_in[4 * g4], acc))));
+    }
+    hl = group_sum(acc);
+    return u;
+}
+__device__ __forceinline__ void load_lw_in(const float* dyn, int G, float (&lw_in)[32])
+{
+#pragma unroll
+    for (int g4 = 0; g4 < 8; ++g4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lw_in[4 * g4 + i] = dyn[2 * RE + 16 * g4 + 4 * i + G];
 }
 
 __device__ __forceinline__ void load_lp_frags(const ReevalArgs& a, int64_t b, int kt, int lane, float (&lpf)[32])
@@ -227,11 +336,13 @@ __device__ __forceinline__ float process_logit(float u, float clip, float inv_te
 // forward: logp[r][t], lse[r][t]
 // ---------------------------------------------------------------------------------------------------------------------
 // HEADS: the rollout's glimpse outputs (eamrl_reeval.heads) are staged instead of recomputed (training: the entropy pass)
-template <int RTT, bool HEADS>
+template <int RTT, bool HEADS, bool DYN = false>
 __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
 {
     __shared__ __attribute__((aligned(16))) float QT[16 * TS];
     __shared__ __attribute__((aligned(16))) float HT[16 * TS];
+    __shared__ __attribute__((aligned(16))) float REM[DYN ? 16 * 16 * RTT : 4];
+    __shared__ float DYNL[DYN ? 2 * RE : 4];
     __shared__ float RED[8][16], RED2[8][16], RED3[8][16], ZA[16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -242,13 +353,25 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
     const int64_t nq = (int64_t)(s1 - s0) * a.T;
     const int64_t ntiles = (nq + 15) / 16;
 
-    float kf[RTT][4], vtf[4 * RTT], lpf[32];
+    float kf[RTT][4], vtf[4 * RTT], lpf[32], lw_in[32];
+    const DynLane dl = {DYNL, wv, G};
     if (!HEADS) load_head_frags<RTT>(a, b, wv, lane, kf, vtf);
     if (wv < RTT) load_lp_frags(a, b, wv, lane, lpf);
+    if (DYN) {
+        fill_dyn_lds(a.dyn, DYNL);
+        load_lw_in(a.dyn, G, lw_in);
+    }
     const float inv_temp = 1.0f / a.temp;
 
     for (int64_t tile = 0; tile < ntiles; ++tile) {
         if (!HEADS) build_query_tile(a, b, s0, nq, tile, QT);
+        if (DYN) {      // (the previous tile's readers of REM finished before its last barrier)
+            const int jq = threadIdx.x >> 5, e4 = threadIdx.x & 31;
+            const Q qq = tile_query(a, b, s0, nq, tile, jq);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qq.qi >= 0) v = *reinterpret_cast<const float4*>(a.rem + qq.qi * RMP + 4 * e4);
+            stage_rem<RTT>(REM, jq, e4, v, qq.qi >= 0);
+        }
         const Q q = tile_query(a, b, s0, nq, tile, j);
         uint4 mb = make_uint4(0, 0, 0, 0);
         int act = -1;
@@ -268,13 +391,22 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
             hp[0] = v.x; hp[TG] = v.y; hp[2 * TG] = v.z; hp[3 * TG] = v.w;
         } else {
             __syncthreads();
-            glimpse_tile<RTT>(kf, vtf, QT, HT, wv, lane, mb, a.M);
+            glimpse_tile<RTT, DYN>(kf, vtf, QT, HT, wv, lane, mb, a.M, REM, &dl);
         }
         __syncthreads();
         f32x4 z = z4();
         float mx = -INFINITY;
         if (wv < RTT) {
-            const f32x4 u = logit_tile(lpf, HT, lane);
+            f32x4 u;
+            if (DYN) {
+                float hl;
+                u = logit_tile_dyn(lpf, HT, lane, lw_in, hl);
+                const f32x4 rw = rem_quad<RTT>(REM, j, wv, G);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) u[r] = fmaf(rw[r], hl, u[r]);
+            } else {
+                u = logit_tile(lpf, HT, lane);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n0 = 16 * wv + 4 * r;
@@ -332,7 +464,8 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
 template <int RTT>
 static int launch_fwd_t(const ReevalArgs& a, hipStream_t st)
 {
-    if (a.heads) hipLaunchKernelGGL((k_reeval_fwd<RTT, true>), dim3((unsigned)(a.B * a.nchunk)), dim3(512), 0, st, a);
+    if (a.dyn) hipLaunchKernelGGL((k_reeval_fwd<RTT, false, true>), dim3((unsigned)(a.B * a.nchunk)), dim3(512), 0, st, a);
+    else if (a.heads) hipLaunchKernelGGL((k_reeval_fwd<RTT, true>), dim3((unsigned)(a.B * a.nchunk)), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((k_reeval_fwd<RTT, false>), dim3((unsigned)(a.B * a.nchunk)), dim3(512), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
@@ -373,7 +506,7 @@ struct QWalk {          // query l = first, first + 16, ... of the chunk as (sta
 // (the pending-load state merges over the skipped branch), which serialises the prefetch.  Queries past the end of the
 // chunk read query 0 / node 0 instead and are masked by `fl` when the tile is staged.
 struct RowPre {
-    float4 pa, pb, dh;
+    float4 pa, pb, dh, rem;     // rem: SDVRP only (the row's remaining demands, float4 e4)
     float sc[2];        // state scalars (NC <= 2)
     int fl;             // bit 0: query exists, 1: idxA names a node, 2: idxB names a node, 3: step >= tstart
 };
@@ -385,10 +518,11 @@ __device__ __forceinline__ void load_idx(const ReevalArgs& a, int qi, int& ia, i
     ib = a.idxB ? a.idxB[q] : -1;
 }
 
-template <bool DH>
+template <bool DH, bool DYN = false>
 __device__ __forceinline__ void load_rows(const ReevalArgs& a, int64_t b, int e4, int qi, int t, int ia, int ib, RowPre& p)
 {
     const int q = max(qi, 0);
+    if (DYN) p.rem = *reinterpret_cast<const float4*>(a.rem + (int64_t)q * RMP + 4 * e4);
     p.fl = (qi >= 0 ? 1 : 0) | (ia >= 0 ? 2 : 0) | (ib >= 0 ? 4 : 0) | (t >= a.tstart ? 8 : 0);
     p.pa = *reinterpret_cast<const float4*>(a.Pa + (b * a.M + max(ia, 0)) * a.ld + 4 * e4);
     p.pb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -430,7 +564,7 @@ __device__ __forceinline__ uint4 load_mask_words(const ReevalArgs& a, int qi)
     return qi >= 0 ? m : make_uint4(0, 0, 0, 0);
 }
 
-template <int RTT, bool HEADS>
+template <int RTT, bool HEADS, bool DYN = false>
 __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -440,6 +574,8 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
     float* CV = LPT + 8 * RTT * 256;                // [2][128] state-column vectors
     float* DU = CV + 2 * RE;                        // [16 RTT][DS]
     float* LSE = DU + 16 * RTT * DS;                // [16]
+    float* SDR = LSE + 16;                          // DYN: [2][16]  sum_n du[q][n] rem[q][n], summed over the key tiles (LDS atomics)
+    float* REMB = SDR + 32;                         // DYN: [2][16][16 RTT]  staged remaining demands
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, G = lane >> 4;
@@ -453,9 +589,19 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
     // rollout kernels' arithmetic), and the normaliser is recovered as z[action] - logp, one extra LDS hand-off per tile
     const bool derive_lse = a.lse == nullptr;
 
-    float kf[RTT][4], vtf[4 * RTT], lpf[32];
+    float kf[RTT][4], vtf[4 * RTT], lpf[32], lw_out[4] = {0.f, 0.f, 0.f, 0.f}, dlw_acc = 0.0f;
+    float* LWL = REMB + 2 * 16 * 16 * RTT;         // DYN: [4 lane groups][32]  lw in the staged heads' layout
+    float* DYNL = LWL + 128;                        // DYN: [2][E]  wk | wv
+    const float* lw_in = LWL + 32 * G;
+    const DynLane dl = {DYNL, wv, G};
     if (!HEADS) load_head_frags<RTT>(a, b, wv, lane, kf, vtf);
     load_lp_frags(a, b, wv < RTT ? wv : RTT - 1, lane, lpf);       // (wave 7 of RTT = 7 computes no logits)
+    if (DYN) {
+        fill_dyn_lds(a.dyn, DYNL);
+        if (tid < 128) LWL[tid] = a.dyn[2 * RE + 16 * ((tid & 31) >> 2) + 4 * (tid & 3) + (tid >> 5)];     // (visible after the CV barrier)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lw_out[r] = a.dyn[2 * RE + 16 * wv + 4 * G + r];      // the dheads accumulator's columns
+    }
     float4* lpt = reinterpret_cast<float4*>(LPT) + wv * RTT * 64 + lane;
 #pragma unroll
     for (int t4 = 0; t4 < RTT; ++t4) {              // Lp^T: row e = 16 wv + j, k index = key 4 t + G, t = 4 t4 + i
@@ -503,9 +649,10 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
             stage_heads(pre, 0);
         } else {
             load_idx(a, qr, ia, ib);
-            load_rows<false>(a, b, e4, qr, wr.t, ia, ib, pre);
+            load_rows<false, DYN>(a, b, e4, qr, wr.t, ia, ib, pre);
             __syncthreads();            // CV
             stage_rows<false>(pre, gc, CV, QTB, nullptr, jq, e4);
+            if (DYN) stage_rem<RTT>(REMB, jq, e4, pre.rem, pre.fl & 1);
         }
     }
     wr.next(T);
@@ -528,7 +675,7 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
                 load_heads(wr, pre);                                // heads rows of tile + 1
                 wr.next(T);
             } else {
-                load_rows<false>(a, b, e4, qr, wr.t, ia, ib, pre);  // rows of tile + 1 (indices fetched one iteration ago)
+                load_rows<false, DYN>(a, b, e4, qr, wr.t, ia, ib, pre);  // rows of tile + 1 (indices fetched one iteration ago)
                 wr.next(T);
                 qr = qi_of(wr);
                 load_idx(a, qr, ia, ib);                            // indices of tile + 2
@@ -541,9 +688,20 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
             qjn = qi_of(wj);
             tjn = wj.t;
             mbn = load_mask_words(a, qjn);
+            if (DYN && tid < 16) SDR[cur * 16 + tid] = 0.0f;       // (its last readers were two iterations ago)
             __syncthreads();            // heads of this tile complete; the previous tile's du has been consumed
-            f32x4 u = z4();
-            if (wv < RTT) u = logit_tile(lpf, HT, lane);
+            f32x4 u = z4(), rw = z4();
+            if (wv < RTT) {
+                if (DYN) {
+                    float hl;
+                    u = logit_tile_dyn(lpf, HT, lane, lw_in, hl);
+                    rw = rem_quad<RTT>(REMB + cur * 16 * 16 * RTT, j, wv, G);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) u[r] = fmaf(rw[r], hl, u[r]);
+                } else {
+                    u = logit_tile(lpf, HT, lane);
+                }
+            }
             const int act = qj >= 0 ? act_l : -1;
             const float g = live ? g_l : 0.0f;
             float lse = live ? lse_l : 0.0f;
@@ -562,6 +720,7 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
                 if (g != 0.0f) lse = LSE[j];
             }
             if (wv < RTT) {
+                float sdr = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n0 = 16 * wv + 4 * r;
@@ -573,10 +732,16 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
                         du = g * ((n0 + G == act ? 1.0f : 0.0f) - p) * dz[r];
                     }
                     DU[(n0 + G) * DS + j] = du;
+                    if (DYN) sdr = fmaf(du, rw[r], sdr);
+                }
+                if (DYN) {
+                    sdr = group_sum(sdr);
+                    if (G == 0) atomicAdd(&SDR[cur * 16 + j], sdr);
                 }
             }
             if (HEADS) stage_heads(pre, nxt);
             else stage_rows<false>(pre, gc, CV, QTB + nxt * 16 * TS, nullptr, jq, e4);
+            if (DYN) stage_rem<RTT>(REMB + nxt * 16 * 16 * RTT, jq, e4, pre.rem, pre.fl & 1);
             __syncthreads();            // du of this tile and q~ of the next one visible
             // wave wv: embedding columns 16 wv .. 16 wv + 15
             f32x4 dh = z4();
@@ -588,12 +753,21 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
                 dh = mf(ll.z, DU[(16 * t4 + 8 + G) * DS + j], dh);
                 dh = mf(ll.w, DU[(16 * t4 + 12 + G) * DS + j], dh);
             }
+            if (DYN) {                  // dheads += (sum_n du rem) lw
+                const float sq = SDR[cur * 16 + j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dh[r] = fmaf(sq, lw_out[r], dh[r]);
+            }
             if (qj >= 0)
                 *reinterpret_cast<float4*>(a.dheads + (int64_t)qj * RE + 16 * wv + 4 * G) = make_float4(dh[0], dh[1], dh[2], dh[3]);
             float hb[4];
             const int c = 16 * wv + j;
 #pragma unroll
             for (int t = 0; t < 4; ++t) hb[t] = HT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
+            if (DYN) {                  // dlw[c] += sum_q (sum_n du rem)[q] heads[q][c], this lane: the queries 4 t + G
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dlw_acc = fmaf(SDR[cur * 16 + 4 * t + G], hb[t], dlw_acc);
+            }
 #pragma unroll
             for (int nt = 0; nt < RTT; ++nt)
 #pragma unroll
@@ -602,7 +776,12 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
             __syncthreads();            // q~ of tile 0 visible
         }
         mb = mbn; qj = qjn; tj = tjn;
-        if (!HEADS && tile + 1 < ntiles) glimpse_tile<RTT>(kf, vtf, QTB + nxt * 16 * TS, HTB + nxt * 16 * TS, wv, lane, mb, a.M);
+        if (!HEADS && tile + 1 < ntiles)
+            glimpse_tile<RTT, DYN>(kf, vtf, QTB + nxt * 16 * TS, HTB + nxt * 16 * TS, wv, lane, mb, a.M, REMB + nxt * 16 * 16 * RTT, &dl);
+    }
+    if (DYN) {
+        dlw_acc = group_sum(dlw_acc);
+        if (G == 0) atomicAdd(a.ddyn + 2 * RE + 16 * wv + j, dlw_acc);
     }
     // dLp: lane (column 16 wv + j, G), register r -> key 16 nt + 4 G + r
 #pragma unroll
@@ -621,14 +800,19 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
 //   dV += a^T dO,  dK += ds^T q~   (accumulators: lane (column 16 h + j, G), register r -> key 16 nt + 4 G + r).
 // QT / DHT: the staged q~ and dO tiles (A layout); stg: this wave's 4 x 256-float transposition rows; ktl: this lane's K^T
 // fragments in LDS ([t4] at stride 64 float4).
-template <int RTT, typename StoreDq>
+// DYN (SDVRP, see DynLane): REM = the tile's staged remaining demands, srw = 32 wave-private LDS floats, dwk / dwv = this lane's
+// running sums of the gradients of wk[16 h + j] / wv[16 h + j] over the queries 4 t + G
+template <int RTT, bool DYN = false, typename StoreDq>
 __device__ __forceinline__ void attention_bwd_tile(const float (&kf)[RTT][4], const float (&vaf)[RTT][4], const float4* ktl,
                                                    const float* QT, const float* DHT, float* stg, int h, int lane,
-                                                   const uint4& mb, int M, f32x4 (&dV)[RTT], f32x4 (&dK)[RTT], StoreDq store_dq)
+                                                   const uint4& mb, int M, f32x4 (&dV)[RTT], f32x4 (&dK)[RTT], StoreDq store_dq,
+                                                   const float* REM = nullptr, const DynLane* dl = nullptr, float* srw = nullptr,
+                                                   float* dwk = nullptr, float* dwv = nullptr)
 {
     const int j = lane & 15, G = lane >> 4;
     f32x4 s[RTT], da[RTT];
-    const float iz = head_softmax<RTT>(kf, QT, h, lane, mb, M, s);
+    const float* remq = DYN ? rem_lane<RTT>(REM, j, G) : nullptr;
+    const float iz = head_softmax<RTT, DYN>(kf, QT, h, lane, mb, M, s, remq, dl);
     const float* dp = DHT + j * TS + G * TG + 4 * h;
     const float2 dlo = *reinterpret_cast<const float2*>(dp), dhi = *reinterpret_cast<const float2*>(dp + 2);
 #pragma unroll
@@ -639,19 +823,43 @@ __device__ __forceinline__ void attention_bwd_tile(const float (&kf)[RTT][4], co
     for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][2], dhi.x, da[kt]);
 #pragma unroll
     for (int kt = 0; kt < RTT; ++kt) da[kt] = mf(vaf[kt][3], dhi.y, da[kt]);
-    float rs = 0.0f;
+    if (DYN) {                                       // da[n] += rem[n] (wv_h . dO_h)
+        const float e1 = group_sum(fmaf(dhi.y, dl->wv_in(3), fmaf(dhi.x, dl->wv_in(2), fmaf(dlo.y, dl->wv_in(1), dlo.x * dl->wv_in(0)))));
 #pragma unroll
-    for (int kt = 0; kt < RTT; ++kt)
+        for (int kt = 0; kt < RTT; ++kt) {
+            const f32x4 rv = rem_at(remq, kt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) da[kt][r] = fmaf(rv[r], e1, da[kt][r]);
+        }
+    }
+    float rs = 0.0f, ar = 0.0f, sr = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < RTT; ++kt) {
+        f32x4 rv = z4();
+        if (DYN) rv = rem_at(remq, kt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             s[kt][r] *= iz;                          // a
             rs = fmaf(s[kt][r], da[kt][r], rs);
+            if (DYN) ar = fmaf(s[kt][r], rv[r], ar);
         }
+    }
     rs = group_sum(rs);
 #pragma unroll
-    for (int kt = 0; kt < RTT; ++kt)
+    for (int kt = 0; kt < RTT; ++kt) {
+        f32x4 rv = z4();
+        if (DYN) rv = rem_at(remq, kt);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) da[kt][r] = s[kt][r] * (da[kt][r] - rs);      // ds
+        for (int r = 0; r < 4; ++r) {
+            da[kt][r] = s[kt][r] * (da[kt][r] - rs);      // ds
+            if (DYN) sr = fmaf(da[kt][r], rv[r], sr);
+        }
+    }
+    if (DYN) {
+        ar = group_sum(ar);                          // sum_n a[n] rem[n]
+        sr = group_sum(sr);                          // sum_n ds[n] rem[n]
+        if (G == 0) { srw[j] = sr; srw[16 + j] = ar; }
+    }
     // staging of key tile 0 (element (key kappa, query q) of a tile at kappa * 16 + (q & 3) * 4 + (q >> 2))
     float* wp = stg + G * 16 + (j & 3) * 4 + (j >> 2);
 #pragma unroll
@@ -668,6 +876,10 @@ __device__ __forceinline__ void attention_bwd_tile(const float (&kf)[RTT][4], co
         dq = mf(kk.z, da[t4][2], dq);
         dq = mf(kk.w, da[t4][3], dq);
     }
+    if (DYN) {                                       // dq~_h += (sum_n ds rem) wk_h
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dq[r] = fmaf(sr, dl->wk_out(r), dq[r]);
+    }
     store_dq(dq);
     // B operands of the two "sum over queries" products: dO_h [q][e] and q~_h [q][d], column j, k index q = 4 t + G
     float dhb[4], qb[4];
@@ -676,6 +888,14 @@ __device__ __forceinline__ void attention_bwd_tile(const float (&kf)[RTT][4], co
     for (int t = 0; t < 4; ++t) {
         dhb[t] = DHT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
         qb[t] = QT[(4 * t + G) * TS + (c & 3) * TG + (c >> 2)];
+    }
+    if (DYN) {          // dwk[c] += sum_q (sum_n ds rem)[q] q~[q][c],  dwv[c] += sum_q (sum_n a rem)[q] dO[q][c]
+        __builtin_amdgcn_wave_barrier();            // srw: written above by this wavefront (LDS keeps a wave's accesses in order)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            *dwk = fmaf(srw[4 * t + G], qb[t], *dwk);
+            *dwv = fmaf(srw[16 + 4 * t + G], dhb[t], *dwv);
+        }
     }
 #pragma unroll
     for (int nt = 0; nt < RTT; ++nt) {
@@ -720,7 +940,7 @@ __device__ __forceinline__ void attention_bwd_tile(const float (&kf)[RTT][4], co
 // (Round-2 history: with the gathers, two barriers and an LDS-atomic scatter inside the loop this kernel took 37.3 ms at the
 //  POMO training size; 15.6 ms now, plus 2.0 ms of k_reeval_bwd_gather.)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int RTT>
+template <int RTT, bool DYN = false>
 __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -729,6 +949,9 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
     float* STG = DHB + 2 * 16 * TS;                 // [8 waves][2 parities][a | ds][16 keys][16 queries]
     float* KTL = STG + 8 * 4 * 256;                 // [8 waves][RTT][64 lanes][4]  K^T fragments of the dq~ product
     float* CV = KTL + 8 * RTT * 256;                // [2][128] state-column vectors
+    float* SRW = CV + 2 * RE;                       // DYN: [8 waves][32]  per-query sums of the tile, wave-private
+    float* REMB = SRW + 8 * 32;                     // DYN: [2][16][16 RTT]  staged remaining demands
+    float* DYNL = REMB + 2 * 16 * 16 * RTT;         // DYN: [2][E]  wk | wv
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, G = lane >> 4, pi = 4 * (j & 3) + (j >> 2);
@@ -768,6 +991,9 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
     f32x4 dV[RTT], dK[RTT];
 #pragma unroll
     for (int nt = 0; nt < RTT; ++nt) { dV[nt] = z4(); dK[nt] = z4(); }
+    const DynLane dl = {DYNL, h, G};
+    float dwk_acc = 0.0f, dwv_acc = 0.0f;
+    if (DYN) fill_dyn_lds(a.dyn, DYNL);             // (visible after the prologue's barrier)
 
     // query index r * T + t as a 32-bit value (R * T < 2^31 is checked by the caller), -1 past the chunk's end
     auto qi_of = [&](const QWalk& w) -> int { return w.sl < ns ? ((s0 + w.sl) * (int)a.B + (int)b) * T + w.t : -1; };
@@ -778,7 +1004,7 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
     int qr = qi_of(wr), ia, ib;
     load_idx(a, qr, ia, ib);
     RowPre pre;
-    load_rows<true>(a, b, e4, qr, wr.t, ia, ib, pre);
+    load_rows<true, DYN>(a, b, e4, qr, wr.t, ia, ib, pre);
     wr.next(T);
     qr = qi_of(wr);
     load_idx(a, qr, ia, ib);
@@ -789,8 +1015,9 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
     for (int tile = 0; tile < ntiles; ++tile) {
         const int cur = tile & 1;
         stage_rows<true>(pre, gc, CV, QTB + cur * 16 * TS, DHB + cur * 16 * TS, jq, e4);
+        if (DYN) stage_rem<RTT>(REMB + cur * 16 * 16 * RTT, jq, e4, pre.rem, pre.fl & 1);
         // rows of tile + 1 (their indices arrived during the previous tile), indices of tile + 2, mask words of tile + 1
-        load_rows<true>(a, b, e4, qr, wr.t, ia, ib, pre);
+        load_rows<true, DYN>(a, b, e4, qr, wr.t, ia, ib, pre);
         wr.next(T);
         qr = qi_of(wr);
         load_idx(a, qr, ia, ib);
@@ -802,11 +1029,19 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
         __syncthreads();
         const float* QT = QTB + cur * 16 * TS;
         const float* DHT = DHB + cur * 16 * TS;
-        attention_bwd_tile<RTT>(kf, vaf, ktl, QT, DHT, stg, h, lane, mb_cur, a.M, dV, dK, [&](const f32x4& dq) {
+        attention_bwd_tile<RTT, DYN>(kf, vaf, ktl, QT, DHT, stg, h, lane, mb_cur, a.M, dV, dK, [&](const f32x4& dq) {
             if (qj_cur >= 0)        // dq~ takes the place of the tile's dheads row (read one tile ahead)
                 *reinterpret_cast<float4*>(a.dheads + (int64_t)qj_cur * RE + 16 * h + 4 * G) =
                     make_float4(0.25f * dq[0], 0.25f * dq[1], 0.25f * dq[2], 0.25f * dq[3]);
-        });
+        }, REMB + cur * 16 * 16 * RTT, &dl, SRW + wv * 32, &dwk_acc, &dwv_acc);
+    }
+    if (DYN) {
+        dwk_acc = group_sum(dwk_acc);
+        dwv_acc = group_sum(dwv_acc);
+        if (G == 0) {
+            atomicAdd(a.ddyn + 16 * h + j, dwk_acc);
+            atomicAdd(a.ddyn + RE + 16 * h + j, dwv_acc);
+        }
     }
 #pragma unroll
     for (int nt = 0; nt < RTT; ++nt)
@@ -932,14 +1167,15 @@ template <int RTT>
 static int launch_bwd_t(const ReevalArgs& a, hipStream_t st)
 {
     const unsigned grid = (unsigned)(a.B * a.nchunk);
-    const size_t ldl = (4 * 16 * (size_t)TS + 8 * RTT * 256 + 2 * RE + 16 * RTT * DS + 16) * sizeof(float);
-    auto kl = a.heads ? k_reeval_bwd_logits<RTT, true> : k_reeval_bwd_logits<RTT, false>;
+    const bool dyn = a.dyn != nullptr;
+    const size_t ldl = (4 * 16 * (size_t)TS + 8 * RTT * 256 + 2 * RE + 16 * RTT * DS + 16 + 32 + (dyn ? 2 * 16 * 16 * RTT + 128 + 2 * RE : 0)) * sizeof(float);
+    auto kl = dyn ? k_reeval_bwd_logits<RTT, false, true> : a.heads ? k_reeval_bwd_logits<RTT, true> : k_reeval_bwd_logits<RTT, false>;
     if (ldl > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldl) != hipSuccess)
         return EAMRL_E_LAUNCH;
     hipLaunchKernelGGL(kl, dim3(grid), dim3(512), ldl, st, a);
-    const size_t lds = (4 * 16 * (size_t)TS + 8 * 4 * 256 + 8 * RTT * 256 + 2 * RE) * sizeof(float);
-    auto k = k_reeval_bwd_glimpse<RTT>;
+    const size_t lds = (4 * 16 * (size_t)TS + 8 * 4 * 256 + 8 * RTT * 256 + 2 * RE + 8 * 32 + (dyn ? 2 * 16 * 16 * RTT + 2 * RE : 0)) * sizeof(float);
+    auto k = dyn ? k_reeval_bwd_glimpse<RTT, true> : k_reeval_bwd_glimpse<RTT, false>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return EAMRL_E_LAUNCH;

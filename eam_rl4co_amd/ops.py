@@ -459,6 +459,25 @@ def replay_states(st, actions, B):
     return bits, idxA, sc
 
 
+def replay_states_sdvrp(st, actions):
+    """SDVRP: as replay_states, plus the remaining demands rem [R, T, 128] (zero padded rows) before every step -- what the
+    dynamic embedding multiplies (eamrl_replay_states_sdvrp)."""
+    lib = _lib.load()
+    _chk(actions, "actions", torch.int64)
+    R, T = actions.shape
+    if R != st.R or st.env_name != "sdvrp" or st.M > 128:
+        raise ValueError("replay_states_sdvrp: an sdvrp state of at most 128 nodes, one action row per state row")
+    dev = actions.device
+    bits = torch.empty(R, T, 4, dtype=torch.int32, device=dev)
+    idxA = torch.empty(R, T, dtype=torch.int32, device=dev)
+    sc = torch.empty(1, R, T, dtype=torch.float32, device=dev)
+    rem = torch.empty(R, T, 128, dtype=torch.float32, device=dev)
+    ss = st.struct()
+    _lib.check(lib.eamrl_replay_states_sdvrp(C.byref(ss), R, st.M, _ptr(actions), T, _ptr(bits), _ptr(idxA), _ptr(sc), _ptr(rem),
+                                             _stream(actions)), "eamrl_replay_states_sdvrp")
+    return bits, idxA, sc, rem
+
+
 def tsp_mask_bits(actions, M):
     lib = _lib.load()
     _chk(actions, "actions", torch.int64)
@@ -475,7 +494,7 @@ class ReevalPlan:
     None; idxA / idxB int32 [R, T]; sc [NC, R, T]; maskbits int32 [R, T, 4]; actions int64 [R, T]."""
 
     def __init__(self, buf, has_pb, gctx, cvec, idxA, idxB, sc, maskbits, actions, S, tstart, clip, temp, rollout_logp=None,
-                 slots=None, E=None, want_entropy=False, rollout_heads=None):
+                 slots=None, E=None, want_entropy=False, rollout_heads=None, rem=None, dyn=None):
         _chk(buf, "operands", torch.float32)
         # slots: {"K", "V", "Lp", "Pa"[, "Pb"]} -> E-wide column block of buf (default: side by side in that order); with it
         # the plan reads a decoder cache (ops.DecodeCache.buf) in place
@@ -506,6 +525,13 @@ class ReevalPlan:
         # forward pass is needed for the gradient: forward() hands them back and the backward recovers the normaliser.
         # rollout_heads [R, Th, E]: every decode step's glimpse output as the rollout kernel computed it (RolloutState.heads):
         # the backward reads them instead of recomputing the glimpse (row r, step t at [r, t - tstart])
+        # SDVRP: rem [R, T, 128] remaining demands per (row, step), dyn [3, E] = wk | wv | lw of the dynamic embedding
+        self.rem = self.dyn = None
+        if dyn is not None:
+            _chk(rem, "remaining demands", torch.float32, (R, T, 128))
+            _chk(dyn, "dynamic embedding vectors", torch.float32, (3, self.E))
+            self.rem, self.dyn = rem, dyn
+            rollout_heads = None        # (the kernels recompute the glimpse for this env)
         self.heads = None
         if rollout_heads is not None:
             _chk(rollout_heads, "rollout heads", torch.float32)
@@ -536,6 +562,8 @@ class ReevalPlan:
         s.entropy = _ptr(self.entropy)
         if self.heads is not None:
             s.heads, s.heads_T = _ptr(self.heads), self.heads.shape[1]
+        if self.dyn is not None:
+            s.rem, s.dyn = _ptr(self.rem), _ptr(self.dyn)
         return s
 
     def forward(self):
@@ -570,6 +598,8 @@ class ReevalPlan:
         s.dPb = C.c_void_p(base + 4 * E4) if self.has_pb else None
         s.ldg = dbuf.shape[2]
         s.dgctx, s.dCvec = _ptr(dg), _ptr(dc)
+        self.ddyn = torch.zeros_like(self.dyn) if self.dyn is not None else None      # read by the caller (SDVRP)
+        s.ddyn = _ptr(self.ddyn)
         _lib.check(lib.eamrl_reeval_backward(C.byref(s), _stream(self.buf)), "eamrl_reeval_backward")
         return dbuf, dg, dc
 

@@ -625,7 +625,7 @@ class _ChunkedReeval(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------------
 # native (HIP) re-evaluation: forward and backward of all decode steps on fp32 MFMA (csrc/reeval.hip)
 # ------------------------------------------------------------------------------------------------------------
-_NATIVE_ENVS = ("tsp", "cvrp", "pctsp", "op", "cvrptw")
+_NATIVE_ENVS = ("tsp", "cvrp", "pctsp", "op", "cvrptw", "sdvrp")
 
 
 def native_reeval_supported(policy, M: int) -> bool:
@@ -668,6 +668,10 @@ def replay_states(policy, td, actions, S: int, multistart: bool):
         return dict(maskbits=bits, idxA=first, idxB=prev.contiguous(), sc=sc, tstart=1 if multistart else 0,
                     placeholder=placeholder)
     B = td["action_mask"].shape[0]
+    if env_name == "sdvrp":     # + the remaining demands of every step (the dynamic embedding's input)
+        st = state_from_td(env_name, td, S, copy=False)
+        bits, idxA, sc, rem = ops.replay_states_sdvrp(st, actions)
+        return dict(maskbits=bits, idxA=idxA, idxB=None, sc=sc, tstart=1 if multistart else 0, placeholder=False, rem=rem)
     if os.environ.get("EAMRL_REPLAY_LOOP", "0") != "1":        # one launch: the env's transitions replayed inside a kernel
         st = state_from_td(env_name, td, S, copy=False)         # read-only
         bits, idxA, sc = ops.replay_states(st, actions, B)
@@ -694,7 +698,7 @@ class _NativeReeval(torch.autograd.Function):
     """logp [R, T] = eamrl_reeval_forward(K, V, Lp, Pa, Pb, gctx, cvec | replayed states); backward = eamrl_reeval_backward."""
 
     @staticmethod
-    def forward(ctx, K, V, Lp, Pa, Pb, gctx, cvec, meta):
+    def forward(ctx, K, V, Lp, Pa, Pb, gctx, cvec, meta, dyn=None):
         from . import ops
 
         parts = [K, V, Lp, Pa] + ([Pb] if Pb is not None else [])
@@ -702,9 +706,10 @@ class _NativeReeval(torch.autograd.Function):
         plan = ops.ReevalPlan(buf, Pb is not None, None if gctx is None else gctx.detach().contiguous(),
                               None if cvec is None else cvec.detach().contiguous(), meta["idxA"], meta["idxB"], meta["sc"],
                               meta["maskbits"], meta["actions"], meta["S"], meta["tstart"], meta["clip"], meta["temp"],
-                              rollout_logp=meta.get("rollout_logp"), rollout_heads=meta.get("rollout_heads"))
+                              rollout_logp=meta.get("rollout_logp"), rollout_heads=meta.get("rollout_heads"),
+                              rem=meta.get("rem"), dyn=None if dyn is None else dyn.detach().contiguous())
         ctx.plan = plan
-        ctx.has = (Pb is not None, gctx is not None, cvec is not None)
+        ctx.has = (Pb is not None, gctx is not None, cvec is not None, dyn is not None)
         return plan.forward()
 
     @staticmethod
@@ -715,7 +720,7 @@ class _NativeReeval(torch.autograd.Function):
         E = plan.E
         sl = [dbuf[..., i * E:(i + 1) * E] for i in range(5 if ctx.has[0] else 4)]
         return (sl[0], sl[1], sl[2], sl[3], sl[4] if ctx.has[0] else None, dg if ctx.has[1] else None,
-                dc if ctx.has[2] else None, None)
+                dc if ctx.has[2] else None, None, plan.ddyn if ctx.has[3] else None)
 
 
 def _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip, rollout_logp=None, rollout_heads=None):
@@ -736,7 +741,11 @@ def _evaluate_native(policy, t, td, actions, S, multistart, temperature, clip, r
         meta["rollout_logp"] = rollout_logp.detach().to(torch.float32).contiguous()
         if rollout_heads is not None:           # the rollout kernel's glimpse outputs of these very steps: not recomputed
             meta["rollout_heads"] = rollout_heads.detach()
-    return _NativeReeval.apply(t["K"], t["V"], Lp, Pa, Pb, t.get("gctx"), cvec, meta)
+    dyn = None
+    if policy.env_name == "sdvrp":      # wk | wv | lw: the logit-key column folded through project_out like Lp (dynamic.py:59-78)
+        wk, wv, wl = t["dyn"].view(3, E)
+        dyn = torch.stack((wk, wv, wl @ t["Wout"]))
+    return _NativeReeval.apply(t["K"], t["V"], Lp, Pa, Pb, t.get("gctx"), cvec, meta, dyn)
 
 
 def evaluate_log_likelihood(policy, td, env, actions, num_starts: int = 0, temperature=None, tanh_clipping=None,

@@ -341,6 +341,11 @@ typedef struct eamrl_reeval {
                                                              * over the feasible nodes (calculate_entropy, utils/ops.py) */
     float *dK, *dV, *dLp, *dPa, *dPb; int64_t ldg;          /* gradients [B][M][.] (row stride ldg), ACCUMULATED into (+=) */
     float *dgctx, *dCvec;                                   /* [B][E] or NULL, [NC][E]; accumulated */
+    /* SDVRP only (NULL otherwise): the dynamic embedding  [nn/env_embeddings/dynamic.py:59-78] -- every step adds
+     * rem[n] * (wk | wv | wl) to row n of the glimpse key / value / logit key, rem = demand_with_depot at that step.
+     * rem [R][T][128] (rows zero padded; eamrl_replay_states_sdvrp records them), dyn = wk | wv | lw [3][E] with
+     * lw = wl folded through project_out like Lp; ddyn [3][E] accumulated (backward).  Excludes `heads`. */
+    const float* rem; const float* dyn; float* ddyn;
 } eamrl_reeval;
 
 int eamrl_reeval_supported(int M, int E, int H);                  /* 1 for M <= 112, E = 128, H = 8 */
@@ -494,6 +499,10 @@ int eamrl_check_solution(int env, const int64_t* actions, const float* demand, c
  * same result as T rounds of {eamrl_pack_mask_bits, copy, eamrl_*_step_mask}.  M <= 128. */
 int eamrl_replay_states(int env, const eamrl_state* state, int64_t R, int64_t B, int M, const int64_t* actions, int T,
                         uint32_t* bits, int32_t* idxA, float* sc, void* stream);
+/* The same for SDVRP  [sdvrp/env.py:58-92,137-146]: state->rem [R][M] (demand_with_depot), used, vcap, cur; additionally
+ * rem_out [R][T][128] = the remaining demands before each step (the rows the dynamic embedding reads), zero padded. */
+int eamrl_replay_states_sdvrp(const eamrl_state* state, int64_t R, int M, const int64_t* actions, int T, uint32_t* bits,
+                              int32_t* idxA, float* sc, float* rem_out, void* stream);
 
 /* ---- beam search ------------------------------------------------------------------------------------------ */
 

@@ -166,6 +166,35 @@ def test_replay_states_kernel_equals_step_by_step(env_name, N, B, ns):
     assert int((a["maskbits"] != 0).sum()) > 0
 
 
+@pytest.mark.parametrize("N,B,ns", [(20, 7, 0), (50, 3, 5), (100, 2, 4), (127, 2, 0)])
+def test_sdvrp_replay_kernel_equals_torch_state_loop(N, B, ns):
+    """eamrl_replay_states_sdvrp (SDVRPEnv._step + get_action_mask replayed inside one kernel, sdvrp/env.py:58-92,137-146) gives
+    the masks, current nodes, free capacities and remaining demands of the PyTorch step loop the fallback path runs (bit for bit:
+    the same float operations in the same order)."""
+    import eam_rl4co_amd as ea
+    from eam_rl4co_amd.train import _sdvrp_states, replay_states
+
+    env = ea.get_env("sdvrp", generator_params=dict(num_loc=N), seed=N + B)
+    torch.manual_seed(N)
+    td = env.reset(batch_size=[B]).to(DEV)
+    pol = make_policy("am_sdvrp")
+    kw = dict(decode_type="multistart_sampling", num_starts=ns) if ns else dict(decode_type="sampling")
+    with torch.no_grad():
+        acts = pol(td.clone(), env, phase="test", **kw)["actions"].contiguous()
+    S = max(ns, 1)
+    got = replay_states(pol, td, acts, S, bool(ns))
+    M = N + 1
+    rep = lambda x: x.repeat(S, *([1] * (x.dim() - 1)))
+    cur, free, mask, rem = _sdvrp_states(acts, rep(td["demand"]), rep(td["vehicle_capacity"].reshape(-1)), M)
+    bits = got["maskbits"].cpu().numpy().astype(np.uint32)                       # [R, T, 4]
+    unpacked = ((bits[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(*bits.shape[:2], 128)[..., :M].astype(bool)
+    assert np.array_equal(unpacked, mask.cpu().numpy())
+    assert torch.equal(got["idxA"].long(), cur)
+    assert_bits_equal(got["sc"][0], free.cpu().numpy(), "free capacity")
+    assert_bits_equal(got["rem"][..., :M], rem.cpu().numpy(), "remaining demands")
+    assert (M == 128 or float(got["rem"][..., M:].abs().max()) == 0.0) and got["tstart"] == (1 if ns else 0)
+
+
 @pytest.mark.parametrize("env_name,cfg,N", [("tsp", "pomo_tsp", 20), ("cvrp", "am_cvrp", 20)])
 def test_eam_shared_step_restated_runs_on_the_policy(env_name, cfg, N):
     """EAM.shared_step's training branch (zoo/earl/model.py:146-247, POMO baseline) restated line by line around the policy
@@ -515,6 +544,8 @@ def test_linear_autograd_function_matches_torch(relu, with_res):
     ("pomo_tsp", "tsp", 50, 4, 50, None), ("pomo_tsp", "tsp", 100, 3, 10, None), ("am_tsp", "tsp", 112, 2, 0, None),
     ("am_cvrp", "cvrp", 20, 5, 0, None), ("am_cvrp", "cvrp", 50, 3, 6, None), ("am_cvrp", "cvrp", 100, 2, 3, None),
     ("am_pctsp", "pctsp", 20, 4, 0, None), ("am_op", "op", 20, 4, 4, None), ("am_cvrptw", "cvrptw", 20, 4, 0, None),
+    # SDVRP: the dynamic embedding's rank-one terms (remaining demands per step) in all three kernels
+    ("am_sdvrp", "sdvrp", 20, 5, 0, None), ("am_sdvrp", "sdvrp", 50, 3, 6, None), ("am_sdvrp", "sdvrp", 100, 2, 3, None),
     # the gather kernel's cooperative bins (the depot of CVRP names > 512 queries of an instance) and its own chunking
     # (more than 24,576 queries of an instance: 250 samples x 100 steps)
     ("am_cvrp", "cvrp", 50, 2, 50, None), ("am_tsp", "tsp", 100, 1, 250, False),
