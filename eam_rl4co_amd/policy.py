@@ -1100,7 +1100,8 @@ class AttentionModelPolicy(nn.Module):
         slots = {n: cache.slots[n] for n in ("K", "V", "Lp", "Pa") + (("Pb",) if "Pb" in cache.slots else ())}
         plan = ops.ReevalPlan(cache.buf, "Pb" in cache.slots, cache.gctx, cvec, meta["idxA"], meta["idxB"], meta["sc"],
                               meta["maskbits"], acts, S, meta["tstart"], float(p["tanh_clipping"]), float(p["temperature"]),
-                              slots=slots, E=E, want_entropy=True, rollout_heads=p.get("final_heads"))
+                              slots=slots, E=E, want_entropy=True, rollout_heads=p.get("final_heads"),
+                              rem=meta.get("rem"), dyn=cache.dyn if meta.get("rem") is not None else None)     # (SDVRP)
         plan.forward()
         return plan.entropy.sum(1)
 
