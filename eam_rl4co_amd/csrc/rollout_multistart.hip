@@ -129,6 +129,8 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
     constexpr bool CV = ENV == EAMRL_ENV_CVRP || TW;    // vehicle load against the demands
     constexpr bool PC = ENV == EAMRL_ENV_PCTSP;         // prize collecting: used = collected prize, cap = required prize
     constexpr bool OP = ENV == EAMRL_ENV_OP;            // orienteering: used = tour length, s_dem = arrival limit per node
+    constexpr bool SD = ENV == EAMRL_ENV_SDVRP;         // split delivery: the state is the remaining-demand row, and the decoder adds
+                                                        // rem[n] * (wk | wv | lw) to the node's key / value / logit key
     constexpr bool DEP = ENV != EAMRL_ENV_TSP;          // depot envs: visited set, half-wavefront transition
     constexpr bool XY = OP || TW;                       // the transition needs distances
     __shared__ __attribute__((aligned(16))) float QT[16 * TS];
@@ -145,8 +147,13 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
     __shared__ int s_i0[(PC || OP) ? SMAX : 1];                                      // PCTSP / OP: the step counter the launch started from
     __shared__ float s_xy[XY ? 256 : 2], s_tw0[TW ? 128 : 1], s_tw1[TW ? 128 : 1], s_dur[TW ? 128 : 1];   // coordinates, windows, service
     __shared__ uint32_t s_flags;
+    __shared__ __attribute__((aligned(16))) float s_dyn[SD ? 3 * ME : 4];           // SDVRP: wk | wv | lw
     extern __shared__ __attribute__((aligned(16))) float LPF[];    // [RTT waves][32 k-steps][64 lanes]: the logit-key (Lp) A fragments
                                                                     // (kept in LDS, lane-linear: 32 VGPRs fewer per wave)
+    // SDVRP: remaining demands of every start, [SMAX][16 RTT] in accumulator order -- node n at (n >> 4) * 16 + (n & 3) * 4 + ((n & 15) >> 2),
+    // so that lane (start j, G) of the glimpse reads the nodes 16 kt + 4 r + G (r = 0..3) of its registers as one float4
+    float* SREM = LPF + RTT * 32 * 64;
+    auto rperm = [](int n) -> int { return (n >> 4) * 16 + (n & 3) * 4 + ((n & 15) >> 2); };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,7 +210,11 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
             if (a.mask[r * M + n]) { w[n >> 5] |= 1u << (n & 31); ++cnt; }
         s_bits[s][0] = w[0]; s_bits[s][1] = w[1]; s_bits[s][2] = w[2]; s_bits[s][3] = w[3];
         s_cur[s] = (int)a.cur[r];
-        if (DEP) {
+        if (SD) {
+            for (int n = 0; n < 16 * RTT; ++n) SREM[s * (16 * RTT) + rperm(n)] = n < M ? a.rem[r * M + n] : 0.0f;
+            s_used[s] = a.used[r];
+            s_cap[s] = a.vcap[r];
+        } else if (DEP) {
             uint32_t v[4] = {0, 0, 0, 0};
             cnt = 0;                                   // CVRP: nodes visited so far (the episode ends at M, depot included);
             for (int n = 0; n < M; ++n)                // PCTSP: customers visited so far
@@ -220,7 +231,9 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
         s_cnt[s] = cnt;
         s_done[s] = a.done[r] != 0;
     }
-    if (DEP)
+    if (SD)
+        for (int i = tid; i < 3 * ME; i += blockDim.x) s_dyn[i] = a.dyn[i];
+    if (DEP && !SD)
         for (int n = tid; n < 128; n += blockDim.x) {
             if (CV) s_dem[n] = (n >= 1 && n < M) ? a.demand[b * (M - 1) + n - 1] : 0.0f;     // demand of customer n
             else s_dem[n] = n < M ? a.demand[b * M + n] : 0.0f;                                // prize / arrival limit of node n
@@ -316,6 +329,31 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 for (int kt = 0; kt < RTT; ++kt) s[kt] = mf(kf[kt][2], qhi.x, s[kt]);
 #pragma unroll
                 for (int kt = 0; kt < RTT; ++kt) s[kt] = mf(kf[kt][3], qhi.y, s[kt]);
+                // SDVRP: s[n] = fma(rem[n], q~_h . wk_h, s[n]) -- the 16-term chain in column order (q~ carries the 1/4 of the scores,
+                // a power of two: the products and sums are the canonical ones scaled)
+                const float* remq = SREM + (sq < SMAX ? sq : 0) * (16 * RTT) + 4 * G;       // this lane's float4 column, + 16 kt
+                if (SD) {
+                    float qw = 0.0f;
+                    float4 qg[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) qg[g] = *reinterpret_cast<const float4*>(QT + j * TS + g * TG + 4 * wv);   // q~[16 h + 4 i + g]
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 wk4 = *reinterpret_cast<const float4*>(s_dyn + 16 * wv + 4 * i);
+                        const float qi[4] = {i == 0 ? qg[0].x : i == 1 ? qg[0].y : i == 2 ? qg[0].z : qg[0].w,
+                                             i == 0 ? qg[1].x : i == 1 ? qg[1].y : i == 2 ? qg[1].z : qg[1].w,
+                                             i == 0 ? qg[2].x : i == 1 ? qg[2].y : i == 2 ? qg[2].z : qg[2].w,
+                                             i == 0 ? qg[3].x : i == 1 ? qg[3].y : i == 2 ? qg[3].z : qg[3].w};
+                        qw = fma_(qi[0], wk4.x, qw); qw = fma_(qi[1], wk4.y, qw);
+                        qw = fma_(qi[2], wk4.z, qw); qw = fma_(qi[3], wk4.w, qw);
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < RTT; ++kt) {
+                        const float4 rv = *reinterpret_cast<const float4*>(remq + 16 * kt);
+                        s[kt][0] = fma_(rv.x, qw, s[kt][0]); s[kt][1] = fma_(rv.y, qw, s[kt][1]);
+                        s[kt][2] = fma_(rv.z, qw, s[kt][2]); s[kt][3] = fma_(rv.w, qw, s[kt][3]);
+                    }
+                }
                 float m = -INFINITY;
                 {
                     // infeasible keys: the score is OR-ed with all ones (a quiet NaN) where the key's mask bit is clear -- v_bfe_i32 of
@@ -351,6 +389,27 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                     }
                 }
                 MSTAMP(3);
+                // SDVRP: R_h = the lane tree (canonical order: adjacent pairs over the NODE index, block 0 + block 1) of w[n] rem[n].  Node
+                // n = 16 kt + 4 r + G: levels 1, 2 are the lane groups G (one row swap each, per register), 4 and 8 the registers r,
+                // 16 and 32 the key tiles kt & 3, the two 64-node blocks kt >> 2
+                float Rh = 0.0f;
+                if (SD) {
+                    float tk[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kt = 0; kt < RTT; ++kt) {
+                        const float4 rv = *reinterpret_cast<const float4*>(remq + 16 * kt);
+                        float pr[4] = {s[kt][0] * rv.x, s[kt][1] * rv.y, s[kt][2] * rv.z, s[kt][3] * rv.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(pr[r]), __float_as_uint(pr[r]), false, false);
+                            pr[r] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+                            auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(pr[r]), __float_as_uint(pr[r]), false, false);
+                            pr[r] = __uint_as_float(y[0]) + __uint_as_float(y[1]);
+                        }
+                        tk[kt] = (pr[0] + pr[1]) + (pr[2] + pr[3]);
+                    }
+                    Rh = ((tk[0] + tk[1]) + (tk[2] + tk[3])) + ((tk[4] + tk[5]) + (tk[6] + tk[7]));
+                }
                 // Value product per node chunk g = [g C, (g+1) C), chunks in ascending order: `cur` accumulates the chunk in
                 // progress (A_g against V^T, Z_g against a row of ones), `tot` the finished ones as ((A0 + A1) + A2) + A3.
                 // K-step t holds nodes 4 t .. 4 t + 3 (this lane: 4 t + G); where it straddles a chunk boundary it is issued
@@ -424,6 +483,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                 float hv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (SD) tot_o[r] = fma_(Rh, s_dyn[ME + 16 * wv + 4 * G + r], tot_o[r]);      // heads_h += R_h wv_h
                     hv[r] = tot_o[r] / tot_z;
                     hp[r * TG] = hv[r];
                 }
@@ -453,6 +513,44 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                         c[g] = mf(lpf[64 * (8 * g + 4 * u + 1)], lo.y, c[g]);
                         c[g] = mf(lpf[64 * (8 * g + 4 * u + 2)], hi.x, c[g]);
                         c[g] = mf(lpf[64 * (8 * g + 4 * u + 3)], hi.y, c[g]);
+                    }
+                }
+                if (SD) {
+                    // c_g[n] = fma(rem[n], hl_g, c_g[n]) with hl_g = heads . lw over the column chunk g (32-term chain in column order):
+                    // lane group G computes the chain of chunk G, three row swaps hand every lane all four
+                    float hl = 0.0f;
+                    const float* hq = HT + j * TS + 8 * G;                  // heads[j][32 G + 4 i + g2] at g2 * TG + i
+                    float4 hg[4][2];
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; ++g2) {
+                        hg[g2][0] = *reinterpret_cast<const float4*>(hq + g2 * TG);
+                        hg[g2][1] = *reinterpret_cast<const float4*>(hq + g2 * TG + 4);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float4 lw4 = *reinterpret_cast<const float4*>(s_dyn + 2 * ME + 32 * G + 4 * i);
+                        float hh[4];
+#pragma unroll
+                        for (int g2 = 0; g2 < 4; ++g2) {
+                            const float4 v = hg[g2][i >> 2];
+                            hh[g2] = (i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w;
+                        }
+                        hl = fma_(hh[0], lw4.x, hl); hl = fma_(hh[1], lw4.y, hl);
+                        hl = fma_(hh[2], lw4.z, hl); hl = fma_(hh[3], lw4.w, hl);
+                    }
+                    // rows of 16 lanes = lane groups: the 16-lane swap leaves (even group's, odd group's) value in every lane, the 32-lane
+                    // swap of each (groups 0-1's, groups 2-3's)
+                    const auto eo = __builtin_amdgcn_permlane16_swap(__float_as_uint(hl), __float_as_uint(hl), false, false);
+                    const auto e2 = __builtin_amdgcn_permlane32_swap(eo[0], eo[0], false, false);
+                    const auto o2 = __builtin_amdgcn_permlane32_swap(eo[1], eo[1], false, false);
+                    const float hlg[4] = {__uint_as_float(e2[0]), __uint_as_float(o2[0]), __uint_as_float(e2[1]), __uint_as_float(o2[1])};
+                    // this lane's keys 16 wv + 4 G + r: node n -> SREM slot (n >> 4) * 16 + (n & 3) * 4 + ((n & 15) >> 2) = 16 wv + 4 r + G
+                    const float* rq = SREM + (sq < SMAX ? sq : 0) * (16 * RTT) + 16 * wv + G;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float rn = rq[4 * r];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) c[g][r] = fma_(rn, hlg[g], c[g][r]);
                     }
                 }
                 const f32x4 u = ((c[0] + c[1]) + c[2]) + c[3];          // lane (query j, G): keys 16 wv + 4 G + (0..3)
@@ -583,7 +681,15 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                     int cnt = s_cnt[s], ist = 0;
                     bool done_new;
                     if (XY) { cx = s_xy[2 * sl]; cy = s_xy[2 * sl + 1]; }
-                    if (OP) {
+                    float sd_left = 0.0f;
+                    if (SD) {           // SDVRPEnv._step (sdvrp/env.py:58-92): deliver min(remaining demand, free capacity)
+                        const float selrem = SREM[s * (16 * RTT) + rperm(sl)];
+                        const float free_cap = s_cap[s] - u;
+                        const float delivered = selrem < free_cap ? selrem : free_cap;
+                        u = (u + delivered) * (sl != 0 ? 1.0f : 0.0f);
+                        sd_left = selrem + (-delivered);
+                        done_new = false;       // (set from the remaining demands below)
+                    } else if (OP) {
                         ist = s_istep[s];
                         const float dx = cx - s_xy[2 * curn], dy = cy - s_xy[2 * curn + 1];
                         u = u + __builtin_sqrtf(fma_(dy, dy, dx * dx));
@@ -610,7 +716,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                     }
                     const bool v0 = (vw.x & 1u) != 0;               // the depot has been visited (after this step)
                     const float lim = s_cap[s] + 1e-5f;
-                    uint32_t nb[4], fr = 0;
+                    uint32_t nb[4], fr = 0, anyrem = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int n = 32 * k + l32;
@@ -618,7 +724,13 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                         const bool vis_n = (vk >> l32) & 1u;
                         const bool cust = n >= 1 && n < M;
                         bool ok, freeb = false;
-                        if (PC) {
+                        if (SD) {       // get_action_mask (sdvrp/env.py:137-146): nothing left to deliver there, or the vehicle is full
+                            float rv = (n < 16 * RTT) ? SREM[s * (16 * RTT) + rperm(n)] : 0.0f;
+                            rv = n == sl ? sd_left : rv;
+                            freeb = cust && !((rv == 0.0f) | (u >= s_cap[s]));
+                            ok = freeb;
+                            anyrem |= (uint32_t)(__ballot(n < M && rv > 0.0f) >> (32 * hw));
+                        } else if (PC) {
                             ok = cust && !(vis_n | v0);
                         } else if (OP) {
                             const float dx = s_xy[2 * n] - cx, dy = s_xy[2 * n + 1] - cy;
@@ -633,8 +745,9 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                             }
                         }
                         nb[k] = (uint32_t)(__ballot(ok) >> (32 * hw));
-                        if (CV) fr |= (uint32_t)(__ballot(freeb) >> (32 * hw));
+                        if (CV || SD) fr |= (uint32_t)(__ballot(freeb) >> (32 * hw));
                     }
+                    if (SD) done_new = anyrem == 0u;            // done = no demand left anywhere (sdvrp/env.py:84-86)
                     // the depot's bit
                     if (PC) {
                         if (!((u < 1.0f) && (cnt < M - 1))) nb[0] |= 1u;     // opens once the prize is collected (or everyone visited)
@@ -653,7 +766,8 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                         a.logp[mul32w(r2, a.t_max) + t] = lpv;
                         if (!(oword & bit)) atomicOr(&s_flags, EAMRL_ST_INFEASIBLE);
                         *reinterpret_cast<uint4*>(&s_bits[s][0]) = make_uint4(nb[0], nb[1], nb[2], nb[3]);
-                        *reinterpret_cast<uint4*>(&s_vis[s][0]) = vw;
+                        if (!SD) *reinterpret_cast<uint4*>(&s_vis[s][0]) = vw;
+                        if (SD) SREM[s * (16 * RTT) + rperm(sl)] = sd_left;     // (every lane's reads of the row are above: one wavefront, LDS in order)
                         s_used[s] = u;
                         s_cur[s] = sl;
                         s_cnt[s] = cnt;
@@ -690,7 +804,10 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
         const int64_t r = (int64_t)s * a.B + b;
         for (int n = 0; n < M; ++n) a.mask[r * M + n] = (s_bits[s][n >> 5] >> (n & 31)) & 1u;
         a.cur[r] = s_cur[s];
-        if (DEP) {
+        if (SD) {
+            for (int n = 0; n < M; ++n) a.rem[r * M + n] = SREM[s * (16 * RTT) + rperm(n)];
+            a.used[r] = s_used[s];
+        } else if (DEP) {
             for (int n = 0; n < M; ++n) a.visited[r * M + n] = (s_vis[s][n >> 5] >> (n & 31)) & 1u;
             a.used[r] = s_used[s];
             if (TW) a.time[r] = s_time[s];
@@ -712,10 +829,10 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
 template <int RTT, int CC, int ENV>
 int launch_t(const DecArgs& a, int S, hipStream_t st)
 {
-    const size_t lds = (size_t)RTT * 32 * 64 * sizeof(float);
+    const size_t lds = ((size_t)RTT * 32 * 64 + (ENV == EAMRL_ENV_SDVRP ? (size_t)SMAX * 16 * RTT : 0)) * sizeof(float);
     auto k = k_rollout_ms_mfma<RTT, CC, ENV>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 32 * 1024)) !=
-        hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(lds + (ENV == EAMRL_ENV_SDVRP ? 0 : 32 * 1024))) != hipSuccess)
         return EAMRL_E_LAUNCH;
     // one workgroup per CU is resident (register budget): a batch smaller than the chip splits each instance's query tiles
     const int nqt = (S + 15) / 16;
@@ -758,7 +875,15 @@ extern "C" __attribute__((visibility("default"))) int eamrl_debug_read_ms_stamps
 // shape_only: the question eamrl_rollout_rng_native asks before the state exists (cache shape and row count alone)
 bool rollout_ms_mfma_supports(int env, const DecArgs& a, bool shape_only)
 {
+    const bool sd = env == EAMRL_ENV_SDVRP;
     const bool depot_env = env == EAMRL_ENV_CVRP || env == EAMRL_ENV_CVRPTW || env == EAMRL_ENV_PCTSP || env == EAMRL_ENV_OP;
+    if (sd) {
+        if (g_debug[14] || a.E != ME || a.H != MH || a.M < 2 || a.M > 112 || a.ld % 4 != 0 || a.ld >= (1 << 24)) return false;
+        if (!shape_only && (!a.dyn || !a.rem || !a.used || !a.vcap)) return false;
+        if (a.R % a.B != 0 || a.R >= (1ll << 31)) return false;
+        const int64_t S = a.R / a.B;
+        return S >= 2 && S <= SMAX && a.top_k == 0 && !(a.top_p > 0.0f && a.top_p < 1.0f);
+    }
     if ((env != EAMRL_ENV_TSP && !depot_env) || a.E != ME || a.H != MH || a.M < 2 || a.M > 112 || a.ld % 4 != 0 || a.ld >= (1 << 24)) return false;
     if (depot_env && (g_debug[14] || (!shape_only && (!a.visited || !a.used || !a.vcap || !a.demand)))) return false;
     if (!shape_only && (env == EAMRL_ENV_OP || env == EAMRL_ENV_CVRPTW) && !a.locs) return false;
@@ -776,7 +901,8 @@ int launch_rollout_ms_mfma(int env, const DecArgs& a, hipStream_t st)
     if (env == EAMRL_ENV_TSP) return launch_env_t<EAMRL_ENV_TSP>(a, S, C, st);
     const int rc = env == EAMRL_ENV_CVRP ? launch_env_t<EAMRL_ENV_CVRP>(a, S, C, st)
                  : env == EAMRL_ENV_CVRPTW ? launch_env_t<EAMRL_ENV_CVRPTW>(a, S, C, st)
-                 : env == EAMRL_ENV_PCTSP ? launch_env_t<EAMRL_ENV_PCTSP>(a, S, C, st) : launch_env_t<EAMRL_ENV_OP>(a, S, C, st);
+                 : env == EAMRL_ENV_PCTSP ? launch_env_t<EAMRL_ENV_PCTSP>(a, S, C, st)
+                 : env == EAMRL_ENV_SDVRP ? launch_env_t<EAMRL_ENV_SDVRP>(a, S, C, st) : launch_env_t<EAMRL_ENV_OP>(a, S, C, st);
     if (rc) return rc;
     launch_rollout_pad(env, a, st);              // rows that finished early end at the depot (and PCTSP / OP get their step counters)
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;

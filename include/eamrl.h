@@ -65,7 +65,7 @@ const char* eamrl_last_error(void);
  * key 6: 1 = eamrl_am_rollout does not use the start-sharing kernel for multistart batches (R = S*B rows).
  * key 11: 1 = eamrl_am_rollout does not use the MFMA start-sharing kernel (TSP multistart) but the VALU ones.
  * key 13: 1 = the MFMA start-sharing kernel never splits an instance's starts over several workgroups (small batches).
- * key 14: 1 = CVRP multistart batches use the VALU start-sharing kernel, not the MFMA one. */
+ * key 14: 1 = multistart batches of the depot envs (CVRP, CVRPTW, SDVRP, PCTSP, OP) use the VALU start-sharing kernel, not the MFMA one. */
 int eamrl_debug_set(int key, int value);
 
 /* ---- environment state machines ---------------------------------------------------------------- */

@@ -807,10 +807,11 @@ def test_full_size_pomo_cvrp_256x100_mfma_kernel_equals_valu_kernel():
 
 
 @pytest.mark.parametrize("env_name,N,B,S", [("cvrptw", 100, 48, 100), ("pctsp", 100, 64, 100), ("op", 100, 64, 100),
-                                            ("cvrptw", 20, 7, 20), ("pctsp", 50, 5, 50), ("op", 20, 6, 20)])
+                                            ("cvrptw", 20, 7, 20), ("pctsp", 50, 5, 50), ("op", 20, 6, 20),
+                                            ("sdvrp", 100, 48, 100), ("sdvrp", 20, 7, 20), ("sdvrp", 50, 5, 50), ("sdvrp", 37, 3, 30)])
 def test_sibling_env_multistart_mfma_kernel_equals_valu_kernel(env_name, N, B, S):
-    """Round 3: the MFMA start-sharing kernel also rolls out CVRPTW, PCTSP and OP multistart batches (their state machines run
-    per half-wavefront inside it).  Against the register-resident VALU start-sharing kernel (debug key 14) on the same
+    """Round 3: the MFMA start-sharing kernel also rolls out CVRPTW, PCTSP, OP and SDVRP multistart batches (their state machines
+    run per half-wavefront inside it; SDVRP adds the dynamic embedding's rank-one terms in the canonical order).  Against the register-resident VALU start-sharing kernel (debug key 14) on the same
     multistart-sampling batch and noise field: bit-identical tours, log-probs, rewards and final env state."""
     import time
 
