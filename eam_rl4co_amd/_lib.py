@@ -51,7 +51,9 @@ class Reeval(C.Structure):
                 ("logp", _vp), ("lse", _vp), ("glogp", _vp), ("dheads", _vp), ("heads", _vp), ("heads_T", C.c_int32),
                 ("entropy", _vp),
                 ("dK", _vp), ("dV", _vp), ("dLp", _vp), ("dPa", _vp), ("dPb", _vp), ("ldg", _i64),
-                ("dgctx", _vp), ("dCvec", _vp), ("rem", _vp), ("dyn", _vp), ("ddyn", _vp)]
+                ("dgctx", _vp), ("dCvec", _vp), ("rem", _vp), ("dyn", _vp), ("ddyn", _vp),
+                ("nkc", C.c_int32), ("scratch", _vp), ("mc_koff", C.c_int32), ("mc_mstride", C.c_int32),
+                ("mc_part_o", _vp), ("mc_part_s", _vp), ("mc_gstat", _vp), ("mc_lpart", _vp), ("mc_rsq", _vp), ("mc_dq", _vp)]
 
 
 class State(C.Structure):
@@ -98,6 +100,9 @@ PROTOTYPES = {
     "eamrl_encoder_fused": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "eamrl_encoder_fused_init": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "eamrl_reeval_supported": [_i32, _i32, _i32],
+    "eamrl_reeval_scratch_floats": [_i64, _i32, _i32],
+    "eamrl_pack_mask_bits_chunked": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "eamrl_tsp_mask_bits_chunked": [_vp, _vp, _i64, _i32, _i32, _vp],
     "eamrl_reeval_forward": [_vp, _vp],
     "eamrl_reeval_backward": [_vp, _vp],
     "eamrl_pack_mask_bits": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
@@ -128,7 +133,8 @@ PROTOTYPES = {
     "eamrl_ea_tsp_run": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"eamrl_last_error": C.c_char_p, "eamrl_linear_wgrad_scratch": C.c_int64,
-             "eamrl_small_linear_wgrad_scratch": C.c_int64, "eamrl_batchnorm_backward_scratch": C.c_int64}
+             "eamrl_small_linear_wgrad_scratch": C.c_int64, "eamrl_batchnorm_backward_scratch": C.c_int64,
+             "eamrl_reeval_scratch_floats": C.c_int64}
 
 _lib = None
 

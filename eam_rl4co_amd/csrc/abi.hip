@@ -394,6 +394,8 @@ static int check_reeval(const eamrl_reeval* p, const char* what, bool bwd)
 {
     REQUIRE(p, what);
     REQUIRE(reeval_supports(p->M, 128, 8), what);
+    if (p->M > 112)         // key chunks: scratch from the caller, the forward pass always run, no rollout heads / dynamic embedding
+        REQUIRE(p->scratch && p->lse && !p->heads && !p->dyn && (uintptr_t)p->scratch % 16 == 0 && p->NC <= 2, what);
     REQUIRE(p->K && p->V && p->Lp && p->Pa && p->idxA && p->maskbits && p->actions && p->logp, what);
     REQUIRE((p->idxB == nullptr) == (p->Pb == nullptr) || p->Pb, what);
     REQUIRE(p->B > 0 && p->S > 0 && p->T > 0 && p->R == p->B * p->S && p->nchunk >= 1 && p->nchunk <= p->S, what);
@@ -415,6 +417,7 @@ static int check_reeval(const eamrl_reeval* p, const char* what, bool bwd)
 }
 
 __attribute__((visibility("default"))) int eamrl_reeval_supported(int M, int E, int H) { return reeval_supports(M, E, H) ? 1 : 0; }
+__attribute__((visibility("default"))) int64_t eamrl_reeval_scratch_floats(int64_t R, int T, int M) { return reeval_scratch_floats(R, T, M); }
 
 __attribute__((visibility("default"))) int eamrl_reeval_forward(const eamrl_reeval* p, void* stream)
 {
@@ -434,7 +437,7 @@ __attribute__((visibility("default"))) int eamrl_replay_states(int env, const ea
 {
     REQUIRE(env == EAMRL_ENV_CVRP || env == EAMRL_ENV_CVRPTW || env == EAMRL_ENV_PCTSP || env == EAMRL_ENV_OP,
             "eamrl_replay_states (CVRP, CVRPTW, PCTSP or OP)");
-    REQUIRE(s && actions && bits && idxA && sc && R >= 0 && B > 0 && R % B == 0 && M >= 2 && M <= 128 && T > 0 &&
+    REQUIRE(s && actions && bits && idxA && sc && R >= 0 && B > 0 && R % B == 0 && M >= 2 && M <= 1024 && T > 0 &&
                 ((uintptr_t)bits % 16 == 0), "eamrl_replay_states");
     REQUIRE(s->mask && s->visited && s->used && s->vcap && s->cur && s->demand, "eamrl_replay_states (state)");
     if (env == EAMRL_ENV_PCTSP || env == EAMRL_ENV_OP) REQUIRE(s->istep != nullptr, "eamrl_replay_states (istep)");
@@ -463,6 +466,21 @@ __attribute__((visibility("default"))) int eamrl_pack_mask_bits(const uint8_t* m
 {
     REQUIRE(mask && bits && R >= 0 && M > 0 && M <= 128 && T > 0 && t >= 0 && t < T, "eamrl_pack_mask_bits");
     return launched(launch_pack_mask_bits(mask, bits, R, M, T, t, (hipStream_t)stream), "eamrl_pack_mask_bits");
+}
+
+__attribute__((visibility("default"))) int eamrl_pack_mask_bits_chunked(const uint8_t* mask, uint32_t* bits, int64_t R, int M, int T,
+                                                                       int t, void* stream)
+{
+    REQUIRE(mask && bits && R >= 0 && M > 0 && M <= 1024 && T > 0 && t >= 0 && t < T && ((uintptr_t)bits % 16 == 0),
+            "eamrl_pack_mask_bits_chunked");
+    return launched(launch_pack_mask_bits_chunked(mask, bits, R, M, T, t, (hipStream_t)stream), "eamrl_pack_mask_bits_chunked");
+}
+
+__attribute__((visibility("default"))) int eamrl_tsp_mask_bits_chunked(const int64_t* actions, uint32_t* bits, int64_t R, int M, int T,
+                                                                      void* stream)
+{
+    REQUIRE(actions && bits && R >= 0 && M > 0 && M <= 1024 && T > 0 && ((uintptr_t)bits % 16 == 0), "eamrl_tsp_mask_bits_chunked");
+    return launched(launch_tsp_mask_bits_chunked(actions, bits, R, M, T, (hipStream_t)stream), "eamrl_tsp_mask_bits_chunked");
 }
 
 __attribute__((visibility("default"))) int eamrl_tsp_mask_bits(const int64_t* actions, uint32_t* bits, int64_t R, int M, int T,

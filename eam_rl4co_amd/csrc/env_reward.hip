@@ -676,10 +676,12 @@ struct ReplayArgs {
     int64_t R, B; int M, T;
 };
 
-template <int ENV>
+// SLOTS = 128: graphs up to 112 nodes, masks as one 128-bit word per (row, step).  SLOTS = 1024: larger graphs, masks in the layout
+// of the key-chunked re-evaluation kernels -- bits [R][T][nkc][4], nkc = ceil(M / 112), bit i of chunk c = node 112 c + i.
+template <int ENV, int SLOTS = 128>
 __global__ __launch_bounds__(EB) void k_replay_states(ReplayArgs a)
 {
-    __shared__ uint8_t s_mask[ROWS_PER_BLOCK][128], s_vis[ROWS_PER_BLOCK][128], s_done[ROWS_PER_BLOCK][8];
+    __shared__ uint8_t s_mask[ROWS_PER_BLOCK][SLOTS], s_vis[ROWS_PER_BLOCK][SLOTS], s_done[ROWS_PER_BLOCK][8];
     __shared__ float s_used[ROWS_PER_BLOCK], s_time[ROWS_PER_BLOCK];
     __shared__ int64_t s_cur[ROWS_PER_BLOCK], s_istep[ROWS_PER_BLOCK];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -687,10 +689,11 @@ __global__ __launch_bounds__(EB) void k_replay_states(ReplayArgs a)
     if (r >= a.R) return;
     const int M = a.M, T = a.T;
     const int64_t bi = r % a.B;
-    for (int n = lane; n < 128; n += 64) {
+    for (int n = lane; n < SLOTS; n += 64) {
         s_mask[wv][n] = n < M ? a.mask[r * M + n] : 0;
         s_vis[wv][n] = n < M ? a.visited[r * M + n] : 0;
     }
+    const int nkc = (M + 111) / 112;
     if (lane == 0) {
         s_used[wv] = a.used[r];
         s_time[wv] = a.time ? a.time[r] : 0.0f;
@@ -703,10 +706,22 @@ __global__ __launch_bounds__(EB) void k_replay_states(ReplayArgs a)
     for (int t = 0; t < T; ++t) {
         // ---- record ------------------------------------------------------------------------------------------------------
         const unsigned long long b0 = __ballot(s_mask[wv][lane] != 0), b1 = __ballot(s_mask[wv][64 + lane] != 0);
+        if (SLOTS > 128) {          // one 32-bit word of one chunk per lane
+            for (int wi = lane; wi < 4 * nkc; wi += 64) {
+                const int c = wi >> 2, w = wi & 3;
+                uint32_t v = 0;
+                for (int i = 0; i < 32; ++i) {
+                    const int li = 32 * w + i, n = 112 * c + li;
+                    if (li < 112 && n < M && s_mask[wv][n]) v |= 1u << i;
+                }
+                a.bits[((r * T + t) * nkc + c) * 4 + w] = v;
+            }
+        }
         if (lane == 0) {
             const int64_t q = r * T + t;
-            *reinterpret_cast<uint4*>(a.bits + q * 4) =
-                make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32));
+            if (SLOTS == 128)
+                *reinterpret_cast<uint4*>(a.bits + q * 4) =
+                    make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32));
             a.idxA[q] = (int32_t)s_cur[wv];
             float free_ = vc - s_used[wv];            // free capacity / prize still to collect / length still allowed
             if (ENV == EAMRL_ENV_PCTSP) free_ = free_ < 0.0f ? 0.0f : free_;
@@ -1026,7 +1041,12 @@ int launch_replay_states(int env, const uint8_t* mask, const uint8_t* visited, c
 {
     ReplayArgs a{mask, visited, used, vcap, cur, istep, time, demand, locs, tw, dur, actions, bits, idxA, sc, R, B, M, T};
     const dim3 grid(row_blocks(R)), block(EB);
-    if (env == EAMRL_ENV_CVRP) hipLaunchKernelGGL(k_replay_states<EAMRL_ENV_CVRP>, grid, block, 0, st, a);
+    if (M > 112) {              // the chunked mask layout (graphs above 112 nodes)
+        if (env == EAMRL_ENV_CVRP) hipLaunchKernelGGL((k_replay_states<EAMRL_ENV_CVRP, 1024>), grid, block, 0, st, a);
+        else if (env == EAMRL_ENV_CVRPTW) hipLaunchKernelGGL((k_replay_states<EAMRL_ENV_CVRPTW, 1024>), grid, block, 0, st, a);
+        else if (env == EAMRL_ENV_PCTSP) hipLaunchKernelGGL((k_replay_states<EAMRL_ENV_PCTSP, 1024>), grid, block, 0, st, a);
+        else if (env == EAMRL_ENV_OP) hipLaunchKernelGGL((k_replay_states<EAMRL_ENV_OP, 1024>), grid, block, 0, st, a);
+    } else if (env == EAMRL_ENV_CVRP) hipLaunchKernelGGL(k_replay_states<EAMRL_ENV_CVRP>, grid, block, 0, st, a);
     else if (env == EAMRL_ENV_CVRPTW) hipLaunchKernelGGL(k_replay_states<EAMRL_ENV_CVRPTW>, grid, block, 0, st, a);
     else if (env == EAMRL_ENV_PCTSP) hipLaunchKernelGGL(k_replay_states<EAMRL_ENV_PCTSP>, grid, block, 0, st, a);
     else if (env == EAMRL_ENV_OP) hipLaunchKernelGGL(k_replay_states<EAMRL_ENV_OP>, grid, block, 0, st, a);

@@ -62,6 +62,9 @@ int launch_linear_wgrad(const float* dy, int64_t ldy, const float* x, int64_t ld
 // teacher-forced re-evaluation (reeval.hip)
 typedef eamrl_reeval ReevalArgs;
 bool reeval_supports(int M, int E, int H);
+int64_t reeval_scratch_floats(int64_t R, int T, int M);
+int launch_pack_mask_bits_chunked(const uint8_t* mask, uint32_t* bits, int64_t R, int M, int T, int t, hipStream_t st);
+int launch_tsp_mask_bits_chunked(const int64_t* actions, uint32_t* bits, int64_t R, int M, int T, hipStream_t st);
 int launch_reeval_fwd(const ReevalArgs& a, hipStream_t st);
 int launch_reeval_bwd(const ReevalArgs& a, hipStream_t st);
 bool mha_encoder_bwd_supports(int N, int E, int H);

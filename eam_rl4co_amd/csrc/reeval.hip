@@ -128,6 +128,38 @@ __device__ __forceinline__ Q tile_query(const ReevalArgs& a, int64_t b, int s0, 
     return q;
 }
 
+// ---- graphs above 112 nodes: key chunks ---------------------------------------------------------------------------------------
+// The kernels below hold ONE chunk of at most 112 keys (K / V / Lp fragments in registers).  A larger graph is cut into
+// nkc = ceil(M / 112) chunks and every (instance, row chunk) gets one workgroup per key chunk; `chunk_view` turns the arguments
+// into those of a 112-node instance made of the chunk's keys (pointer arithmetic only: the kernels' index expressions
+// (b * M + n) * ld stay as they are), the mask words and the action index become chunk-local, and what a softmax needs from the
+// other chunks travels through small per-query statistics (k_reeval_mc_* below).
+constexpr int KCH = 112;
+struct Blk { int64_t b; int ch, c; };
+__device__ __forceinline__ Blk decode_block(const ReevalArgs& a)
+{
+    Blk k;
+    int64_t blk = blockIdx.x;
+    k.c = (int)(blk % a.nkc);
+    blk /= a.nkc;
+    k.b = blk / a.nchunk;
+    k.ch = (int)(blk - k.b * a.nchunk);
+    return k;
+}
+__device__ __forceinline__ void chunk_view(ReevalArgs& a, int64_t b, int c)
+{
+    if (a.nkc <= 1) return;
+    const int koff = KCH * c, Mc = min(KCH, a.M - koff);
+    const int64_t adj = b * (a.M - Mc);            // the body computes (b * Mc + n) * ld: make that row b * M + koff + n
+    a.K += (adj + koff) * a.ld; a.V += (adj + koff) * a.ld; a.Lp += (adj + koff) * a.ld;
+    a.Pa += adj * a.ld;                            // context rows are indexed by any node of the instance
+    if (a.Pb) a.Pb += adj * a.ld;
+    if (a.dK) { a.dK += (adj + koff) * a.ldg; a.dV += (adj + koff) * a.ldg; a.dLp += (adj + koff) * a.ldg; }
+    a.maskbits += 4 * c;
+    a.mc_koff = koff;
+    a.M = Mc;
+}
+
 // q~ tile = 0.25 * (Pa[ia] + Pb[ib] + gctx + sum_k sc_k C_k)  ->  QT (A layout); 512 threads: 32 float4 per query
 __device__ __forceinline__ void build_query_tile(const ReevalArgs& a, int64_t b, int s0, int64_t nq, int64_t tile, float* QT)
 {
@@ -185,8 +217,11 @@ __device__ __forceinline__ void load_head_frags(const ReevalArgs& a, int64_t b, 
 // registers (the RTT = 7 backward kernels have none to spare)
 template <int RTT, bool DYN = false>
 __device__ __forceinline__ float head_softmax(const float (&kf)[RTT][4], const float* QT, int h, int lane, const uint4& mb, int M,
-                                              f32x4 (&s)[RTT], const float* remq = nullptr, const DynLane* dl = nullptr)
+                                              f32x4 (&s)[RTT], const float* remq = nullptr, const DynLane* dl = nullptr,
+                                              float* stats = nullptr, const float* given = nullptr)
 {
+    // stats (key chunks, forward): -> (maximum or -inf, sum of the weights) of THIS chunk; given (backward): (maximum, 1 / sum) over
+    // ALL chunks -- the weights are then exp(s - given maximum) and nothing is reduced here
     const int j = lane & 15, G = lane >> 4;
     const float* qp = QT + j * TS + G * TG + 4 * h;
     const float2 qlo = *reinterpret_cast<const float2*>(qp), qhi = *reinterpret_cast<const float2*>(qp + 2);
@@ -218,7 +253,16 @@ __device__ __forceinline__ float head_softmax(const float (&kf)[RTT][4], const f
             s[kt][r] = ok ? s[kt][r] : -INFINITY;
             m = fmaxf(m, s[kt][r]);
         }
+    if (given) {
+        m = given[0];
+#pragma unroll
+        for (int kt = 0; kt < RTT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][r] = fexp(s[kt][r] - m);
+        return given[1];
+    }
     m = group_max(m);
+    if (stats) stats[0] = m;
     if (m == -INFINITY) m = 0.0f;
     float z = 0.0f;
 #pragma unroll
@@ -229,6 +273,7 @@ __device__ __forceinline__ float head_softmax(const float (&kf)[RTT][4], const f
             z += s[kt][r];
         }
     z = group_sum(z);
+    if (stats) stats[1] = z;
     return z > 0.0f ? 1.0f / z : 0.0f;
 }
 
@@ -336,7 +381,9 @@ __device__ __forceinline__ float process_logit(float u, float clip, float inv_te
 // forward: logp[r][t], lse[r][t]
 // ---------------------------------------------------------------------------------------------------------------------
 // HEADS: the rollout's glimpse outputs (eamrl_reeval.heads) are staged instead of recomputed (training: the entropy pass)
-template <int RTT, bool HEADS, bool DYN = false>
+// MC (key chunks): the logits half of a chunk -- heads come from the combined glimpse (HEADS), and instead of log-probs the
+// chunk's (maximum, sum of exponentials, sum of e z, z[action] or -inf) go to mc_lpart for k_reeval_mc_combine_logits
+template <int RTT, bool HEADS, bool DYN = false, bool MC = false>
 __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
 {
     __shared__ __attribute__((aligned(16))) float QT[16 * TS];
@@ -347,8 +394,10 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, G = lane >> 4;
-    const int64_t b = blockIdx.x / a.nchunk;
-    const int ch = (int)(blockIdx.x - b * a.nchunk);
+    const Blk blk = decode_block(a);
+    const int64_t b = blk.b;
+    const int ch = blk.ch, kc = blk.c;
+    chunk_view(a, b, kc);
     const int s0 = (int)((int64_t)a.S * ch / a.nchunk), s1 = (int)((int64_t)a.S * (ch + 1) / a.nchunk);
     const int64_t nq = (int64_t)(s1 - s0) * a.T;
     const int64_t ntiles = (nq + 15) / 16;
@@ -376,9 +425,10 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
         uint4 mb = make_uint4(0, 0, 0, 0);
         int act = -1;
         if (q.qi >= 0) {
-            mb = *reinterpret_cast<const uint4*>(a.maskbits + q.qi * 4);
-            act = (int)a.actions[q.qi];
+            mb = *reinterpret_cast<const uint4*>(a.maskbits + q.qi * a.mc_mstride);
+            act = (int)a.actions[q.qi] - a.mc_koff;
         }
+        if (MC && tid < 16) ZA[tid] = -INFINITY;     // (its readers of the previous tile: these very threads, earlier in program order)
         if (HEADS) {
             const int jq = threadIdx.x >> 5, e4 = threadIdx.x & 31;
             const Q qq = tile_query(a, b, s0, nq, tile, jq);
@@ -446,6 +496,11 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
             if (qq.qi >= 0) {
                 float sm = 0.0f, sz = 0.0f, mm = -INFINITY;
                 for (int w = 0; w < RTT; ++w) { sm += RED2[w][tid]; mm = fmaxf(mm, RED[w][tid]); }
+                if (MC) {        // this chunk's share of the query's log-softmax
+                    for (int w = 0; w < RTT; ++w) sz += a.entropy ? RED3[w][tid] : 0.0f;
+                    *reinterpret_cast<float4*>(a.mc_lpart + (qq.qi * a.nkc + kc) * 4) = make_float4(mm, sm, sz, ZA[tid]);
+                    continue;
+                }
                 if (mm == -INFINITY) mm = 0.0f;
                 const float lse = mm + __builtin_amdgcn_logf(sm) * 0.6931471805599453f;
                 if (a.lse) a.lse[qq.qi] = lse;
@@ -461,6 +516,125 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
     }
 }
 
+// ---- key chunks, forward: glimpse of one chunk -> per-(query, head) partials; combine -> heads + statistics ------------------------
+// mc_part_s [(q * 8 + h) * nkc + c][2] = (maximum or -inf, sum of exp(s - maximum)) over the chunk's feasible keys,
+// mc_part_o [(q * nkc + c)][128] = sum_n exp(s_n - maximum) V[n] (unnormalised head outputs, all heads side by side)
+template <int RTT>
+__global__ __launch_bounds__(512, 2) void k_reeval_mc_glimpse_part(ReevalArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float QT[16 * TS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, G = lane >> 4;
+    const Blk blk = decode_block(a);
+    const int64_t b = blk.b;
+    const int ch = blk.ch, kc = blk.c;
+    chunk_view(a, b, kc);
+    const int s0 = (int)((int64_t)a.S * ch / a.nchunk), s1 = (int)((int64_t)a.S * (ch + 1) / a.nchunk);
+    const int64_t nq = (int64_t)(s1 - s0) * a.T;
+    const int64_t ntiles = (nq + 15) / 16;
+    float kf[RTT][4], vtf[4 * RTT];
+    load_head_frags<RTT>(a, b, wv, lane, kf, vtf);
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+        build_query_tile(a, b, s0, nq, tile, QT);
+        const Q q = tile_query(a, b, s0, nq, tile, j);
+        uint4 mb = make_uint4(0, 0, 0, 0);
+        if (q.qi >= 0) mb = *reinterpret_cast<const uint4*>(a.maskbits + q.qi * a.mc_mstride);
+        __syncthreads();
+        f32x4 s[RTT];
+        float st2[2];
+        head_softmax<RTT>(kf, QT, wv, lane, mb, a.M, s, nullptr, nullptr, st2);
+        f32x4 o = z4();
+#pragma unroll
+        for (int t = 0; t < 4 * RTT; ++t) o = mf(vtf[t], s[t >> 2][t & 3], o);
+        if (q.qi >= 0) {
+            if (G == 0) *reinterpret_cast<float2*>(a.mc_part_s + ((q.qi * RH + wv) * a.nkc + kc) * 2) = make_float2(st2[0], st2[1]);
+            *reinterpret_cast<float4*>(a.mc_part_o + (q.qi * a.nkc + kc) * RE + 16 * wv + 4 * G) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();            // QT is rebuilt by the next tile
+    }
+}
+
+// heads [r][t - tstart][E] (the layout of eamrl_reeval.heads with heads_T = T) and mc_gstat [(q * 8 + h)][2] = (maximum, 1 / sum)
+// over all chunks; one thread per (query, four columns)
+__global__ void k_reeval_mc_combine_glimpse(ReevalArgs a, float* heads)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t qi = idx >> 5;
+    const int e4 = (int)(idx & 31), h = e4 >> 2;
+    if (qi >= a.R * a.T) return;
+    const int64_t r = qi / a.T;
+    const int t = (int)(qi - r * a.T);
+    if (t < a.tstart) return;
+    const float* ps = a.mc_part_s + (qi * RH + h) * a.nkc * 2;
+    float m = -INFINITY;
+    for (int c = 0; c < a.nkc; ++c) m = fmaxf(m, ps[2 * c]);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    float Z = 0.0f;
+    if (m > -INFINITY)
+        for (int c = 0; c < a.nkc; ++c) {
+            const float mc = ps[2 * c];
+            if (mc == -INFINITY) continue;
+            const float f = fexp(mc - m);
+            Z = fmaf(f, ps[2 * c + 1], Z);
+            const float4 v = *reinterpret_cast<const float4*>(a.mc_part_o + (qi * a.nkc + c) * RE + 4 * e4);
+            o.x = fmaf(f, v.x, o.x); o.y = fmaf(f, v.y, o.y); o.z = fmaf(f, v.z, o.z); o.w = fmaf(f, v.w, o.w);
+        }
+    const float iz = Z > 0.0f ? 1.0f / Z : 0.0f;
+    *reinterpret_cast<float4*>(heads + (r * a.T + t - a.tstart) * RE + 4 * e4) = make_float4(o.x * iz, o.y * iz, o.z * iz, o.w * iz);
+    if ((e4 & 3) == 0) *reinterpret_cast<float2*>(a.mc_gstat + (qi * RH + h) * 2) = make_float2(m > -INFINITY ? m : 0.0f, iz);
+}
+
+// log-softmax over the chunks: mc_lpart [(q * nkc + c)][4] = (maximum, sum of exp, sum of e z, z[action] or -inf) -> logp, lse, entropy
+__global__ void k_reeval_mc_combine_logits(ReevalArgs a)
+{
+    const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= a.R * a.T) return;
+    const int t = (int)(qi % a.T);
+    const float4* lp = reinterpret_cast<const float4*>(a.mc_lpart) + qi * a.nkc;
+    float mm = -INFINITY, za = -INFINITY;
+    for (int c = 0; c < a.nkc; ++c) { mm = fmaxf(mm, lp[c].x); za = fmaxf(za, lp[c].w); }
+    float sm = 0.0f, sz = 0.0f;
+    if (mm > -INFINITY)
+        for (int c = 0; c < a.nkc; ++c) {
+            if (lp[c].x == -INFINITY) continue;
+            const float f = fexp(lp[c].x - mm);
+            sm = fmaf(f, lp[c].y, sm);
+            sz = fmaf(f, lp[c].z, sz);
+        }
+    if (mm == -INFINITY) mm = 0.0f;
+    const float lse = mm + __builtin_amdgcn_logf(sm) * 0.6931471805599453f;
+    const bool active = t >= a.tstart;
+    if (a.lse) a.lse[qi] = lse;
+    a.logp[qi] = active ? za - lse : 0.0f;
+    if (a.entropy) a.entropy[qi] = (active && sm > 0.0f) ? lse - sz / sm : 0.0f;
+}
+
+// backward, between the two kernels: dheads = sum of the chunks' partials (into partial 0), rs [(q * 8 + h)] = heads_h . dheads_h --
+// the sum_n a[n] (V[n] . dO) over ALL keys that the glimpse backward subtracts; one thread per (query, four columns)
+__global__ void k_reeval_mc_sum_dheads(ReevalArgs a, const float* heads)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t qi = idx >> 5, RT = a.R * a.T;
+    const int e4 = (int)(idx & 31);
+    const bool in = qi < RT;
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f), hv = d;
+    if (in) {
+        for (int c = 0; c < a.nkc; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(a.dheads + (c * RT + qi) * RE + 4 * e4);
+            d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w;
+        }
+        *reinterpret_cast<float4*>(a.dheads + qi * RE + 4 * e4) = d;
+        const int64_t r = qi / a.T;
+        const int t = (int)(qi - r * a.T);
+        if (t >= a.tstart) hv = *reinterpret_cast<const float4*>(heads + (r * a.T + t - a.tstart) * RE + 4 * e4);
+    }
+    float p = fmaf(hv.w, d.w, fmaf(hv.z, d.z, fmaf(hv.y, d.y, hv.x * d.x)));
+    p += __shfl_xor(p, 1);
+    p += __shfl_xor(p, 2);
+    if (in && (e4 & 3) == 0) a.mc_rsq[qi * RH + (e4 >> 2)] = p;
+}
+
 template <int RTT>
 static int launch_fwd_t(const ReevalArgs& a, hipStream_t st)
 {
@@ -470,11 +644,55 @@ static int launch_fwd_t(const ReevalArgs& a, hipStream_t st)
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 
-bool reeval_supports(int M, int E, int H) { return M >= 1 && M <= 112 && E == RE && H == RH; }
+bool reeval_supports(int M, int E, int H) { return M >= 1 && M <= 1024 && E == RE && H == RH; }
 
-int launch_reeval_fwd(const ReevalArgs& a, hipStream_t st)
+// ---- key chunks: scratch layout (floats) -------------------------------------------------------------------------------------------
+//   heads [R T][E] | part_o [R T][nkc][E] | part_s [R T][8][nkc][2] | gstat [R T][8][2] | lpart [R T][nkc][4] | rsq [R T][8]
+// (the per-chunk dq~ rows of the backward live behind the caller's dheads partials: dheads is [2 nkc][R][T][E])
+int64_t reeval_scratch_floats(int64_t R, int T, int M)
 {
-    if (a.B <= 0 || a.S <= 0 || a.T <= 0) return 0;
+    if (M <= KCH) return 0;
+    const int64_t nkc = (M + KCH - 1) / KCH, RT = R * T;
+    return RT * (RE + nkc * RE + RH * nkc * 2 + RH * 2 + nkc * 4 + RH);
+}
+static float* mc_bind(ReevalArgs& a)        // -> heads
+{
+    const int64_t RT = a.R * (int64_t)a.T;
+    a.nkc = (a.M + KCH - 1) / KCH;
+    a.mc_mstride = 4 * a.nkc;
+    a.mc_koff = 0;
+    float* p = a.scratch;
+    float* heads = p; p += RT * RE;
+    a.mc_part_o = p; p += RT * a.nkc * RE;
+    a.mc_part_s = p; p += RT * RH * a.nkc * 2;
+    a.mc_gstat = p; p += RT * RH * 2;
+    a.mc_lpart = p; p += RT * a.nkc * 4;
+    a.mc_rsq = p;
+    a.mc_dq = a.dheads ? a.dheads + (int64_t)a.nkc * RT * RE : nullptr;
+    return heads;
+}
+
+static int launch_fwd_mc(const ReevalArgs& a0, hipStream_t st)
+{
+    ReevalArgs a = a0;
+    float* heads = mc_bind(a);
+    const int64_t RT = a.R * (int64_t)a.T;
+    const unsigned grid = (unsigned)(a.B * a.nchunk * a.nkc);
+    hipLaunchKernelGGL((k_reeval_mc_glimpse_part<7>), dim3(grid), dim3(512), 0, st, a);
+    hipLaunchKernelGGL(k_reeval_mc_combine_glimpse, dim3((unsigned)((RT * 32 + 255) / 256)), dim3(256), 0, st, a, heads);
+    ReevalArgs l = a;
+    l.heads = heads; l.heads_T = a.T;
+    hipLaunchKernelGGL((k_reeval_fwd<7, true, false, true>), dim3(grid), dim3(512), 0, st, l);
+    hipLaunchKernelGGL(k_reeval_mc_combine_logits, dim3((unsigned)((RT + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_reeval_fwd(const ReevalArgs& a0, hipStream_t st)
+{
+    if (a0.B <= 0 || a0.S <= 0 || a0.T <= 0) return 0;
+    if (a0.M > KCH) return launch_fwd_mc(a0, st);
+    ReevalArgs a = a0;
+    a.nkc = 1; a.mc_koff = 0; a.mc_mstride = 4;
     if (a.M <= 32) return launch_fwd_t<2>(a, st);
     if (a.M <= 64) return launch_fwd_t<4>(a, st);
     return launch_fwd_t<7>(a, st);
@@ -560,7 +778,7 @@ __device__ __forceinline__ void stage_rows(const RowPre& p, const float4& gc, co
 
 __device__ __forceinline__ uint4 load_mask_words(const ReevalArgs& a, int qi)
 {
-    const uint4 m = *reinterpret_cast<const uint4*>(a.maskbits + (int64_t)max(qi, 0) * 4);
+    const uint4 m = *reinterpret_cast<const uint4*>(a.maskbits + (int64_t)max(qi, 0) * a.mc_mstride);
     return qi >= 0 ? m : make_uint4(0, 0, 0, 0);
 }
 
@@ -580,11 +798,14 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, G = lane >> 4;
     const int jq = tid >> 5, e4 = tid & 31;
-    const int64_t b = blockIdx.x / a.nchunk;
-    const int ch = (int)(blockIdx.x - b * a.nchunk);
+    const Blk blk = decode_block(a);
+    const int64_t b = blk.b;
+    const int ch = blk.ch, kc = blk.c;
+    chunk_view(a, b, kc);
     const int s0 = (int)((int64_t)a.S * ch / a.nchunk), s1 = (int)((int64_t)a.S * (ch + 1) / a.nchunk);
     const int ns = s1 - s0, T = a.T;
     const int ntiles = (ns * T + 15) / 16;
+    if (a.nkc > 1) a.dheads += (int64_t)kc * a.R * a.T * RE;        // key chunks: this chunk's partial (summed by k_reeval_mc_sum_dheads)
     // lse == NULL: no forward pass was run -- logp holds the ROLLOUT's log-prob of the chosen node (the same quantity in the
     // rollout kernels' arithmetic), and the normaliser is recovered as z[action] - logp, one extra LDS hand-off per tile
     const bool derive_lse = a.lse == nullptr;
@@ -682,7 +903,7 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
             }
             const int qjc = max(qj, 0);
             const bool live = qj >= 0 && tj >= a.tstart;
-            const int act_l = (int)a.actions[qjc];
+            const int act_l = (int)a.actions[qjc] - a.mc_koff;
             const float g_l = a.glogp[qjc], lse_l = derive_lse ? a.logp[qjc] : a.lse[qjc];
             wj.next(T);
             qjn = qi_of(wj);
@@ -802,17 +1023,19 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
 // fragments in LDS ([t4] at stride 64 float4).
 // DYN (SDVRP, see DynLane): REM = the tile's staged remaining demands, srw = 32 wave-private LDS floats, dwk / dwv = this lane's
 // running sums of the gradients of wk[16 h + j] / wv[16 h + j] over the queries 4 t + G
+// given (key chunks): (maximum, 1 / sum, rs) of the lane's query over ALL chunks -- the softmax is not renormalised here and the
+// row sum rs = sum_n a[n] da[n] = heads_h . dO_h comes from k_reeval_mc_sum_dheads
 template <int RTT, bool DYN = false, typename StoreDq>
 __device__ __forceinline__ void attention_bwd_tile(const float (&kf)[RTT][4], const float (&vaf)[RTT][4], const float4* ktl,
                                                    const float* QT, const float* DHT, float* stg, int h, int lane,
                                                    const uint4& mb, int M, f32x4 (&dV)[RTT], f32x4 (&dK)[RTT], StoreDq store_dq,
                                                    const float* REM = nullptr, const DynLane* dl = nullptr, float* srw = nullptr,
-                                                   float* dwk = nullptr, float* dwv = nullptr)
+                                                   float* dwk = nullptr, float* dwv = nullptr, const float* given = nullptr)
 {
     const int j = lane & 15, G = lane >> 4;
     f32x4 s[RTT], da[RTT];
     const float* remq = DYN ? rem_lane<RTT>(REM, j, G) : nullptr;
-    const float iz = head_softmax<RTT, DYN>(kf, QT, h, lane, mb, M, s, remq, dl);
+    const float iz = head_softmax<RTT, DYN>(kf, QT, h, lane, mb, M, s, remq, dl, nullptr, given);
     const float* dp = DHT + j * TS + G * TG + 4 * h;
     const float2 dlo = *reinterpret_cast<const float2*>(dp), dhi = *reinterpret_cast<const float2*>(dp + 2);
 #pragma unroll
@@ -844,7 +1067,7 @@ __device__ __forceinline__ void attention_bwd_tile(const float (&kf)[RTT][4], co
             if (DYN) ar = fmaf(s[kt][r], rv[r], ar);
         }
     }
-    rs = group_sum(rs);
+    rs = given ? given[2] : group_sum(rs);
 #pragma unroll
     for (int kt = 0; kt < RTT; ++kt) {
         f32x4 rv = z4();
@@ -940,7 +1163,7 @@ __device__ __forceinline__ void attention_bwd_tile(const float (&kf)[RTT][4], co
 // (Round-2 history: with the gathers, two barriers and an LDS-atomic scatter inside the loop this kernel took 37.3 ms at the
 //  POMO training size; 15.6 ms now, plus 2.0 ms of k_reeval_bwd_gather.)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int RTT, bool DYN = false>
+template <int RTT, bool DYN = false, bool MC = false>
 __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -956,8 +1179,10 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, G = lane >> 4, pi = 4 * (j & 3) + (j >> 2);
     const int jq = tid >> 5, e4 = tid & 31;
-    const int64_t b = blockIdx.x / a.nchunk;
-    const int ch = (int)(blockIdx.x - b * a.nchunk);
+    const Blk blk = decode_block(a);
+    const int64_t b = blk.b;
+    const int ch = blk.ch, kc = blk.c;
+    chunk_view(a, b, kc);
     const int s0 = (int)((int64_t)a.S * ch / a.nchunk), s1 = (int)((int64_t)a.S * (ch + 1) / a.nchunk);
     const int ns = s1 - s0, T = a.T;
     const int ntiles = (ns * T + 15) / 16;
@@ -1010,6 +1235,16 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
     load_idx(a, qr, ia, ib);
     int qj = qi_of(wj);
     uint4 mb = load_mask_words(a, qj);
+    // key chunks: the query's statistics over all chunks (maximum, 1 / sum, rs), fetched one tile ahead like the mask words
+    const int64_t RT = a.R * (int64_t)a.T;
+    auto load_given = [&](int q, float (&g)[3]) {
+        const int qc = max(q, 0);
+        const float2 st2 = *reinterpret_cast<const float2*>(a.mc_gstat + ((int64_t)qc * RH + h) * 2);
+        const float rsv = a.mc_rsq[(int64_t)qc * RH + h];
+        g[0] = q >= 0 ? st2.x : 0.0f; g[1] = q >= 0 ? st2.y : 0.0f; g[2] = q >= 0 ? rsv : 0.0f;
+    };
+    float gv[3] = {0.f, 0.f, 0.f};
+    if (MC) load_given(qj, gv);
     __syncthreads();                    // CV, KTL
 
     for (int tile = 0; tile < ntiles; ++tile) {
@@ -1023,17 +1258,20 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
         load_idx(a, qr, ia, ib);
         const int qj_cur = qj;
         const uint4 mb_cur = mb;
+        const float gv_cur[3] = {gv[0], gv[1], gv[2]};
         wj.next(T);
         qj = qi_of(wj);
         mb = load_mask_words(a, qj);
+        if (MC) load_given(qj, gv);
         __syncthreads();
         const float* QT = QTB + cur * 16 * TS;
         const float* DHT = DHB + cur * 16 * TS;
         attention_bwd_tile<RTT, DYN>(kf, vaf, ktl, QT, DHT, stg, h, lane, mb_cur, a.M, dV, dK, [&](const f32x4& dq) {
-            if (qj_cur >= 0)        // dq~ takes the place of the tile's dheads row (read one tile ahead)
-                *reinterpret_cast<float4*>(a.dheads + (int64_t)qj_cur * RE + 16 * h + 4 * G) =
-                    make_float4(0.25f * dq[0], 0.25f * dq[1], 0.25f * dq[2], 0.25f * dq[3]);
-        }, REMB + cur * 16 * 16 * RTT, &dl, SRW + wv * 32, &dwk_acc, &dwv_acc);
+            if (qj_cur >= 0) {      // dq~ takes the place of the tile's dheads row (read one tile ahead); key chunks: its own buffer
+                float* dst = MC ? a.mc_dq + ((int64_t)kc * RT + qj_cur) * RE : a.dheads + (int64_t)qj_cur * RE;
+                *reinterpret_cast<float4*>(dst + 16 * h + 4 * G) = make_float4(0.25f * dq[0], 0.25f * dq[1], 0.25f * dq[2], 0.25f * dq[3]);
+            }
+        }, REMB + cur * 16 * 16 * RTT, &dl, SRW + wv * 32, &dwk_acc, &dwv_acc, MC ? gv_cur : nullptr);
     }
     if (DYN) {
         dwk_acc = group_sum(dwk_acc);
@@ -1064,13 +1302,14 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_glimpse(ReevalArgs a)
 constexpr int GU = 8;           // rows in flight per wavefront
 constexpr int GBIG = 512;
 constexpr int GCAP = 24576;     // queries per workgroup (LDS: 4 bytes each)
+constexpr int GBINS = 1032;     // bins: up to 1024 nodes (+ "no node", + the end offset)
 
 __global__ __launch_bounds__(512) void k_reeval_bwd_gather(ReevalArgs a, int nchunk)
 {
     extern __shared__ __attribute__((aligned(16))) int ldsi[];
     int* OFF = ldsi;                // [M + 2] counts, then offsets
-    int* CUR = OFF + 132;           // [M + 1] cursors
-    int* ORD = CUR + 132;           // [nq] query indices grouped by node
+    int* CUR = OFF + GBINS;         // [M + 1] cursors
+    int* ORD = CUR + GBINS;         // [nq] query indices grouped by node
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t b = blockIdx.x / nchunk;
@@ -1085,7 +1324,7 @@ __global__ __launch_bounds__(512) void k_reeval_bwd_gather(ReevalArgs a, int nch
         if (!idx) break;
         const int nb = pass ? M : M + 1;
         __syncthreads();
-        for (int i = tid; i < 2 * 132; i += blockDim.x) OFF[i] = 0;
+        for (int i = tid; i < 2 * GBINS; i += blockDim.x) OFF[i] = 0;
         __syncthreads();
         for (int l = tid; l < nq; l += blockDim.x) {
             const int sl = l / T, t = l - sl * T;
@@ -1094,17 +1333,22 @@ __global__ __launch_bounds__(512) void k_reeval_bwd_gather(ReevalArgs a, int nch
             if (n >= 0 || !pass) atomicAdd(OFF + (n >= 0 ? n : M), 1);
         }
         __syncthreads();
-        if (wv == 0) {              // exclusive prefix over the nb <= 128 bins: two per lane
-            const int c0 = 2 * lane < nb ? OFF[2 * lane] : 0, c1 = 2 * lane + 1 < nb ? OFF[2 * lane + 1] : 0;
-            int x = c0 + c1;
+        if (wv == 0) {              // exclusive prefix over the nb bins: 128 per pass (two per lane), the running total carried over
+            int carry = 0;
+            for (int base = 0; base <= nb; base += 128) {
+                const int i0 = base + 2 * lane, i1 = i0 + 1;
+                const int c0 = i0 < nb ? OFF[i0] : 0, c1 = i1 < nb ? OFF[i1] : 0;
+                int x = c0 + c1;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int y = __shfl_up(x, d);
-                if (lane >= d) x += y;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int y = __shfl_up(x, d);
+                    if (lane >= d) x += y;
+                }
+                const int ex = carry + x - c0 - c1;
+                if (i0 <= nb) { OFF[i0] = ex; CUR[i0] = ex; }
+                if (i1 <= nb) { OFF[i1] = ex + c0; CUR[i1] = ex + c0; }
+                carry += __shfl(x, 63);
             }
-            const int ex = x - c0 - c1;
-            if (2 * lane <= nb) { OFF[2 * lane] = ex; CUR[2 * lane] = ex; }
-            if (2 * lane + 1 <= nb) { OFF[2 * lane + 1] = ex + c0; CUR[2 * lane + 1] = ex + c0; }
         }
         __syncthreads();
         for (int l = tid; l < nq; l += blockDim.x) {
@@ -1129,7 +1373,14 @@ __global__ __launch_bounds__(512) void k_reeval_bwd_gather(ReevalArgs a, int nch
                     sc[u][0] = sc[u][1] = 0.0f;
                     if (i + u < end) {
                         const int q = __builtin_amdgcn_readfirstlane(ORD[i + u]);
-                        v[u] = reinterpret_cast<const float2*>(a.dheads + (int64_t)q * RE)[lane];
+                        if (a.nkc > 1) {        // key chunks: the query's gradient is the sum of the chunks' dq~ rows
+                            for (int c = 0; c < a.nkc; ++c) {
+                                const float2 w2 = reinterpret_cast<const float2*>(a.mc_dq + ((int64_t)c * a.R * T + q) * RE)[lane];
+                                v[u].x += w2.x; v[u].y += w2.y;
+                            }
+                        } else {
+                            v[u] = reinterpret_cast<const float2*>(a.dheads + (int64_t)q * RE)[lane];
+                        }
                         if (!pass) {
 #pragma unroll
                             for (int k = 0; k < 2; ++k)
@@ -1184,7 +1435,7 @@ static int launch_bwd_t(const ReevalArgs& a, hipStream_t st)
     int ng = a.nchunk;
     while ((int64_t)((a.S + ng - 1) / ng) * a.T > GCAP && ng < a.S) ++ng;
     if ((int64_t)((a.S + ng - 1) / ng) * a.T > GCAP) return EAMRL_E_LAUNCH;
-    const size_t ldg = (2 * 132 + (size_t)((a.S + ng - 1) / ng) * a.T) * sizeof(int);
+    const size_t ldg = (2 * GBINS + (size_t)((a.S + ng - 1) / ng) * a.T) * sizeof(int);
     if (ldg > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_reeval_bwd_gather),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldg) != hipSuccess)
         return EAMRL_E_LAUNCH;
@@ -1192,9 +1443,44 @@ static int launch_bwd_t(const ReevalArgs& a, hipStream_t st)
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 
-int launch_reeval_bwd(const ReevalArgs& a, hipStream_t st)
+// key chunks: the forward call has left heads, the glimpse statistics and lse in the scratch / the caller's buffers
+static int launch_bwd_mc(const ReevalArgs& a0, hipStream_t st)
 {
-    if (a.B <= 0 || a.S <= 0 || a.T <= 0) return 0;
+    constexpr int RTT = 7;
+    ReevalArgs a = a0;
+    float* heads = mc_bind(a);
+    const int64_t RT = a.R * (int64_t)a.T;
+    const unsigned grid = (unsigned)(a.B * a.nchunk * a.nkc);
+    ReevalArgs l = a;
+    l.heads = heads; l.heads_T = a.T;
+    const size_t ldl = (4 * 16 * (size_t)TS + 8 * RTT * 256 + 2 * RE + 16 * RTT * DS + 16 + 32) * sizeof(float);
+    auto kl = k_reeval_bwd_logits<RTT, true>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldl) != hipSuccess)
+        return EAMRL_E_LAUNCH;
+    hipLaunchKernelGGL(kl, dim3(grid), dim3(512), ldl, st, l);
+    hipLaunchKernelGGL(k_reeval_mc_sum_dheads, dim3((unsigned)((RT * 32 + 255) / 256)), dim3(256), 0, st, a, heads);
+    const size_t lds = (4 * 16 * (size_t)TS + 8 * 4 * 256 + 8 * RTT * 256 + 2 * RE + 8 * 32) * sizeof(float);
+    auto k = k_reeval_bwd_glimpse<RTT, false, true>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return EAMRL_E_LAUNCH;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
+    int ng = a.nchunk;
+    while ((int64_t)((a.S + ng - 1) / ng) * a.T > GCAP && ng < a.S) ++ng;
+    if ((int64_t)((a.S + ng - 1) / ng) * a.T > GCAP) return EAMRL_E_LAUNCH;
+    const size_t ldg = (2 * GBINS + (size_t)((a.S + ng - 1) / ng) * a.T) * sizeof(int);
+    if (ldg > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_reeval_bwd_gather),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldg) != hipSuccess)
+        return EAMRL_E_LAUNCH;
+    hipLaunchKernelGGL(k_reeval_bwd_gather, dim3((unsigned)(a.B * ng)), dim3(512), ldg, st, a, ng);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+
+int launch_reeval_bwd(const ReevalArgs& a0, hipStream_t st)
+{
+    if (a0.B <= 0 || a0.S <= 0 || a0.T <= 0) return 0;
+    if (a0.M > KCH) return launch_bwd_mc(a0, st);
+    ReevalArgs a = a0;
+    a.nkc = 1; a.mc_koff = 0; a.mc_mstride = 4;
     if (a.M <= 32) return launch_bwd_t<2>(a, st);
     if (a.M <= 64) return launch_bwd_t<4>(a, st);
     return launch_bwd_t<7>(a, st);
@@ -1360,6 +1646,55 @@ __global__ void k_tsp_mask_bits(const int64_t* __restrict__ actions, uint32_t* _
         const int a = (int)actions[r * T + t];
         if (a >= 0 && a < M) m[a >> 5] &= ~(1u << (a & 31));
     }
+}
+
+// the same two in the layout of the key-chunked kernels: bits [R][T][nkc][4], bit i of chunk c = node 112 c + i
+__global__ void k_pack_mask_bits_chunked(const uint8_t* __restrict__ mask, uint32_t* __restrict__ bits, int64_t R, int M, int T, int t,
+                                         int nkc)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 32-bit word per thread
+    if (idx >= R * nkc * 4) return;
+    const int64_t r = idx / (nkc * 4);
+    const int cw = (int)(idx - r * nkc * 4), c = cw >> 2, w = cw & 3;
+    uint32_t v = 0;
+    for (int i = 0; i < 32; ++i) {
+        const int li = 32 * w + i, n = KCH * c + li;
+        if (li < KCH && n < M && mask[r * M + n]) v |= 1u << i;
+    }
+    bits[((r * T + t) * nkc + c) * 4 + w] = v;
+}
+__global__ void k_tsp_mask_bits_chunked(const int64_t* __restrict__ actions, uint32_t* __restrict__ bits, int64_t R, int M, int T, int nkc)
+{
+    // one thread per (row, chunk): the chunk's 112 bits through the steps
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * nkc) return;
+    const int64_t r = idx / nkc;
+    const int c = (int)(idx - r * nkc);
+    const int left = min(KCH, M - KCH * c);
+    uint32_t m[4];
+    for (int w = 0; w < 4; ++w) {
+        const int l = left - 32 * w;
+        m[w] = l >= 32 ? 0xffffffffu : l > 0 ? ((1u << l) - 1u) : 0u;
+    }
+    for (int t = 0; t < T; ++t) {
+        *reinterpret_cast<uint4*>(bits + ((r * T + t) * nkc + c) * 4) = make_uint4(m[0], m[1], m[2], m[3]);
+        const int a = (int)actions[r * T + t] - KCH * c;
+        if (a >= 0 && a < left) m[a >> 5] &= ~(1u << (a & 31));
+    }
+}
+int launch_pack_mask_bits_chunked(const uint8_t* mask, uint32_t* bits, int64_t R, int M, int T, int t, hipStream_t st)
+{
+    if (R <= 0) return 0;
+    const int nkc = (M + KCH - 1) / KCH;
+    hipLaunchKernelGGL(k_pack_mask_bits_chunked, dim3((unsigned)((R * nkc * 4 + 255) / 256)), dim3(256), 0, st, mask, bits, R, M, T, t, nkc);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+}
+int launch_tsp_mask_bits_chunked(const int64_t* actions, uint32_t* bits, int64_t R, int M, int T, hipStream_t st)
+{
+    if (R <= 0) return 0;
+    const int nkc = (M + KCH - 1) / KCH;
+    hipLaunchKernelGGL(k_tsp_mask_bits_chunked, dim3((unsigned)((R * nkc + 127) / 128)), dim3(128), 0, st, actions, bits, R, M, T, nkc);
+    return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
 
 int launch_tsp_mask_bits(const int64_t* actions, uint32_t* bits, int64_t R, int M, int T, hipStream_t st)

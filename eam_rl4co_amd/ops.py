@@ -446,17 +446,44 @@ def replay_states(st, actions, B):
     lib = _lib.load()
     _chk(actions, "actions", torch.int64)
     R, T = actions.shape
-    if R != st.R or st.env_name not in ("cvrp", "cvrptw", "pctsp", "op") or st.M > 128:
-        raise ValueError("replay_states: cvrp / cvrptw / pctsp / op states of at most 128 nodes, one action row per state row")
+    if R != st.R or st.env_name not in ("cvrp", "cvrptw", "pctsp", "op") or st.M > 1024:
+        raise ValueError("replay_states: cvrp / cvrptw / pctsp / op states of at most 1024 nodes, one action row per state row")
     dev = actions.device
     NC = 2 if st.env_name == "cvrptw" else 1
-    bits = torch.empty(R, T, 4, dtype=torch.int32, device=dev)
+    # (graphs above 112 nodes: the chunked layout of the key-chunked re-evaluation kernels)
+    bits = torch.empty((R, T, -(-st.M // 112), 4) if st.M > 112 else (R, T, 4), dtype=torch.int32, device=dev)
     idxA = torch.empty(R, T, dtype=torch.int32, device=dev)
     sc = torch.empty(NC, R, T, dtype=torch.float32, device=dev)
     ss = st.struct()
     _lib.check(lib.eamrl_replay_states(ENVS[st.env_name], C.byref(ss), R, int(B), st.M, _ptr(actions), T, _ptr(bits), _ptr(idxA),
                                        _ptr(sc), _stream(actions)), "eamrl_replay_states")
     return bits, idxA, sc
+
+
+KEY_CHUNK = 112        # keys per chunk of the re-evaluation kernels (graphs above 112 nodes: csrc/reeval.hip)
+
+
+def tsp_mask_bits_chunked(actions, M):
+    """TSP masks of every step in the layout of the key-chunked re-evaluation: int32 [R, T, nkc, 4], bit i of chunk c = node 112 c + i."""
+    lib = _lib.load()
+    _chk(actions, "actions", torch.int64)
+    R, T = actions.shape
+    nkc = -(-int(M) // KEY_CHUNK)
+    bits = torch.empty(R, T, nkc, 4, dtype=torch.int32, device=actions.device)
+    _lib.check(lib.eamrl_tsp_mask_bits_chunked(_ptr(actions), _ptr(bits), R, int(M), T, _stream(actions)), "eamrl_tsp_mask_bits_chunked")
+    return bits
+
+
+def pack_mask_bits_chunked_(mask, bits, t):
+    """bits[:, t] (int32 [R, T, nkc, 4], chunked layout) <- mask [R, M] (bool / uint8)."""
+    lib = _lib.load()
+    R, M = mask.shape
+    _chk(bits, "mask bits", torch.int32)
+    nkc = -(-int(M) // KEY_CHUNK)
+    if bits.dim() != 4 or bits.shape[0] != R or bits.shape[2] != nkc or bits.shape[3] != 4:
+        raise ValueError("pack_mask_bits_chunked: bits must be [R, T, nkc, 4] int32")
+    _lib.check(lib.eamrl_pack_mask_bits_chunked(_ptr(_bytes(mask)), _ptr(bits), R, M, bits.shape[1], int(t), _stream(mask)),
+               "eamrl_pack_mask_bits_chunked")
 
 
 def replay_states_sdvrp(st, actions):
@@ -498,7 +525,13 @@ class ReevalPlan:
         _chk(buf, "operands", torch.float32)
         # slots: {"K", "V", "Lp", "Pa"[, "Pb"]} -> E-wide column block of buf (default: side by side in that order); with it
         # the plan reads a decoder cache (ops.DecodeCache.buf) in place
-        self.B, self.M, width = buf.shape
+        # (a decoder cache of a large graph keeps its operands as planes [P, B, M, E] instead of side by side [B, M, P * E])
+        self.planes = buf.dim() == 4
+        if self.planes:
+            _, self.B, self.M, width = buf.shape
+            E = width
+        else:
+            self.B, self.M, width = buf.shape
         self.slots = slots or {n: i for i, n in enumerate(["K", "V", "Lp", "Pa"] + (["Pb"] if has_pb else []))}
         self.E = E if E is not None else width // (5 if has_pb else 4)
         self.buf, self.has_pb, self.gctx, self.cvec = buf, has_pb, gctx, cvec
@@ -511,7 +544,15 @@ class ReevalPlan:
         _chk(idxA, "idxA", torch.int32, (R, T))
         if has_pb:
             _chk(idxB, "idxB", torch.int32, (R, T))
-        _chk(maskbits, "mask bits", torch.int32, (R, T, 4))
+        # graphs above 112 nodes: key chunks (csrc/reeval.hip) -- chunked mask layout, a scratch that lives from forward to backward,
+        # the forward pass always runs (its statistics feed the backward), no rollout heads
+        self.nkc = -(-self.M // KEY_CHUNK) if self.M > KEY_CHUNK else 1
+        self.scratch = None
+        if self.nkc > 1:
+            _chk(maskbits, "mask bits", torch.int32, (R, T, self.nkc, 4))
+            rollout_heads = None
+        else:
+            _chk(maskbits, "mask bits", torch.int32, (R, T, 4))
         self.NC = 0 if cvec is None else cvec.shape[0]
         if self.NC:
             _chk(cvec, "state columns", torch.float32, (self.NC, self.E))
@@ -539,7 +580,7 @@ class ReevalPlan:
                     or rollout_heads.shape[1] < T - int(tstart):
                 raise ValueError("reeval: rollout heads must be [R, >= T - tstart, E]")
             self.heads = rollout_heads
-        if rollout_logp is not None:
+        if rollout_logp is not None and self.nkc == 1:
             _chk(rollout_logp, "rollout log-probs", torch.float32, (R, T))
             self.logp, self.lse = rollout_logp, None
         else:
@@ -548,11 +589,11 @@ class ReevalPlan:
 
     def _struct(self):
         s = _lib.Reeval()
-        E4 = self.E * 4
+        E4 = self.B * self.M * self.E * 4 if self.planes else self.E * 4
         base = self.buf.data_ptr()
         s.K, s.V, s.Lp, s.Pa = (C.c_void_p(base + self.slots[n] * E4) for n in ("K", "V", "Lp", "Pa"))
         s.Pb = C.c_void_p(base + self.slots["Pb"] * E4) if self.has_pb else None
-        s.ld = self.buf.shape[2]
+        s.ld = self.buf.shape[-1]
         s.gctx, s.Cvec, s.NC = _ptr(self.gctx), _ptr(self.cvec), self.NC
         s.idxA, s.idxB, s.sc = _ptr(self.idxA), _ptr(self.idxB if self.has_pb else None), _ptr(self.sc if self.NC else None)
         s.maskbits, s.actions = _ptr(self.maskbits), _ptr(self.actions)
@@ -564,6 +605,11 @@ class ReevalPlan:
             s.heads, s.heads_T = _ptr(self.heads), self.heads.shape[1]
         if self.dyn is not None:
             s.rem, s.dyn = _ptr(self.rem), _ptr(self.dyn)
+        if self.nkc > 1:
+            if self.scratch is None:
+                n = int(_lib.load().eamrl_reeval_scratch_floats(self.R, self.T, self.M))
+                self.scratch = torch.empty(n, dtype=torch.float32, device=self.buf.device)
+            s.nkc, s.scratch = self.nkc, _ptr(self.scratch)
         return s
 
     def forward(self):
@@ -582,12 +628,15 @@ class ReevalPlan:
 
     def backward(self, glogp):
         """-> (dbuf [B, M, P*E], dgctx or None, dcvec or None)"""
+        if self.planes:
+            raise ValueError("reeval backward: operands side by side [B, M, P * E] (a plane-layout decoder cache serves the forward only)")
         lib = _lib.load()
         glogp = glogp.contiguous()
         _chk(glogp, "grad of logp", torch.float32, (self.R, self.T))
         dev = self.buf.device
         dbuf = torch.zeros_like(self.buf)
-        dheads = torch.empty(self.R, self.T, self.E, dtype=torch.float32, device=dev)
+        # (key chunks: per-chunk partials of dheads, then the per-chunk query gradients)
+        dheads = torch.empty((2 * self.nkc if self.nkc > 1 else 1) * self.R, self.T, self.E, dtype=torch.float32, device=dev)
         dg = torch.zeros_like(self.gctx) if self.gctx is not None else None
         dc = torch.zeros_like(self.cvec) if self.NC else None
         s = self._struct()

@@ -838,7 +838,7 @@ class AttentionModelPolicy(nn.Module):
             from .train import native_reeval_supported
             tk, tp = decoding_kwargs.get("top_k", 0) or 0, decoding_kwargs.get("top_p", 0.0) or 0.0
             Mq = td["action_mask"].shape[-1]
-            if native_reeval_supported(self, Mq) and Mq <= 128 and not tk and not (0.0 < tp < 1.0):
+            if native_reeval_supported(self, Mq) and not tk and not (0.0 < tp < 1.0):
                 store_all_logp, entropy_native = False, return_entropy
         num_starts = decoding_kwargs.pop("num_starts", None)
         num_samples = decoding_kwargs.pop("num_samples", None)

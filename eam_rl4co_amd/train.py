@@ -635,7 +635,8 @@ def native_reeval_supported(policy, M: int) -> bool:
 
     dec = policy.decoder
     return (os.environ.get("EAMRL_NATIVE_REEVAL", "1") != "0" and policy.env_name in _NATIVE_ENVS
-            and ops.reeval_supported(M, dec.embed_dim, dec.num_heads))
+            and ops.reeval_supported(M, dec.embed_dim, dec.num_heads)
+            and not (policy.env_name == "sdvrp" and M > ops.KEY_CHUNK))       # (the dynamic embedding: single-chunk kernels only)
 
 
 @torch.no_grad()
@@ -654,7 +655,7 @@ def replay_states(policy, td, actions, S: int, multistart: bool):
     actions = actions.contiguous()
     if env_name == "tsp":
         M = td["locs"].shape[1]
-        bits = ops.tsp_mask_bits(actions, M)
+        bits = ops.tsp_mask_bits(actions, M) if M <= ops.KEY_CHUNK else ops.tsp_mask_bits_chunked(actions, M)
         a32 = actions.to(torch.int32)
         prev = torch.cat((torch.full((R, 1), -1, dtype=torch.int32, device=dev), a32[:, :-1]), 1)       # a_{t-1}
         first = a32[:, :1].expand(R, T).contiguous()
@@ -672,17 +673,18 @@ def replay_states(policy, td, actions, S: int, multistart: bool):
         st = state_from_td(env_name, td, S, copy=False)
         bits, idxA, sc, rem = ops.replay_states_sdvrp(st, actions)
         return dict(maskbits=bits, idxA=idxA, idxB=None, sc=sc, tstart=1 if multistart else 0, placeholder=False, rem=rem)
-    if os.environ.get("EAMRL_REPLAY_LOOP", "0") != "1":        # one launch: the env's transitions replayed inside a kernel
+    big = td["action_mask"].shape[-1] > ops.KEY_CHUNK            # key-chunked kernels: their mask layout (either way)
+    if os.environ.get("EAMRL_REPLAY_LOOP", "0") != "1":         # one launch: the env's transitions replayed inside a kernel
         st = state_from_td(env_name, td, S, copy=False)         # read-only
         bits, idxA, sc = ops.replay_states(st, actions, B)
         return dict(maskbits=bits, idxA=idxA, idxB=None, sc=sc, tstart=1 if multistart else 0, placeholder=False)
     st = state_from_td(env_name, td, S)                         # (the step-by-step form, kept as the cross-check)
     NC = 2 if env_name == "cvrptw" else 1
-    bits = torch.empty(R, T, 4, dtype=torch.int32, device=dev)
+    bits = torch.empty((R, T, -(-st.M // ops.KEY_CHUNK), 4) if big else (R, T, 4), dtype=torch.int32, device=dev)
     idxA = torch.empty(R, T, dtype=torch.int32, device=dev)
     sc = torch.empty(NC, R, T, dtype=torch.float32, device=dev)
     for t in range(T):
-        ops.pack_mask_bits_(st.mask, bits, t)
+        (ops.pack_mask_bits_chunked_ if big else ops.pack_mask_bits_)(st.mask, bits, t)
         idxA[:, t] = st.cur
         if env_name == "pctsp":          # prize still to collect, clamped at 0 (context.py:194-208)
             sc[0, :, t] = (st.vcap - st.used).clamp_(min=0)

@@ -346,9 +346,19 @@ typedef struct eamrl_reeval {
      * rem [R][T][128] (rows zero padded; eamrl_replay_states_sdvrp records them), dyn = wk | wv | lw [3][E] with
      * lw = wl folded through project_out like Lp; ddyn [3][E] accumulated (backward).  Excludes `heads`. */
     const float* rem; const float* dyn; float* ddyn;
+    /* Graphs above 112 nodes (M <= 1024; not with `heads`, `dyn` or a NULL lse): the keys are split into nkc = ceil(M / 112) chunks,
+     * one workgroup per (instance, row chunk, key chunk); the softmax statistics of the glimpse and of the logits are combined
+     * across the chunks by small kernels, and the backward uses rs = heads . dheads instead of a row sum over all keys.
+     * nkc <= 1: the single-chunk kernels.  Otherwise maskbits is [R][T][nkc][4] (bit i of chunk c = node 112 c + i;
+     * eamrl_tsp_mask_bits_chunked / eamrl_pack_mask_bits_chunked), `scratch` holds eamrl_reeval_scratch_floats(R, T, M) floats
+     * that must survive from the forward to the backward call, and dheads is [nkc + nkc][R][T][E] (per-chunk partials, then the
+     * per-chunk query gradients).  The mc_* fields are set by the library. */
+    int nkc; float* scratch;
+    int mc_koff, mc_mstride; float *mc_part_o, *mc_part_s, *mc_gstat, *mc_lpart, *mc_rsq, *mc_dq;
 } eamrl_reeval;
 
-int eamrl_reeval_supported(int M, int E, int H);                  /* 1 for M <= 112, E = 128, H = 8 */
+int eamrl_reeval_supported(int M, int E, int H);                  /* 1 for M <= 112 (1024 with key chunks), E = 128, H = 8 */
+int64_t eamrl_reeval_scratch_floats(int64_t R, int T, int M);     /* 0 for M <= 112 */
 int eamrl_reeval_forward(const eamrl_reeval* p, void* stream);    /* -> logp, lse (lse may be NULL) [, entropy] */
 int eamrl_reeval_backward(const eamrl_reeval* p, void* stream);   /* glogp, lse (or rollout logp) -> dK dV dLp dPa dPb dgctx dCvec */
 
@@ -356,6 +366,9 @@ int eamrl_reeval_backward(const eamrl_reeval* p, void* stream);   /* glogp, lse 
 int eamrl_pack_mask_bits(const uint8_t* mask, uint32_t* bits, int64_t R, int M, int T, int t, void* stream);
 /* TSP: all T steps from the action rows (node n feasible at step t iff not among a_0 .. a_{t-1})  [tsp/env.py:62-88]. */
 int eamrl_tsp_mask_bits(const int64_t* actions, uint32_t* bits, int64_t R, int M, int T, void* stream);
+/* The same two in the chunked layout of graphs above 112 nodes: bits [R][T][nkc][4], nkc = ceil(M / 112), bit i of chunk c = node 112 c + i. */
+int eamrl_pack_mask_bits_chunked(const uint8_t* mask, uint32_t* bits, int64_t R, int M, int T, int t, void* stream);
+int eamrl_tsp_mask_bits_chunked(const int64_t* actions, uint32_t* bits, int64_t R, int M, int T, void* stream);
 
 /* ---- per-step decode ------------------------------------------------------------------------------ */
 
@@ -496,7 +509,8 @@ int eamrl_check_solution(int env, const int64_t* actions, const float* demand, c
  * transitions of actions [R][T] are replayed, and BEFORE each step t are recorded: bits[r][t][4] the feasibility mask,
  * idxA[r][t] the current node, sc[0][r][t] = vcap - used (PCTSP: clamped at 0: prize still to collect; OP: length still
  * allowed) and, CVRPTW, sc[1][r][t] = the current time.  Same transitions as eamrl_*_step_mask (the same code), i.e. the
- * same result as T rounds of {eamrl_pack_mask_bits, copy, eamrl_*_step_mask}.  M <= 128. */
+ * same result as T rounds of {eamrl_pack_mask_bits, copy, eamrl_*_step_mask}.  M <= 128. 
+ * Graphs above 112 nodes (M <= 1024): bits is [R][T][nkc][4] in the chunked layout of eamrl_reeval (nkc = ceil(M / 112)). */
 int eamrl_replay_states(int env, const eamrl_state* state, int64_t R, int64_t B, int M, const int64_t* actions, int T,
                         uint32_t* bits, int32_t* idxA, float* sc, void* stream);
 /* The same for SDVRP  [sdvrp/env.py:58-92,137-146]: state->rem [R][M] (demand_with_depot), used, vcap, cur; additionally

@@ -584,6 +584,8 @@ def test_entropy_and_stepwise_path_agree_with_single_launch():
     ("pctsp", 20, 5, dict(decode_type="sampling")), ("op", 20, 5, dict(decode_type="greedy")),
     ("cvrptw", 20, 4, dict(decode_type="sampling")), ("tsp", 112, 2, dict(decode_type="sampling", temperature=1.7)),
     ("sdvrp", 20, 5, dict(decode_type="sampling")), ("sdvrp", 50, 3, dict(decode_type="multistart_sampling", num_starts=5)),
+    # graphs above 112 nodes: the key-chunked forward kernels
+    ("tsp", 150, 3, dict(decode_type="sampling")), ("cvrp", 200, 2, dict(decode_type="multistart_sampling", num_starts=4)),
 ])
 def test_return_entropy_single_launch_equals_stepwise(env_name, N, B, kw):
     """`return_entropy=True` (what the fork's EAM trainer passes, earl/model.py:153-155): the rollout stays one launch and

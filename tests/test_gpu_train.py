@@ -136,7 +136,9 @@ def test_instance_norm_training_kernels_match_torch(B, N, E):
 
 @pytest.mark.parametrize("env_name,N,B,ns", [("cvrp", 20, 7, 0), ("cvrp", 100, 3, 6), ("cvrp", 127, 2, 0), ("cvrptw", 20, 5, 0),
                                              ("cvrptw", 50, 2, 4), ("pctsp", 20, 6, 0), ("pctsp", 100, 2, 5), ("op", 20, 6, 0),
-                                             ("op", 100, 3, 4)])
+                                             ("op", 100, 3, 4),
+                                             # graphs above 112 nodes: the chunked mask layout, both ways
+                                             ("cvrp", 150, 3, 0), ("cvrp", 230, 2, 3), ("pctsp", 130, 2, 0), ("op", 300, 2, 0)])
 def test_replay_states_kernel_equals_step_by_step(env_name, N, B, ns):
     """eamrl_replay_states (the env transitions replayed inside one kernel) gives bit for bit what T rounds of
     {pack mask bits, copy current node, state scalar, env step kernel} give: the inputs of the re-evaluation kernels."""
@@ -544,6 +546,9 @@ def test_linear_autograd_function_matches_torch(relu, with_res):
     ("pomo_tsp", "tsp", 50, 4, 50, None), ("pomo_tsp", "tsp", 100, 3, 10, None), ("am_tsp", "tsp", 112, 2, 0, None),
     ("am_cvrp", "cvrp", 20, 5, 0, None), ("am_cvrp", "cvrp", 50, 3, 6, None), ("am_cvrp", "cvrp", 100, 2, 3, None),
     ("am_pctsp", "pctsp", 20, 4, 0, None), ("am_op", "op", 20, 4, 4, None), ("am_cvrptw", "cvrptw", 20, 4, 0, None),
+    # graphs above 112 nodes: key chunks of 112 (2, 2, 3 and 5 chunks; the last ones ragged), statistics combined across them
+    ("am_tsp", "tsp", 150, 3, 0, None), ("am_tsp", "tsp", 200, 2, 4, None), ("am_cvrp", "cvrp", 120, 3, 0, None),
+    ("am_cvrp", "cvrp", 230, 2, 3, None), ("am_tsp", "tsp", 500, 1, 2, None), ("am_op", "op", 130, 2, 0, None),
     # SDVRP: the dynamic embedding's rank-one terms (remaining demands per step) in all three kernels
     ("am_sdvrp", "sdvrp", 20, 5, 0, None), ("am_sdvrp", "sdvrp", 50, 3, 6, None), ("am_sdvrp", "sdvrp", 100, 2, 3, None),
     # the gather kernel's cooperative bins (the depot of CVRP names > 512 queries of an instance) and its own chunking
@@ -576,8 +581,11 @@ def test_native_reevaluation_matches_autograd(cfg, env_name, N, B, ns, ms):
                                      rollout_logp=out["log_likelihood"] if native == "from_rollout" else None)
         (lp * w).sum().backward()
         res.append((lp.detach(), {k: p.grad.clone() for k, p in pol.named_parameters() if p.grad is not None}))
-    assert torch.equal(res[2][0], out["log_likelihood"])
     tol = 2e-4 if env_name == "cvrptw" else 1e-5          # cvrptw: unscaled inputs (see the oracle tests)
+    if td["locs"].shape[1] <= 112:
+        assert torch.equal(res[2][0], out["log_likelihood"])
+    else:       # key chunks: the forward kernels always run (their statistics feed the backward), the rollout's values are not handed back
+        np.testing.assert_allclose(res[2][0].cpu().numpy(), out["log_likelihood"].cpu().numpy(), rtol=0, atol=tol)
     np.testing.assert_allclose(res[0][0].cpu().numpy(), out["log_likelihood"].cpu().numpy(), rtol=0, atol=tol)
     np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), rtol=0, atol=tol)
     assert res[0][1].keys() == res[1][1].keys()
