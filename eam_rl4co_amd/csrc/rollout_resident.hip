@@ -227,8 +227,13 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
     for (;;) {
         // the LDS reads that open a step are issued together: episode flag and this lane's two mask bytes
         // (slots >= M hold 0 for the whole episode, so no range check is needed)
+        // (+ the wave's 32 query columns, lane e = column e: broadcast by v_readlane in S1 -- one LDS read instead of eight
+        //  wave-uniform float4 reads with three exposed latencies and 32 registers of buffers.  Measured and dropped: forcing the
+        //  flag's read into the same wait as the other three with an empty asm -- the four pinned registers cost 14 more spilled
+        //  dwords at the limit of 256, 0.485 ms instead of 0.460.)
         done = l.done != 0;
         const bool f0 = l.msk[n0] != 0, f1 = l.msk[n1] != 0;
+        const float qv = l.q[32 * wv + (lane & 31)];
         if (done || t >= a.t_max) break;
         // prefetch this step's per-row inputs (latency hidden behind the glimpse)
         float nz0 = 1.0f, nz1 = 1.0f;
@@ -252,7 +257,11 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             for (int d = 0; d < RD; d += 4) {
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
-                    const float4 qq = *reinterpret_cast<const float4*>(l.q + (2 * wv + hh) * RD + d);
+                    float4 qq;
+                    qq.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv), hh * RD + d));
+                    qq.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv), hh * RD + d + 1));
+                    qq.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv), hh * RD + d + 2));
+                    qq.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv), hh * RD + d + 3));
                     if (SD) {       // q_h . wk_h (wavefront-uniform, every lane keeps its own copy)
                         const float4 dk = *reinterpret_cast<const float4*>(l.dynv + (2 * wv + hh) * RD + d);
                         qw[hh] = fma_(qq.x, dk.x, qw[hh]); qw[hh] = fma_(qq.y, dk.y, qw[hh]);
@@ -302,9 +311,22 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             static_assert(CR <= CP && CP % 2 == 0, "a chunk's CR slots must lie inside its padded row");
             const float* wp = l.w + h * WROW + vg * (2 * CP);
             f32x2 acc2 = splat2(0.0f), zc[4] = {splat2(0.0f), splat2(0.0f), splat2(0.0f), splat2(0.0f)};
+            // the reads of the row are issued eight deep (what the register file has room for): left to itself the compiler keeps
+            // two in flight and the chain below waits out an LDS latency per float4 -- the glimpse was nine exposed latencies long
+            constexpr int NWQ = (CR + 1) / 2, WDEEP = NWQ < 8 ? NWQ : 8;
+            float4 wq[NWQ];
+#pragma unroll
+            for (int i = 0; i < WDEEP; ++i) wq[i] = *reinterpret_cast<const float4*>(wp + 4 * i);
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int i = 0; i < CR; i += 2) {          // slots >= C hold w = 0 (and are skipped beyond CR)
-                const float4 ww = *reinterpret_cast<const float4*>(wp + 2 * i);
+                if ((i >> 1) == NWQ - WDEEP && NWQ > WDEEP) {      // the first NWQ - WDEEP buffers are free again: the rest of the row
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int k = WDEEP; k < NWQ; ++k) wq[k] = *reinterpret_cast<const float4*>(wp + 4 * k);
+                    asm volatile("" ::: "memory");
+                }
+                const float4 ww = wq[i >> 1];
                 const f32x2 wa = (f32x2){ww.x, ww.y}, wb = (f32x2){ww.z, ww.w};
                 zc[i & 3] = zc[i & 3] + wa;
                 acc2 = pk_fma(wa, v2[i], acc2);
@@ -328,16 +350,19 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
         }
         STAMP(1);
 
-        // ---- S4: the wave's 32 glimpse values, re-read as a wave-private LDS row; then the logit partials of both nodes ----
+        // ---- S4: the wave's 32 glimpse values (lane e holds column e) broadcast by v_readlane -- scalar operands of the chains, no
+        //      LDS round trip (round 3: the wave-private row cost a write -> read latency and eight reads the register-starved
+        //      loop could only issue two at a time); then the logit partials of both nodes ---------------------------------------
         {
-            float* hw = l.headsw + wv * 32;
-            if (lane < 32) hw[lane] = head_e;
-            __builtin_amdgcn_wave_barrier();        // same wavefront: LDS executes its accesses in order
             f32x2 c2 = splat2(0.0f);            // (node n0, node n1)
             float hl = 0.0f;
 #pragma unroll
             for (int e = 0; e < 32; e += 4) {
-                const float4 h4 = *reinterpret_cast<const float4*>(hw + e);
+                float4 h4;
+                h4.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head_e), e));
+                h4.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head_e), e + 1));
+                h4.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head_e), e + 2));
+                h4.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(head_e), e + 3));
                 if (SD) {       // heads_c . lw_c of this wavefront's column chunk
                     const float4 dl = *reinterpret_cast<const float4*>(l.dynv + 2 * RE + 32 * wv + e);
                     hl = fma_(h4.x, dl.x, hl); hl = fma_(h4.y, dl.y, hl);
