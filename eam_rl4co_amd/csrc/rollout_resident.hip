@@ -311,16 +311,27 @@ __global__ __launch_bounds__(RB, 2) void k_rollout_resident(DecArgs a, int S, in
             static_assert(CR <= CP && CP % 2 == 0, "a chunk's CR slots must lie inside its padded row");
             const float* wp = l.w + h * WROW + vg * (2 * CP);
             f32x2 acc2 = splat2(0.0f), zc[4] = {splat2(0.0f), splat2(0.0f), splat2(0.0f), splat2(0.0f)};
-            // the reads of the row are issued eight deep (what the register file has room for): left to itself the compiler keeps
-            // two in flight and the chain below waits out an LDS latency per float4 -- the glimpse was nine exposed latencies long
-            constexpr int NWQ = (CR + 1) / 2, WDEEP = NWQ < 8 ? NWQ : 8;
+            // The reads of the row run ahead of the chain that consumes them: left to itself the compiler keeps two in flight and the
+            // chain below waits out an LDS latency per float4 (the glimpse was nine exposed latencies long).  TSP / CVRP / SDVRP / PCTSP
+            // at <= 104 nodes (CR <= 26): eight reads up front, the remaining ones once their buffers are free (0.491 -> 0.460 ms at
+            // TSP-100 x 1024).  Larger chunks and the envs with more state of their own have less register room -- spills cost more
+            // than the prefetch hides (CVRPTW-100: 1.17 -> 1.12 ms with the shallower form) --: a rolling window of 4 .. 6.
+            // (Measured and dropped for CR <= 26: the rolling form, 0.47 ms; the episode flag riding with the query as float2, 0.47 ms.)
+            constexpr int NWQ = (CR + 1) / 2;
+            constexpr bool ROLL = CR > 26 || TW || OP;
+            constexpr int WD0 = ROLL ? ((CR <= 26 ? 7 : CR <= 28 ? 6 : 4) - ((TW || OP) ? 2 : 0)) : 8, WDEEP = NWQ < WD0 ? NWQ : WD0;
             float4 wq[NWQ];
 #pragma unroll
             for (int i = 0; i < WDEEP; ++i) wq[i] = *reinterpret_cast<const float4*>(wp + 4 * i);
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int i = 0; i < CR; i += 2) {          // slots >= C hold w = 0 (and are skipped beyond CR)
-                if ((i >> 1) == NWQ - WDEEP && NWQ > WDEEP) {      // the first NWQ - WDEEP buffers are free again: the rest of the row
+                if (ROLL) {
+                    if ((i >> 1) + WDEEP < NWQ) {      // (the buffer of the float4 consumed one round ago is free)
+                        wq[(i >> 1) + WDEEP] = *reinterpret_cast<const float4*>(wp + 4 * ((i >> 1) + WDEEP));
+                        asm volatile("" ::: "memory");
+                    }
+                } else if ((i >> 1) == NWQ - WDEEP && NWQ > WDEEP) {      // the first NWQ - WDEEP buffers are free again: the rest of the row
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int k = WDEEP; k < NWQ; ++k) wq[k] = *reinterpret_cast<const float4*>(wp + 4 * k);
