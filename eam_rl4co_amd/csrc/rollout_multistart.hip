@@ -259,35 +259,54 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
     const float* const gq_b = a.gctx ? a.gctx + b * ME + 4 * e4 : nullptr;
     const float* const cv_b = a.cvec + 4 * e4;
     const uint32_t ld24 = (uint32_t)ld;
-    auto q_load = [&](int qtile) -> float4 {
-        const int s = 16 * qtile + jq;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s < S && !s_done[s]) {
-            float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gq_b) g4 = *reinterpret_cast<const float4*>(gq_b);
-            if (DEP) {              // EnvContext: fma(state column, state scalar, Pa[current]) + graph context -- free capacity (VRPContext),
-                                    // prize still to collect clamped at 0 (PCTSPContext), length still allowed (OPContext); CVRPTW: + the clock column
-                const float4 c4 = *reinterpret_cast<const float4*>(cv_b);
-                const float4 p = *reinterpret_cast<const float4*>(pa_b + __umul24((uint32_t)s_cur[s], ld24));
-                float fr = s_cap[s] - s_used[s];
-                if (PC) fr = fr < 0.0f ? 0.0f : fr;
-                float4 y = make_float4(fma_(c4.x, fr, p.x), fma_(c4.y, fr, p.y), fma_(c4.z, fr, p.z), fma_(c4.w, fr, p.w));
-                if (TW) {
-                    const float4 c2 = *reinterpret_cast<const float4*>(cv_b + ME);
-                    const float now = s_time[s];
-                    y = make_float4(fma_(c2.x, now, y.x), fma_(c2.y, now, y.y), fma_(c2.z, now, y.z), fma_(c2.w, now, y.w));
-                }
-                v = make_float4(y.x + g4.x, y.y + g4.y, y.z + g4.z, y.w + g4.w);
-            } else if (s_istep[s] == 0) {
-                const float4 c4 = *reinterpret_cast<const float4*>(cv_b);
-                v = make_float4(c4.x + g4.x, c4.y + g4.y, c4.z + g4.z, c4.w + g4.w);
-            } else {
-                const float4 p = *reinterpret_cast<const float4*>(pa_b + __umul24((uint32_t)s_first[s], ld24));
-                const float4 c4 = *reinterpret_cast<const float4*>(pb_b + __umul24((uint32_t)s_cur[s], ld24));
-                v = make_float4((p.x + c4.x) + g4.x, (p.y + c4.y) + g4.y, (p.z + c4.z) + g4.z, (p.w + c4.w) + g4.w);
+    // A tile's query rows in two halves: q_fetch reads the start's state and ISSUES the row loads (branch-free, nothing computed on
+    // what they return), q_combine does the arithmetic.  Round 3: as one function, called ahead of the logit phase to hide the
+    // loads behind it, the compiler put the additions -- and a wait for every load -- in front of the MFMAs: an L2 latency per
+    // tile with the whole workgroup stalled.
+    struct QRaw { float4 a, b, g, c2; float fr, now; int fl; };     // fl: bit 0 = the start is live, bit 1 = TSP before the first pick
+    auto q_fetch = [&](int qtile) -> QRaw {
+        QRaw r;
+        const int s = 16 * qtile + jq, sc = s < S ? s : 0;
+        // (the start's state words read together: one LDS latency, not one per word)
+        const int st_done = s_done[sc], st_cur = s_cur[sc], st_first = DEP ? 0 : s_first[sc], st_istep = DEP ? 1 : s_istep[sc];
+        r.fl = (s < S && !st_done) ? 1 : 0;
+        r.g = make_float4(0.f, 0.f, 0.f, 0.f);
+        r.c2 = r.g;
+        r.fr = r.now = 0.0f;
+        if (gq_b) r.g = *reinterpret_cast<const float4*>(gq_b);
+        const uint32_t curn = (uint32_t)min(max(st_cur, 0), M - 1);
+        if (DEP) {
+            r.a = *reinterpret_cast<const float4*>(cv_b);
+            r.b = *reinterpret_cast<const float4*>(pa_b + __umul24(curn, ld24));
+            float fr = s_cap[sc] - s_used[sc];
+            if (PC) fr = fr < 0.0f ? 0.0f : fr;
+            r.fr = fr;
+            if (TW) {
+                r.c2 = *reinterpret_cast<const float4*>(cv_b + ME);
+                r.now = s_time[sc];
             }
+        } else {
+            const uint32_t firstn = (uint32_t)min(max(st_first, 0), M - 1);
+            if (st_istep == 0) r.fl |= 2;
+            r.a = *reinterpret_cast<const float4*>(pa_b + __umul24(firstn, ld24));
+            r.b = *reinterpret_cast<const float4*>(pb_b + __umul24(curn, ld24));
+            r.c2 = *reinterpret_cast<const float4*>(cv_b);
         }
-        return v;
+        return r;
+    };
+    auto q_combine = [&](const QRaw& r) -> float4 {
+        float4 v;
+        if (DEP) {              // EnvContext: fma(state column, state scalar, Pa[current]) + graph context -- free capacity (VRPContext),
+                                // prize still to collect clamped at 0 (PCTSPContext), length still allowed (OPContext); CVRPTW: + the clock column
+            float4 y = make_float4(fma_(r.a.x, r.fr, r.b.x), fma_(r.a.y, r.fr, r.b.y), fma_(r.a.z, r.fr, r.b.z), fma_(r.a.w, r.fr, r.b.w));
+            if (TW) y = make_float4(fma_(r.c2.x, r.now, y.x), fma_(r.c2.y, r.now, y.y), fma_(r.c2.z, r.now, y.z), fma_(r.c2.w, r.now, y.w));
+            v = make_float4(y.x + r.g.x, y.y + r.g.y, y.z + r.g.z, y.w + r.g.w);
+        } else if (r.fl & 2) {
+            v = make_float4(r.c2.x + r.g.x, r.c2.y + r.g.y, r.c2.z + r.g.z, r.c2.w + r.g.w);
+        } else {
+            v = make_float4((r.a.x + r.b.x) + r.g.x, (r.a.y + r.b.y) + r.g.y, (r.a.z + r.b.z) + r.g.z, (r.a.w + r.b.w) + r.g.w);
+        }
+        return (r.fl & 1) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto q_store = [&](const float4 v) {
         float* p = QT + jq * TS + e4;
@@ -308,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
             // With more than one tile per step the NEXT tile's rows are fetched behind this tile's logit phase and stored
             // before its last barrier (q_next below): a tile's starts are touched by no other tile, so their state is final
             // since their own transition one round earlier, and QT is free once every wave has left the glimpse phase.
-            if (!have_q) q_store(q_load(qt));
+            if (!have_q) q_store(q_combine(q_fetch(qt)));
             const int sq = 16 * qt + j;                           // this lane's start (query j of the tile)
             const bool live = sq < S && !s_done[sq];
             uint4 mb = make_uint4(0, 0, 0, 0);
@@ -496,8 +515,8 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
             MSTAMP(4);
             __syncthreads();
             MSTAMP(5);
-            float4 q_next = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pre) q_next = q_load(qt + 1 == qt1 ? qt0 : qt + 1);
+            QRaw q_raw;
+            if (pre) q_raw = q_fetch(qt + 1 == qt1 ? qt0 : qt + 1);       // loads in flight across the logit phase
             // ---- logits of key tile wv: u[query][key] = ((c0 + c1) + c2) + c3, transposed into UT ---------------------------------
             if (wv < RTT) {
                 const float* hp = HT + j * TS + G * TG;
@@ -777,7 +796,7 @@ __global__ __launch_bounds__(512, 2) void k_rollout_ms_mfma(DecArgs a, int S, in
                     }
                 }
             }
-            if (pre) q_store(q_next);           // QT is free since the glimpse barrier; the next tile's first barrier publishes it
+            if (pre) q_store(q_combine(q_raw)); // QT is free since the glimpse barrier; the next tile's first barrier publishes it
             have_q = pre;
             // (UT / LPSEL are rewritten by the next tile only behind its glimpse barrier, which every wavefront reaches after this
             //  finish phase; the state of these 16 starts is next read one round later, or behind the tile-start barrier)
