@@ -1,5 +1,5 @@
 """Development only: times the SDVRP re-evaluation (forward + backward) with the HIP kernels and with the PyTorch fallback
-(python tools/time_sdvrp_reeval.py N B [env])."""
+(python tools/time_reeval.py N B [env])."""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
