@@ -1309,8 +1309,8 @@ def _capture_heads(st, cache, cs, R, t_max, want_heads):
     once: it is a slower path, not an error)."""
     global _heads_skip_logged
     st.heads = st.heads_out = None
-    if not want_heads or not _lib.load().eamrl_rollout_rng_native(ENVS[st.env_name], C.byref(cs), R):
-        return
+    if not want_heads or st.env_name == "sdvrp" or not _lib.load().eamrl_rollout_rng_native(ENVS[st.env_name], C.byref(cs), R):
+        return          # (SDVRP: its re-evaluation recomputes the glimpse -- the dynamic embedding's terms are not in the capture)
     need = R * int(t_max) * cache.E * 4
     free = torch.cuda.mem_get_info(st.mask.device)[0] + torch.cuda.memory_reserved(st.mask.device) - torch.cuda.memory_allocated(st.mask.device)
     reason = None
