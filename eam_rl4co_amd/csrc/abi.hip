@@ -395,7 +395,7 @@ static int check_reeval(const eamrl_reeval* p, const char* what, bool bwd)
     REQUIRE(p, what);
     REQUIRE(reeval_supports(p->M, 128, 8), what);
     if (p->M > 112)         // key chunks: scratch from the caller, the forward pass always run, no rollout heads / dynamic embedding
-        REQUIRE(p->scratch && p->lse && !p->heads && !p->dyn && (uintptr_t)p->scratch % 16 == 0 && p->NC <= 2, what);
+        REQUIRE(p->scratch && p->lse && !p->heads && (uintptr_t)p->scratch % 16 == 0 && p->NC <= 2, what);
     REQUIRE(p->K && p->V && p->Lp && p->Pa && p->idxA && p->maskbits && p->actions && p->logp, what);
     REQUIRE((p->idxB == nullptr) == (p->Pb == nullptr) || p->Pb, what);
     REQUIRE(p->B > 0 && p->S > 0 && p->T > 0 && p->R == p->B * p->S && p->nchunk >= 1 && p->nchunk <= p->S, what);
@@ -453,7 +453,7 @@ __attribute__((visibility("default"))) int eamrl_replay_states_sdvrp(const eamrl
                                                                     int T, uint32_t* bits, int32_t* idxA, float* sc,
                                                                     float* rem_out, void* stream)
 {
-    REQUIRE(s && actions && bits && idxA && sc && rem_out && R >= 0 && M >= 2 && M <= 128 && T > 0 && ((uintptr_t)bits % 16 == 0),
+    REQUIRE(s && actions && bits && idxA && sc && rem_out && R >= 0 && M >= 2 && M <= 1024 && T > 0 && ((uintptr_t)bits % 16 == 0),
             "eamrl_replay_states_sdvrp");
     REQUIRE(s->rem && s->used && s->vcap && s->cur, "eamrl_replay_states_sdvrp (state)");
     if (R == 0) return 0;

@@ -792,9 +792,81 @@ __global__ __launch_bounds__(EB) void k_replay_sdvrp(const float* __restrict__ r
     }
 }
 
+// Graphs above 112 nodes (M <= 1024): the row in 16 registers per lane (node lane + 64 k), masks and remaining demands in the
+// chunked layout of the key-chunked re-evaluation -- bits [R][T][nkc][4], rem_out [R][T][nkc][128] (ZERO-FILLED by the caller:
+// only existing nodes are written), nkc = ceil(M / 112), node n at chunk n / 112, slot n % 112.
+__global__ __launch_bounds__(EB) void k_replay_sdvrp_big(const float* __restrict__ rem, const float* __restrict__ used,
+                                                         const float* __restrict__ vcap, const int64_t* __restrict__ cur,
+                                                         const int64_t* __restrict__ actions, uint32_t* __restrict__ bits,
+                                                         int32_t* __restrict__ idxA, float* __restrict__ sc, float* __restrict__ rem_out,
+                                                         int64_t R, int M, int T)
+{
+    __shared__ uint8_t s_ok[ROWS_PER_BLOCK][1024];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wv;
+    if (r >= R) return;
+    const int nkc = (M + 111) / 112;
+    float rr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) rr[k] = (lane + 64 * k) < M ? rem[r * M + lane + 64 * k] : 0.0f;
+    float u = used[r];
+    const float cap = vcap[r];
+    int c = (int)cur[r];
+    for (int t = 0; t < T; ++t) {
+        const int64_t q = r * T + t;
+        const bool full = u >= cap;
+        bool any_free = false;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int n = lane + 64 * k;
+            const bool ok = n >= 1 && n < M && !((rr[k] == 0.0f) | full);
+            s_ok[wv][n] = ok;
+            any_free |= __ballot(ok) != 0ull;
+            if (n < M) rem_out[(q * nkc + n / 112) * 128 + n % 112] = rr[k];
+        }
+        if (lane == 0) {
+            s_ok[wv][0] = !((c == 0) && any_free);                         // the depot
+            idxA[q] = c;
+            sc[q] = cap - u;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int wi = lane; wi < 4 * nkc; wi += 64) {                      // one 32-bit word of one chunk per lane
+            const int ch = wi >> 2, w = wi & 3;
+            uint32_t v = 0;
+            for (int i = 0; i < 32; ++i) {
+                const int li = 32 * w + i, n = 112 * ch + li;
+                if (li < 112 && n < M && s_ok[wv][n]) v |= 1u << i;
+            }
+            bits[(q * nkc + ch) * 4 + w] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- SDVRPEnv._step ------------------------------------------------------------------------------------------------------
+        int a = __builtin_amdgcn_readfirstlane((int)actions[q]);
+        a = a < 0 ? 0 : (a > M - 1 ? M - 1 : a);
+        float selv = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if ((a >> 6) == k) selv = rr[k];
+        const float sel = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, selv), a & 63));
+        const float free_cap = cap - u;
+        const float delivered = sel < free_cap ? sel : free_cap;
+        u = (u + delivered) * (a != 0 ? 1.0f : 0.0f);
+        const float left = sel + (-delivered);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (lane + 64 * k == a) rr[k] = left;
+        c = a;
+    }
+}
+
 int launch_replay_sdvrp(const float* rem, const float* used, const float* vcap, const int64_t* cur, const int64_t* actions,
                         uint32_t* bits, int32_t* idxA, float* sc, float* rem_out, int64_t R, int M, int T, hipStream_t st)
 {
+    if (M > 112) {
+        hipLaunchKernelGGL(k_replay_sdvrp_big, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(EB), 0, st, rem, used,
+                           vcap, cur, actions, bits, idxA, sc, rem_out, R, M, T);
+        return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
+    }
     hipLaunchKernelGGL(k_replay_sdvrp, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(EB), 0, st, rem, used, vcap, cur, actions, bits, idxA, sc, rem_out,
                        R, M, T);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;

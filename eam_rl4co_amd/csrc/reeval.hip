@@ -61,7 +61,6 @@ __device__ __forceinline__ float group_sum(float v)
 // a.dyn = wk | wv | lw [3][E]; a.rem [R][T][RMP] (zero padded rows, recorded by eamrl_replay_states_sdvrp); a.ddyn accumulates.
 // A tile's rem rows are staged in LDS so that lane (query j, G) reads the keys of its accumulator registers, 16 kt + 4 r + G
 // (r = 0..3), as one float4: element (q, n) at q * 16 RTT + (n >> 4) * 16 + (n & 3) * 4 + ((n & 15) >> 2).
-constexpr int RMP = 128;
 
 // wk | wv live in LDS (DYNL[2][E], filled once per workgroup) and are read where they are used: the RTT = 7 backward kernels
 // have no registers to hold a lane's 16 entries across a tile (volatile: or the compiler hoists the reads and spills instead).
@@ -135,6 +134,7 @@ __device__ __forceinline__ Q tile_query(const ReevalArgs& a, int64_t b, int s0, 
 // (b * M + n) * ld stay as they are), the mask words and the action index become chunk-local, and what a softmax needs from the
 // other chunks travels through small per-query statistics (k_reeval_mc_* below).
 constexpr int KCH = 112;
+constexpr int RMP = 128;      // floats per remaining-demand row (SDVRP), per key chunk
 struct Blk { int64_t b; int ch, c; };
 __device__ __forceinline__ Blk decode_block(const ReevalArgs& a)
 {
@@ -156,6 +156,7 @@ __device__ __forceinline__ void chunk_view(ReevalArgs& a, int64_t b, int c)
     if (a.Pb) a.Pb += adj * a.ld;
     if (a.dK) { a.dK += (adj + koff) * a.ldg; a.dV += (adj + koff) * a.ldg; a.dLp += (adj + koff) * a.ldg; }
     a.maskbits += 4 * c;
+    if (a.rem) a.rem += RMP * c;                  // SDVRP: rem [R][T][nkc][RMP], chunk-local rows
     a.mc_koff = koff;
     a.M = Mc;
 }
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
             const int jq = threadIdx.x >> 5, e4 = threadIdx.x & 31;
             const Q qq = tile_query(a, b, s0, nq, tile, jq);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qq.qi >= 0) v = *reinterpret_cast<const float4*>(a.rem + qq.qi * RMP + 4 * e4);
+            if (qq.qi >= 0) v = *reinterpret_cast<const float4*>(a.rem + qq.qi * (RMP * a.nkc) + 4 * e4);
             stage_rem<RTT>(REM, jq, e4, v, qq.qi >= 0);
         }
         const Q q = tile_query(a, b, s0, nq, tile, j);
@@ -519,10 +520,12 @@ __global__ __launch_bounds__(512, 2) void k_reeval_fwd(ReevalArgs a)
 // ---- key chunks, forward: glimpse of one chunk -> per-(query, head) partials; combine -> heads + statistics ------------------------
 // mc_part_s [(q * 8 + h) * nkc + c][2] = (maximum or -inf, sum of exp(s - maximum)) over the chunk's feasible keys,
 // mc_part_o [(q * nkc + c)][128] = sum_n exp(s_n - maximum) V[n] (unnormalised head outputs, all heads side by side)
-template <int RTT>
+template <int RTT, bool DYN = false>
 __global__ __launch_bounds__(512, 2) void k_reeval_mc_glimpse_part(ReevalArgs a)
 {
     __shared__ __attribute__((aligned(16))) float QT[16 * TS];
+    __shared__ __attribute__((aligned(16))) float REM[DYN ? 16 * 16 * RTT : 4];
+    __shared__ float DYNL[DYN ? 2 * RE : 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, G = lane >> 4;
@@ -535,18 +538,40 @@ __global__ __launch_bounds__(512, 2) void k_reeval_mc_glimpse_part(ReevalArgs a)
     const int64_t ntiles = (nq + 15) / 16;
     float kf[RTT][4], vtf[4 * RTT];
     load_head_frags<RTT>(a, b, wv, lane, kf, vtf);
+    const DynLane dl = {DYNL, wv, G};
+    if (DYN) fill_dyn_lds(a.dyn, DYNL);
     for (int64_t tile = 0; tile < ntiles; ++tile) {
         build_query_tile(a, b, s0, nq, tile, QT);
+        if (DYN) {
+            const int jq = threadIdx.x >> 5, e4 = threadIdx.x & 31;
+            const Q qq = tile_query(a, b, s0, nq, tile, jq);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qq.qi >= 0) v = *reinterpret_cast<const float4*>(a.rem + qq.qi * (RMP * a.nkc) + 4 * e4);
+            stage_rem<RTT>(REM, jq, e4, v, qq.qi >= 0);
+        }
         const Q q = tile_query(a, b, s0, nq, tile, j);
         uint4 mb = make_uint4(0, 0, 0, 0);
         if (q.qi >= 0) mb = *reinterpret_cast<const uint4*>(a.maskbits + q.qi * a.mc_mstride);
         __syncthreads();
         f32x4 s[RTT];
         float st2[2];
-        head_softmax<RTT>(kf, QT, wv, lane, mb, a.M, s, nullptr, nullptr, st2);
+        const float* remq = DYN ? rem_lane<RTT>(REM, j, G) : nullptr;
+        head_softmax<RTT, DYN>(kf, QT, wv, lane, mb, a.M, s, remq, &dl, st2);
         f32x4 o = z4();
 #pragma unroll
         for (int t = 0; t < 4 * RTT; ++t) o = mf(vtf[t], s[t >> 2][t & 3], o);
+        if (DYN) {      // + (sum_n w[n] rem[n]) wv_h, unnormalised like o (the combine scales both by exp(m_c - m) / Z)
+            float ra = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < RTT; ++kt) {
+                const f32x4 rv = rem_at(remq, kt);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ra = fmaf(s[kt][r], rv[r], ra);
+            }
+            ra = group_sum(ra);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = fmaf(ra, dl.wv_out(r), o[r]);
+        }
         if (q.qi >= 0) {
             if (G == 0) *reinterpret_cast<float2*>(a.mc_part_s + ((q.qi * RH + wv) * a.nkc + kc) * 2) = make_float2(st2[0], st2[1]);
             *reinterpret_cast<float4*>(a.mc_part_o + (q.qi * a.nkc + kc) * RE + 16 * wv + 4 * G) = make_float4(o[0], o[1], o[2], o[3]);
@@ -678,11 +703,13 @@ static int launch_fwd_mc(const ReevalArgs& a0, hipStream_t st)
     float* heads = mc_bind(a);
     const int64_t RT = a.R * (int64_t)a.T;
     const unsigned grid = (unsigned)(a.B * a.nchunk * a.nkc);
-    hipLaunchKernelGGL((k_reeval_mc_glimpse_part<7>), dim3(grid), dim3(512), 0, st, a);
+    if (a.dyn) hipLaunchKernelGGL((k_reeval_mc_glimpse_part<7, true>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_reeval_mc_glimpse_part<7>), dim3(grid), dim3(512), 0, st, a);
     hipLaunchKernelGGL(k_reeval_mc_combine_glimpse, dim3((unsigned)((RT * 32 + 255) / 256)), dim3(256), 0, st, a, heads);
     ReevalArgs l = a;
     l.heads = heads; l.heads_T = a.T;
-    hipLaunchKernelGGL((k_reeval_fwd<7, true, false, true>), dim3(grid), dim3(512), 0, st, l);
+    if (a.dyn) hipLaunchKernelGGL((k_reeval_fwd<7, true, true, true>), dim3(grid), dim3(512), 0, st, l);
+    else hipLaunchKernelGGL((k_reeval_fwd<7, true, false, true>), dim3(grid), dim3(512), 0, st, l);
     hipLaunchKernelGGL(k_reeval_mc_combine_logits, dim3((unsigned)((RT + 255) / 256)), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : EAMRL_E_LAUNCH;
 }
@@ -740,7 +767,7 @@ template <bool DH, bool DYN = false>
 __device__ __forceinline__ void load_rows(const ReevalArgs& a, int64_t b, int e4, int qi, int t, int ia, int ib, RowPre& p)
 {
     const int q = max(qi, 0);
-    if (DYN) p.rem = *reinterpret_cast<const float4*>(a.rem + (int64_t)q * RMP + 4 * e4);
+    if (DYN) p.rem = *reinterpret_cast<const float4*>(a.rem + (int64_t)q * (RMP * a.nkc) + 4 * e4);
     p.fl = (qi >= 0 ? 1 : 0) | (ia >= 0 ? 2 : 0) | (ib >= 0 ? 4 : 0) | (t >= a.tstart ? 8 : 0);
     p.pa = *reinterpret_cast<const float4*>(a.Pa + (b * a.M + max(ia, 0)) * a.ld + 4 * e4);
     p.pb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -852,6 +879,7 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
         const int th = max(w.t - a.tstart, 0);
         p.fl = (qi >= 0 ? 1 : 0) | (w.t >= a.tstart && th < a.heads_T ? 8 : 0);
         p.dh = *reinterpret_cast<const float4*>(a.heads + (r * a.heads_T + min(th, a.heads_T - 1)) * RE + 4 * e4);
+        if (DYN) p.rem = *reinterpret_cast<const float4*>(a.rem + (int64_t)max(qi, 0) * (RMP * a.nkc) + 4 * e4);
     };
     auto stage_heads = [&](const RowPre& p, int buf) {
         const bool ok = (p.fl & 9) == 9;
@@ -868,6 +896,7 @@ __global__ __launch_bounds__(512, 2) void k_reeval_bwd_logits(ReevalArgs a)
         if (HEADS) {
             load_heads(wr, pre);
             stage_heads(pre, 0);
+            if (DYN) stage_rem<RTT>(REMB, jq, e4, pre.rem, pre.fl & 1);
         } else {
             load_idx(a, qr, ia, ib);
             load_rows<false, DYN>(a, b, e4, qr, wr.t, ia, ib, pre);
@@ -1453,14 +1482,15 @@ static int launch_bwd_mc(const ReevalArgs& a0, hipStream_t st)
     const unsigned grid = (unsigned)(a.B * a.nchunk * a.nkc);
     ReevalArgs l = a;
     l.heads = heads; l.heads_T = a.T;
-    const size_t ldl = (4 * 16 * (size_t)TS + 8 * RTT * 256 + 2 * RE + 16 * RTT * DS + 16 + 32) * sizeof(float);
-    auto kl = k_reeval_bwd_logits<RTT, true>;
+    const bool dyn = a.dyn != nullptr;
+    const size_t ldl = (4 * 16 * (size_t)TS + 8 * RTT * 256 + 2 * RE + 16 * RTT * DS + 16 + 32 + (dyn ? 2 * 16 * 16 * RTT + 128 + 2 * RE : 0)) * sizeof(float);
+    auto kl = dyn ? k_reeval_bwd_logits<RTT, true, true> : k_reeval_bwd_logits<RTT, true>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldl) != hipSuccess)
         return EAMRL_E_LAUNCH;
     hipLaunchKernelGGL(kl, dim3(grid), dim3(512), ldl, st, l);
     hipLaunchKernelGGL(k_reeval_mc_sum_dheads, dim3((unsigned)((RT * 32 + 255) / 256)), dim3(256), 0, st, a, heads);
-    const size_t lds = (4 * 16 * (size_t)TS + 8 * 4 * 256 + 8 * RTT * 256 + 2 * RE + 8 * 32) * sizeof(float);
-    auto k = k_reeval_bwd_glimpse<RTT, false, true>;
+    const size_t lds = (4 * 16 * (size_t)TS + 8 * 4 * 256 + 8 * RTT * 256 + 2 * RE + 8 * 32 + (dyn ? 2 * 16 * 16 * RTT + 2 * RE : 0)) * sizeof(float);
+    auto k = dyn ? k_reeval_bwd_glimpse<RTT, true, true> : k_reeval_bwd_glimpse<RTT, false, true>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return EAMRL_E_LAUNCH;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);

@@ -492,13 +492,15 @@ def replay_states_sdvrp(st, actions):
     lib = _lib.load()
     _chk(actions, "actions", torch.int64)
     R, T = actions.shape
-    if R != st.R or st.env_name != "sdvrp" or st.M > 128:
-        raise ValueError("replay_states_sdvrp: an sdvrp state of at most 128 nodes, one action row per state row")
+    if R != st.R or st.env_name != "sdvrp" or st.M > 1024:
+        raise ValueError("replay_states_sdvrp: an sdvrp state of at most 1024 nodes, one action row per state row")
     dev = actions.device
-    bits = torch.empty(R, T, 4, dtype=torch.int32, device=dev)
+    big = st.M > KEY_CHUNK             # the chunked layout of the key-chunked re-evaluation kernels
+    nkc = -(-st.M // KEY_CHUNK)
+    bits = torch.empty((R, T, nkc, 4) if big else (R, T, 4), dtype=torch.int32, device=dev)
     idxA = torch.empty(R, T, dtype=torch.int32, device=dev)
     sc = torch.empty(1, R, T, dtype=torch.float32, device=dev)
-    rem = torch.empty(R, T, 128, dtype=torch.float32, device=dev)
+    rem = torch.zeros(R, T, nkc, 128, dtype=torch.float32, device=dev) if big else torch.empty(R, T, 128, dtype=torch.float32, device=dev)
     ss = st.struct()
     _lib.check(lib.eamrl_replay_states_sdvrp(C.byref(ss), R, st.M, _ptr(actions), T, _ptr(bits), _ptr(idxA), _ptr(sc), _ptr(rem),
                                              _stream(actions)), "eamrl_replay_states_sdvrp")
@@ -569,7 +571,7 @@ class ReevalPlan:
         # SDVRP: rem [R, T, 128] remaining demands per (row, step), dyn [3, E] = wk | wv | lw of the dynamic embedding
         self.rem = self.dyn = None
         if dyn is not None:
-            _chk(rem, "remaining demands", torch.float32, (R, T, 128))
+            _chk(rem, "remaining demands", torch.float32, (R, T, 128) if self.M <= KEY_CHUNK else (R, T, -(-self.M // KEY_CHUNK), 128))
             _chk(dyn, "dynamic embedding vectors", torch.float32, (3, self.E))
             self.rem, self.dyn = rem, dyn
             rollout_heads = None        # (the kernels recompute the glimpse for this env)

@@ -635,8 +635,7 @@ def native_reeval_supported(policy, M: int) -> bool:
 
     dec = policy.decoder
     return (os.environ.get("EAMRL_NATIVE_REEVAL", "1") != "0" and policy.env_name in _NATIVE_ENVS
-            and ops.reeval_supported(M, dec.embed_dim, dec.num_heads)
-            and not (policy.env_name == "sdvrp" and M > ops.KEY_CHUNK))       # (the dynamic embedding: single-chunk kernels only)
+            and ops.reeval_supported(M, dec.embed_dim, dec.num_heads))
 
 
 @torch.no_grad()

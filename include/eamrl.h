@@ -343,10 +343,11 @@ typedef struct eamrl_reeval {
     float *dgctx, *dCvec;                                   /* [B][E] or NULL, [NC][E]; accumulated */
     /* SDVRP only (NULL otherwise): the dynamic embedding  [nn/env_embeddings/dynamic.py:59-78] -- every step adds
      * rem[n] * (wk | wv | wl) to row n of the glimpse key / value / logit key, rem = demand_with_depot at that step.
-     * rem [R][T][128] (rows zero padded; eamrl_replay_states_sdvrp records them), dyn = wk | wv | lw [3][E] with
-     * lw = wl folded through project_out like Lp; ddyn [3][E] accumulated (backward).  Excludes `heads`. */
+     * rem [R][T][128] (rows zero padded; eamrl_replay_states_sdvrp records them; [R][T][nkc][128] with key chunks),
+     * dyn = wk | wv | lw [3][E] with lw = wl folded through project_out like Lp; ddyn [3][E] accumulated (backward).
+     * Excludes `heads`. */
     const float* rem; const float* dyn; float* ddyn;
-    /* Graphs above 112 nodes (M <= 1024; not with `heads`, `dyn` or a NULL lse): the keys are split into nkc = ceil(M / 112) chunks,
+    /* Graphs above 112 nodes (M <= 1024; not with `heads` or a NULL lse): the keys are split into nkc = ceil(M / 112) chunks,
      * one workgroup per (instance, row chunk, key chunk); the softmax statistics of the glimpse and of the logits are combined
      * across the chunks by small kernels, and the backward uses rs = heads . dheads instead of a row sum over all keys.
      * nkc <= 1: the single-chunk kernels.  Otherwise maskbits is [R][T][nkc][4] (bit i of chunk c = node 112 c + i;
@@ -514,7 +515,9 @@ int eamrl_check_solution(int env, const int64_t* actions, const float* demand, c
 int eamrl_replay_states(int env, const eamrl_state* state, int64_t R, int64_t B, int M, const int64_t* actions, int T,
                         uint32_t* bits, int32_t* idxA, float* sc, void* stream);
 /* The same for SDVRP  [sdvrp/env.py:58-92,137-146]: state->rem [R][M] (demand_with_depot), used, vcap, cur; additionally
- * rem_out [R][T][128] = the remaining demands before each step (the rows the dynamic embedding reads), zero padded. */
+ * rem_out [R][T][128] = the remaining demands before each step (the rows the dynamic embedding reads), zero padded.
+ * Graphs above 112 nodes (M <= 1024): bits [R][T][nkc][4] and rem_out [R][T][nkc][128] in the chunked layout (node n at chunk
+ * n / 112, slot n % 112); rem_out must arrive zero-filled. */
 int eamrl_replay_states_sdvrp(const eamrl_state* state, int64_t R, int M, const int64_t* actions, int T, uint32_t* bits,
                               int32_t* idxA, float* sc, float* rem_out, void* stream);
 

@@ -168,7 +168,7 @@ def test_replay_states_kernel_equals_step_by_step(env_name, N, B, ns):
     assert int((a["maskbits"] != 0).sum()) > 0
 
 
-@pytest.mark.parametrize("N,B,ns", [(20, 7, 0), (50, 3, 5), (100, 2, 4), (127, 2, 0)])
+@pytest.mark.parametrize("N,B,ns", [(20, 7, 0), (50, 3, 5), (100, 2, 4), (111, 2, 0), (150, 2, 0), (300, 2, 3)])
 def test_sdvrp_replay_kernel_equals_torch_state_loop(N, B, ns):
     """eamrl_replay_states_sdvrp (SDVRPEnv._step + get_action_mask replayed inside one kernel, sdvrp/env.py:58-92,137-146) gives
     the masks, current nodes, free capacities and remaining demands of the PyTorch step loop the fallback path runs (bit for bit:
@@ -188,13 +188,20 @@ def test_sdvrp_replay_kernel_equals_torch_state_loop(N, B, ns):
     M = N + 1
     rep = lambda x: x.repeat(S, *([1] * (x.dim() - 1)))
     cur, free, mask, rem = _sdvrp_states(acts, rep(td["demand"]), rep(td["vehicle_capacity"].reshape(-1)), M)
-    bits = got["maskbits"].cpu().numpy().astype(np.uint32)                       # [R, T, 4]
-    unpacked = ((bits[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(*bits.shape[:2], 128)[..., :M].astype(bool)
-    assert np.array_equal(unpacked, mask.cpu().numpy())
+    bits = got["maskbits"].cpu().numpy().astype(np.uint32)                       # [R, T, 4], or [R, T, nkc, 4] above 112 nodes
+    flat = ((bits[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(*bits.shape[:-1], 128).astype(bool)
+    grem = got["rem"]
+    if M > 112:      # chunked layout: node n at chunk n // 112, slot n % 112
+        nkc = -(-M // 112)
+        assert flat.shape[2] == nkc and grem.shape[2:] == (nkc, 128)
+        assert not flat[..., 112:].any() and float(grem[..., 112:].abs().max()) == 0.0
+        flat = flat[..., :112].reshape(*flat.shape[:2], nkc * 112)
+        grem = grem[..., :112].reshape(*grem.shape[:2], nkc * 112)
+    assert np.array_equal(flat[..., :M], mask.cpu().numpy()) and not flat[..., M:].any()
     assert torch.equal(got["idxA"].long(), cur)
     assert_bits_equal(got["sc"][0], free.cpu().numpy(), "free capacity")
-    assert_bits_equal(got["rem"][..., :M], rem.cpu().numpy(), "remaining demands")
-    assert (M == 128 or float(got["rem"][..., M:].abs().max()) == 0.0) and got["tstart"] == (1 if ns else 0)
+    assert_bits_equal(grem[..., :M], rem.cpu().numpy(), "remaining demands")
+    assert float(grem[..., M:].abs().max()) == 0.0 and got["tstart"] == (1 if ns else 0)
 
 
 @pytest.mark.parametrize("env_name,cfg,N", [("tsp", "pomo_tsp", 20), ("cvrp", "am_cvrp", 20)])
@@ -550,6 +557,7 @@ def test_linear_autograd_function_matches_torch(relu, with_res):
     ("am_tsp", "tsp", 150, 3, 0, None), ("am_tsp", "tsp", 200, 2, 4, None), ("am_cvrp", "cvrp", 120, 3, 0, None),
     ("am_cvrp", "cvrp", 230, 2, 3, None), ("am_tsp", "tsp", 500, 1, 2, None), ("am_op", "op", 130, 2, 0, None),
     ("am_pctsp", "pctsp", 150, 2, 3, None), ("am_cvrptw", "cvrptw", 120, 2, 0, None),
+    ("am_sdvrp", "sdvrp", 130, 2, 0, None), ("am_sdvrp", "sdvrp", 240, 2, 3, None),
     # SDVRP: the dynamic embedding's rank-one terms (remaining demands per step) in all three kernels
     ("am_sdvrp", "sdvrp", 20, 5, 0, None), ("am_sdvrp", "sdvrp", 50, 3, 6, None), ("am_sdvrp", "sdvrp", 100, 2, 3, None),
     # the gather kernel's cooperative bins (the depot of CVRP names > 512 queries of an instance) and its own chunking
