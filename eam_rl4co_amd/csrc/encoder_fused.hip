@@ -105,10 +105,13 @@ __device__ __forceinline__ void load_b0(float4 (&b0)[CT], const float* const (&w
 // SWAP: the MFMA takes the weight fragment as A and the activation fragment as B, so that acc[rt][ct] holds the TRANSPOSED
 // tile (lane = node row, registers = 4 consecutive output columns): the same products in the same k order, laid out for
 // float4 stores to row-major memory.
-template <int RTW, int CT, int S, bool SWAP = false>
-__device__ __forceinline__ void gemm_pass(f32x4 (&acc)[RTW][CT], const float* arow, int nrt, const float* const (&wp)[CT],
-                                          int NU, const float4 (&b0)[CT])
+// NRT: this wave's row tiles as a compile-time value (round 3: as a run-time count every k-step group carried a uniform branch
+// around the last tile's loads and MFMAs plus the register copies that merge the two paths)
+template <int RTW, int CT, int S, bool SWAP, int NRT>
+__device__ __forceinline__ void gemm_pass_n(f32x4 (&acc)[RTW][CT], const float* arow, const float* const (&wp)[CT],
+                                            int NU, const float4 (&b0)[CT])
 {
+    constexpr int nrt = NRT;
     float4 bn[CT];
     float2 an0[RTW], an1[RTW];
 #pragma unroll
@@ -155,6 +158,14 @@ __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[RTW][CT], const float* ar
     }
 }
 
+// nrt is one of two values per kernel variant: RTW (the first row half) or NLOW (the second)
+template <int RTW, int CT, int S, bool SWAP = false, int NLOW = RTW>
+__device__ __forceinline__ void gemm_pass(f32x4 (&acc)[RTW][CT], const float* arow, int nrt, const float* const (&wp)[CT],
+                                          int NU, const float4 (&b0)[CT])
+{
+    if (NLOW == RTW || nrt == RTW) gemm_pass_n<RTW, CT, S, SWAP, RTW>(acc, arow, wp, NU, b0);
+    else gemm_pass_n<RTW, CT, S, SWAP, NLOW>(acc, arow, wp, NU, b0);
+}
 
 // y = norm(res + acc) for the two column tiles of a wave, written back to HB in place (batch norm: per-column affine;
 // instance norm: the sums are written here and normalised per channel after a barrier).
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
                     for (int rt = 0; rt < RTW; ++rt) acc[rt][x] = splat4(b);
                 }
                 ESTAMP(16);
-                gemm_pass<RTW, 3, SA>(acc, HB + (row0 + j) * SA + G * GA, nrt, wp, FE / 16, b0);
+                gemm_pass<RTW, 3, SA, false, RTT - RTA>(acc, HB + (row0 + j) * SA + G * GA, nrt, wp, FE / 16, b0);
                 ESTAMP(17);
                 load_b0<2>(b3, wp3);
                 // q (scaled) and k in the A layout of the 64-column buffers: column 16 cw + j -> (g = j & 3, t = 4 cw + (j >> 2))
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
             __syncthreads();
             ESTAMP(4);
             // ---- P3: out_proj partial over the 64 attention columns of this head group ------------------------------
-            gemm_pass<RTW, 2, SQ>(acc_o, QA + (row0 + j) * SQ + G * 16, nrt, wp3, 4, b3);
+            gemm_pass<RTW, 2, SQ, false, RTT - RTA>(acc_o, QA + (row0 + j) * SQ + G * 16, nrt, wp3, 4, b3);
             ESTAMP(5);
             __syncthreads();
             ESTAMP(6);
@@ -510,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
                     for (int rt = 0; rt < RTW; ++rt) acc[rt][ct] = splat4(b);
                 }
                 ESTAMP(14);
-                gemm_pass<RTW, 2, SA>(acc, HB + (row0 + j) * SA + G * GA, nrt, wp, FE / 16, b0);
+                gemm_pass<RTW, 2, SA, false, RTT - RTA>(acc, HB + (row0 + j) * SA + G * GA, nrt, wp, FE / 16, b0);
                 ESTAMP(15);
                 load_b0<2>(b5, wp5);           // P5's first weights fly during the epilogue and the barrier
 #pragma unroll
@@ -532,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
             __syncthreads();
             ESTAMP(9);
             // P5: ffn2 accumulators += hidden chunk x W2[:, 128 ch .. 128 ch + 127]^T
-            gemm_pass<RTW, 2, SA>(acc_f, HID + (row0 + j) * SA + G * GA, nrt, wp5, 8, b5);
+            gemm_pass<RTW, 2, SA, false, RTT - RTA>(acc_f, HID + (row0 + j) * SA + G * GA, nrt, wp5, 8, b5);
             ESTAMP(10);
             __syncthreads();
             ESTAMP(11);
@@ -598,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void k_encoder_fused(FusedArgs a)
 #pragma unroll
                 for (int rt = 0; rt < RTW; ++rt) acc[rt][ct] = splat4(0.0f);
             if (lp) __syncthreads();               // every wave's part of L is in STG
-            gemm_pass<RTW, 2, SA, true>(acc, (lp ? STG : HB) + (row0 + j) * SA + G * GA, nrt, wp, FE / 16, b0);
+            gemm_pass<RTW, 2, SA, true, RTT - RTA>(acc, (lp ? STG : HB) + (row0 + j) * SA + G * GA, nrt, wp, FE / 16, b0);
             // transposed tiles: lane = node row0 + 16 rt + j, registers = output columns 32 cw + 16 ct + 4 G + (0..3)
 #pragma unroll
             for (int rt = 0; rt < RTW; ++rt)
